@@ -1,0 +1,339 @@
+// eco_conv.hip -- N-D convolution forward as an implicit-GEMM fp32-MFMA kernel for gfx950,
+// with the bias / Eltwise-SUM residual / folded-BN / ReLU epilogue and strided
+// (Concat-slice, r2Dto3D+Permute) stores fused in.
+//
+// Replaces, for the forward path, the reference's per-image im2col + SGEMM + bias-GEMM
+//   ConvolutionLayer::Forward_{cpu,gpu}      caffe_3d/src/caffe/layers/conv_layer.cpp:28-43
+//   BaseConvolutionLayer::forward_*_gemm/bias layers/base_conv_layer.cpp:264-287
+//   im2col_cpu / im2col_nd_core_cpu           util/im2col.cpp:27-64, 91-158
+//   (GPU: im2col_gpu_kernel / im2col_nd_gpu_kernel util/im2col.cu:12-161, cuDNN conv
+//    layers/cudnn_conv_layer.cu:15-65)
+// and the layers the executor fuses behind it (BN bn_layer.cpp:93-207, ReLU
+// relu_layer.cpp:10-20, Eltwise eltwise_layer.cpp:66-72, Concat concat_layer.cpp:54-70,
+// Reshape+Permute reshape_layer.cpp:88 / permute_layer.cpp:9-26).
+//
+// GEMM view (no col buffer is ever materialised):
+//   Y[m, n] = sum_k Wp[k, m] * X[base(n) + koff(k)] * valid(n, tap(k))
+//   m = output channel, n = flattened (image, od, oh, ow) output position,
+//   k = c*taps + tap  (the reference's own weight order [cout][cin][kd][kh][kw]).
+// Per workgroup (256 threads = 4 waves): a BM x BN output tile; the reduction runs in
+// stages of KC rows.  Each stage: Wp rows are fetched as float4 (packed K-major, so rows
+// are contiguous), the im2col rows are *gathered* straight from the NC[D]HW input with a
+// per-position validity bit mask (zero padding) and a per-k offset table, both are staged
+// through double-buffered LDS, and every wave accumulates TM x TN 32x32 tiles with
+// v_mfma_f32_32x32x2_f32.  LDS layout is [k][m] / [k][n], so a wave's A/B fragment reads
+// are 32 consecutive floats per half-wave: bank-conflict free ds_read_b32.
+// Output tile: lane = output position (32 consecutive positions per half-wave), register =
+// output channel -> each store instruction writes 128 contiguous bytes per half-wave into
+// the N,C,[D,]H,W destination.
+#include <string.h>
+
+#include "eco_common.h"
+
+namespace eco {
+
+struct ConvKernelArgs {
+  const float* x;
+  const float* wp;
+  const int32_t* ktab;
+  const float* bias;
+  const float* bn_scale;
+  const float* bn_shift;
+  eco_view residual, raw, act;
+  int relu;
+  int cin, cout, mpad, kpad;
+  int Di, Hi, Wi, Do, Ho, Wo;
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+  int s_in, s_out;      // Di*Hi*Wi, Do*Ho*Wo
+  long img_stride_in;   // cin * s_in
+  int ntot;             // n * s_out output positions
+  int nblk_m, nblk_n;
+};
+
+constexpr int kKoffBits = 26;
+constexpr int kKoffMask = (1 << kKoffBits) - 1;
+constexpr int kNeverTap = 63;  // validity-mask bit that is never set (used by K padding)
+
+__device__ __forceinline__ long view_base(const eco_view& v, int img, int sp) {
+  const int b = img / v.t, t = img - b * v.t;
+  return (long)b * v.stride_b + (long)t * v.stride_t + sp;
+}
+
+template <int TM, int TN, int WM, int WN, int KC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKernelArgs a) {
+  constexpr int BM = 32 * TM * WM;
+  constexpr int BN = 32 * TN * WN;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(BN == 64 || BN == 128 || BN == 256, "BN must divide 256 and be a multiple of the wave");
+  static_assert(KC % 2 == 0, "MFMA 32x32x2 consumes k in pairs");
+  constexpr int KG = 256 / BN;  // threads sharing one output position in the gather
+  constexpr int EPT = KC / KG;  // gathered elements per thread per stage
+  static_assert(KC % KG == 0, "");
+  constexpr int A_F4 = KC * BM / 4;
+  constexpr int A_ITERS = (A_F4 + 255) / 256;
+
+  __shared__ __attribute__((aligned(16))) float As[2][KC][BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][KC][BN];
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
+  const int m0 = mblk * BM, n0 = nblk * BN;
+
+  // ---- gather role of this thread: one output position, EPT of the stage's KC rows ----
+  const int pos_l = tid % BN;
+  const int kg = uniform(tid / BN);
+  long in_base = 0;
+  unsigned long long mask = 0ull;
+  {
+    const int n = n0 + pos_l;
+    if (n < a.ntot) {
+      const int img = n / a.s_out, sp = n - img * a.s_out;
+      const int ow = sp % a.Wo, t = sp / a.Wo;
+      const int oh = t % a.Ho, od = t / a.Ho;
+      const int id0 = od * a.sd - a.pd, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
+      in_base = (long)img * a.img_stride_in + ((long)id0 * a.Hi + ih0) * a.Wi + iw0;
+      int tap = 0;
+      for (int z = 0; z < a.kd; ++z)
+        for (int y = 0; y < a.kh; ++y)
+          for (int xx = 0; xx < a.kw; ++xx, ++tap) {
+            const bool ok = (unsigned)(id0 + z) < (unsigned)a.Di && (unsigned)(ih0 + y) < (unsigned)a.Hi &&
+                            (unsigned)(iw0 + xx) < (unsigned)a.Wi;
+            mask |= (unsigned long long)ok << tap;
+          }
+    }
+  }
+
+  float4 areg[A_ITERS];
+  float breg[EPT];
+
+  auto load_stage = [&](int chunk) {
+    const int k0 = chunk * KC;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < A_F4) {
+        const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+        areg[i] = ld((const float4*)(a.wp + (long)(k0 + row) * a.mpad + m0 + c4 * 4));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const int kt = ld(a.ktab + k0 + kg + j * KG);
+      const int off = kt & kKoffMask;
+      const unsigned tap = (unsigned)kt >> kKoffBits;
+      const bool ok = (mask >> tap) & 1ull;
+      const float v = ld(a.x + (ok ? in_base + off : 0l));
+      breg[j] = ok ? v : 0.0f;
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < A_F4) {
+        const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+        *(float4*)&As[buf][row][c4 * 4] = areg[i];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) Bs[buf][kg + j * KG][pos_l] = breg[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int nchunks = a.kpad / KC;
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) load_stage(c + 1);  // global loads stay in flight under the MFMAs
+#pragma unroll
+    for (int kk = 0; kk < KC / 2; ++kk) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = As[buf][2 * kk + half][(wm * TM + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][2 * kk + half][(wn * TN + j) * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(af[i], bf[j], acc[i][j]);
+    }
+    if (c + 1 < nchunks) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, residual, raw store, folded BN, ReLU, activated store ----
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + l31;
+    if (n >= a.ntot) continue;
+    const int img = n / a.s_out, sp = n - img * a.s_out;
+    const long res_base = a.residual.ptr ? view_base(a.residual, img, sp) : 0;
+    const long raw_base = a.raw.ptr ? view_base(a.raw, img, sp) : 0;
+    const long act_base = a.act.ptr ? view_base(a.act, img, sp) : 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (ch >= a.cout) continue;
+        float v = acc[i][j][r];
+        if (a.bias) v += ld(a.bias + ch);
+        if (a.residual.ptr) v += ld((const float*)a.residual.ptr + res_base + (long)ch * a.residual.stride_c);
+        if (a.raw.ptr) st(a.raw.ptr + raw_base + (long)ch * a.raw.stride_c, v);
+        if (a.act.ptr) {
+          float y = a.bn_scale ? v * ld(a.bn_scale + ch) + ld(a.bn_shift + ch) : v;
+          if (a.relu) y = fmaxf(y, 0.0f);
+          st(a.act.ptr + act_base + (long)ch * a.act.stride_c, y);
+        }
+      }
+    }
+  }
+}
+
+static int validate_geom(const eco_conv_geom* g) {
+  ECO_REQUIRE(g != nullptr, "conv: null geometry");
+  ECO_REQUIRE(g->n > 0 && g->cin > 0 && g->cout > 0, "conv: n/cin/cout must be positive (n=%d cin=%d cout=%d)",
+              g->n, g->cin, g->cout);
+  long taps = 1;
+  for (int i = 0; i < 3; ++i) {
+    ECO_REQUIRE(g->in[i] > 0 && g->kernel[i] > 0 && g->stride[i] > 0 && g->pad[i] >= 0,
+                "conv: Filter/stride dimensions must be nonzero (axis %d)", i);
+    const int o = (g->in[i] + 2 * g->pad[i] - g->kernel[i]) / g->stride[i] + 1;
+    ECO_REQUIRE(g->in[i] + 2 * g->pad[i] >= g->kernel[i] && o == g->out[i],
+                "conv: output dim %d is %d, expected (in+2*pad-kernel)/stride+1 = %d", i, g->out[i], o);
+    taps *= g->kernel[i];
+  }
+  ECO_REQUIRE(taps < kNeverTap, "conv: %ld kernel taps exceed the 63-tap validity mask", taps);
+  const long s_in = (long)g->in[0] * g->in[1] * g->in[2];
+  const long s_out = (long)g->out[0] * g->out[1] * g->out[2];
+  ECO_REQUIRE((long)g->cin * s_in <= kKoffMask, "conv: per-image input (%ld elems) exceeds the 2^26 gather-offset range",
+              (long)g->cin * s_in);
+  ECO_REQUIRE((long)g->n * s_out < 2147483647l, "conv: too many output positions for int32 indexing");
+  return ECO_OK;
+}
+
+}  // namespace eco
+
+using namespace eco;
+
+extern "C" int eco_conv_plan_create(const eco_conv_geom* g, eco_conv_plan* plan) {
+  clear_error();
+  if (int rc = validate_geom(g)) return rc;
+  ECO_REQUIRE(plan != nullptr, "conv: null plan");
+  int bm;
+  if (g->cout <= 32) bm = 32;
+  else if (g->cout <= 64) bm = 64;
+  else if (g->cout <= 96) bm = 96;
+  else {
+    bm = 128;
+    long best = ceil_div(g->cout, 128) * 128;
+    const int cands[2] = {96, 64};
+    for (int c : cands) {
+      const long padded = ceil_div(g->cout, c) * c;
+      if (padded < best) { best = padded; bm = c; }
+    }
+  }
+  plan->bm = bm;
+  plan->bn = (bm == 128) ? 128 : 256;
+  plan->kc = 16;
+  plan->k = g->cin * g->kernel[0] * g->kernel[1] * g->kernel[2];
+  plan->kpad = (int)(ceil_div(plan->k, plan->kc) * plan->kc);
+  plan->mpad = (int)(ceil_div(g->cout, 128) * 128);
+  if (plan->mpad < ceil_div(g->cout, bm) * bm) plan->mpad = (int)(ceil_div(g->cout, bm) * bm);
+  plan->mpad = (int)(ceil_div(plan->mpad, 4) * 4);
+  plan->wp_elems = (int64_t)plan->kpad * plan->mpad;
+  plan->ktab_elems = plan->kpad;
+  return ECO_OK;
+}
+
+extern "C" int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan* plan, const float* w,
+                                     float* wp, int32_t* ktab) {
+  clear_error();
+  if (int rc = validate_geom(g)) return rc;
+  ECO_REQUIRE(plan && w && wp && ktab, "conv pack: null argument");
+  const int taps = g->kernel[0] * g->kernel[1] * g->kernel[2];
+  const int K = g->cin * taps;
+  ECO_REQUIRE(plan->k == K && plan->kpad >= K && plan->mpad >= g->cout, "conv pack: plan does not match geometry");
+  const long s_in = (long)g->in[0] * g->in[1] * g->in[2];
+  memset(wp, 0, sizeof(float) * (size_t)plan->wp_elems);
+  for (int k = 0; k < plan->kpad; ++k) {
+    if (k >= K) {
+      ktab[k] = (int32_t)((unsigned)kNeverTap << kKoffBits);
+      continue;
+    }
+    const int c = k / taps, tap = k % taps;
+    const int kx = tap % g->kernel[2], ky = (tap / g->kernel[2]) % g->kernel[1], kz = tap / (g->kernel[2] * g->kernel[1]);
+    const long off = (long)c * s_in + ((long)kz * g->in[1] + ky) * g->in[2] + kx;
+    ktab[k] = (int32_t)(((unsigned)tap << kKoffBits) | (unsigned)off);
+    float* row = wp + (long)k * plan->mpad;
+    for (int m = 0; m < g->cout; ++m) row[m] = w[(long)m * K + k];
+  }
+  return ECO_OK;
+}
+
+template <int TM, int TN, int WM, int WN, int KC>
+static int launch_conv(const ConvKernelArgs& a, hipStream_t stream) {
+  const int grid = a.nblk_m * a.nblk_n;
+  hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WM, WN, KC>), dim3(grid), dim3(256), 0, stream, a);
+  return check_launch("eco_conv_forward");
+}
+
+static int check_view(const eco_view& v, const char* what) {
+  if (!v.ptr) return ECO_OK;
+  ECO_REQUIRE(v.t >= 1 && v.stride_c >= 1, "conv: %s view needs t >= 1 and stride_c >= 1", what);
+  return ECO_OK;
+}
+
+extern "C" int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* plan, const float* x, const float* wp,
+                                const int32_t* ktab, const eco_conv_epilogue* ep, void* stream) {
+  clear_error();
+  if (int rc = validate_geom(g)) return rc;
+  ECO_REQUIRE(plan && x && wp && ktab && ep, "conv: null argument");
+  ECO_REQUIRE(ep->raw.ptr || ep->act.ptr, "conv: at least one of raw/act outputs is required");
+  ECO_REQUIRE(!ep->bn_scale == !ep->bn_shift, "conv: bn_scale and bn_shift must be given together");
+  if (int rc = check_view(ep->residual, "residual")) return rc;
+  if (int rc = check_view(ep->raw, "raw")) return rc;
+  if (int rc = check_view(ep->act, "act")) return rc;
+  ECO_REQUIRE(plan->k == g->cin * g->kernel[0] * g->kernel[1] * g->kernel[2] && plan->kc == 16 &&
+                  plan->kpad % plan->kc == 0 && plan->mpad % 4 == 0,
+              "conv: plan does not match geometry");
+  ConvKernelArgs a;
+  a.x = x; a.wp = wp; a.ktab = ktab;
+  a.bias = ep->bias; a.bn_scale = ep->bn_scale; a.bn_shift = ep->bn_shift;
+  a.residual = ep->residual; a.raw = ep->raw; a.act = ep->act; a.relu = ep->relu;
+  a.cin = g->cin; a.cout = g->cout; a.mpad = plan->mpad; a.kpad = plan->kpad;
+  a.Di = g->in[0]; a.Hi = g->in[1]; a.Wi = g->in[2];
+  a.Do = g->out[0]; a.Ho = g->out[1]; a.Wo = g->out[2];
+  a.kd = g->kernel[0]; a.kh = g->kernel[1]; a.kw = g->kernel[2];
+  a.sd = g->stride[0]; a.sh = g->stride[1]; a.sw = g->stride[2];
+  a.pd = g->pad[0]; a.ph = g->pad[1]; a.pw = g->pad[2];
+  a.s_in = a.Di * a.Hi * a.Wi; a.s_out = a.Do * a.Ho * a.Wo;
+  a.img_stride_in = (long)a.cin * a.s_in;
+  a.ntot = g->n * a.s_out;
+  a.nblk_m = (int)ceil_div(g->cout, plan->bm);
+  a.nblk_n = (int)ceil_div(a.ntot, plan->bn);
+  ECO_REQUIRE((long)a.nblk_m * plan->bm <= plan->mpad, "conv: plan mpad too small for bm");
+  hipStream_t s = (hipStream_t)stream;
+  switch (plan->bm) {
+    case 128: ECO_REQUIRE(plan->bn == 128, "conv: bad plan"); return launch_conv<2, 2, 2, 2, 16>(a, s);
+    case 96: ECO_REQUIRE(plan->bn == 256, "conv: bad plan"); return launch_conv<3, 2, 1, 4, 16>(a, s);
+    case 64: ECO_REQUIRE(plan->bn == 256, "conv: bad plan"); return launch_conv<2, 2, 1, 4, 16>(a, s);
+    case 32: ECO_REQUIRE(plan->bn == 256, "conv: bad plan"); return launch_conv<1, 2, 1, 4, 16>(a, s);
+    default: return fail(ECO_ERR_INVALID, "conv: unsupported block tile bm=%d", plan->bm);
+  }
+}

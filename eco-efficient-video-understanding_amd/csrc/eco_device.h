@@ -1,0 +1,98 @@
+// eco_device.h -- device-side helpers shared by the ECO kernels (gfx950 / CDNA4).
+//
+// Written for gfx950 only: wave = 64 lanes, fp32 MFMA 32x32x2.  The ECO_EMU branch
+// is not a second GPU backend; it binds the same kernel source to the CPU fiber
+// emulator in tests/emu/ so the CPU test-suite can run the kernels' index math.
+#pragma once
+
+#ifdef ECO_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace eco {
+
+constexpr int kWave = 64;
+
+// D(32x32) += A(32x2) * B(2x32), fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32).
+// Lane l supplies a = A[l&31][l>>5], b = B[l>>5][l&31]; reg r of the result is
+// D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+__device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+#ifdef ECO_EMU
+  return emu::mfma_f32_32x32x2f32(a, b, c);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
+}
+
+// Make a wave-uniform value provably uniform (SGPR) for the compiler.
+__device__ __forceinline__ int uniform(int v) {
+#ifdef ECO_EMU
+  return emu::readfirstlane(v);
+#else
+  return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
+__device__ __forceinline__ int lane_id() {
+#ifdef ECO_EMU
+  return emu::tls_cur->lane;
+#else
+  return (int)(threadIdx.x & 63u);
+#endif
+}
+
+__device__ __forceinline__ float shfl_xor(float v, int mask) {
+#ifdef ECO_EMU
+  return emu::wave_xchg_f32(v, emu::tls_cur->lane ^ mask);
+#else
+  return __shfl_xor(v, mask, 64);
+#endif
+}
+
+// Butterfly reductions over the 64 lanes of a wave; every lane gets the result.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
+  return v;
+}
+
+// Global-memory accessors.  On the GPU these are plain loads/stores; under the
+// emulator they are bounds-checked against the registered "device" buffers.
+template <typename T>
+__device__ __forceinline__ T ld(const T* p) {
+#ifdef ECO_EMU
+  if (!emu::check_access(p, sizeof(T), false)) return T{};
+#endif
+  return *p;
+}
+template <typename T>
+__device__ __forceinline__ void st(T* p, T v) {
+#ifdef ECO_EMU
+  if (!emu::check_access(p, sizeof(T), true)) return;
+#endif
+  *p = v;
+}
+
+// XCD-aware workgroup remap (MI355X: 8 XCDs, hardware places block b on XCD b % 8, each
+// XCD has a private 4 MiB L2).  Returns the logical tile id for hardware block `b` such
+// that each XCD works on a contiguous range of logical tiles; bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  constexpr int kXcd = 8;
+  const int q = nwg / kXcd, r = nwg % kXcd;
+  const int xcd = b % kXcd, idx = b / kXcd;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+}  // namespace eco

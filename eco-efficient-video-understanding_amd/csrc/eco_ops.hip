@@ -1,0 +1,342 @@
+// eco_ops.hip -- the memory-bound operators of the ECO path as stand-alone gfx950 kernels:
+// pooling (2-D / 3-D, MAX / AVE), folded BN (+ReLU), ReLU, Eltwise SUM, Concat copy,
+// Permute, InnerProduct, the fused global-avg-pool + fc tail, Softmax.
+// Reference operators are cited at each entry point in include/eco_hip.h.
+// All of these are HBM/L2-bandwidth bound: consecutive lanes touch consecutive addresses,
+// reductions use 64-lane butterfly shuffles (no LDS round trip), nothing is reshaped into
+// a GEMM.
+#include <float.h>
+
+#include "eco_common.h"
+
+namespace eco {
+
+constexpr int kThreads = 256;
+
+static inline int grid_for(long count, long per_block = kThreads) {
+  long g = ceil_div(count, per_block);
+  if (g < 1) g = 1;
+  if (g > 1048576) g = 1048576;  // grid-stride beyond this
+  return (int)g;
+}
+
+// ---------------------------------------------------------------------------- pooling
+struct PoolArgs {
+  const float* x;
+  float* y;
+  long total;  // n*c*Do*Ho*Wo
+  int Di, Hi, Wi, Do, Ho, Wo;
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+  int method;
+};
+
+__global__ __launch_bounds__(256) void pool_kernel(const PoolArgs a) {
+  const long s_in = (long)a.Di * a.Hi * a.Wi;
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < a.total; i += (long)gridDim.x * kThreads) {
+    const int ow = (int)(i % a.Wo);
+    long t = i / a.Wo;
+    const int oh = (int)(t % a.Ho);
+    t /= a.Ho;
+    const int od = (int)(t % a.Do);
+    const long nc = t / a.Do;
+    const float* xp = a.x + nc * s_in;
+    int ds = od * a.sd - a.pd, hs = oh * a.sh - a.ph, ws = ow * a.sw - a.pw;
+    float r;
+    if (a.method == ECO_POOL_MAX) {
+      const int de = min(ds + a.kd, a.Di), he = min(hs + a.kh, a.Hi), we = min(ws + a.kw, a.Wi);
+      ds = max(ds, 0); hs = max(hs, 0); ws = max(ws, 0);
+      r = -FLT_MAX;
+      for (int d = ds; d < de; ++d)
+        for (int h = hs; h < he; ++h)
+          for (int w = ws; w < we; ++w) r = fmaxf(r, ld(xp + ((long)d * a.Hi + h) * a.Wi + w));
+    } else {
+      int de = min(ds + a.kd, a.Di + a.pd), he = min(hs + a.kh, a.Hi + a.ph), we = min(ws + a.kw, a.Wi + a.pw);
+      const float size = (float)((de - ds) * (he - hs) * (we - ws));
+      ds = max(ds, 0); hs = max(hs, 0); ws = max(ws, 0);
+      de = min(de, a.Di); he = min(he, a.Hi); we = min(we, a.Wi);
+      r = 0.0f;
+      for (int d = ds; d < de; ++d)
+        for (int h = hs; h < he; ++h)
+          for (int w = ws; w < we; ++w) r += ld(xp + ((long)d * a.Hi + h) * a.Wi + w);
+      r /= size;
+    }
+    st(a.y + i, r);
+  }
+}
+
+// Whole-volume average (global_pool): one wave per (n,c) row, butterfly reduction.
+__global__ __launch_bounds__(256) void global_avg_kernel(const float* x, float* y, long rows, int s) {
+  const int lane = lane_id();
+  const int wave = uniform((int)(threadIdx.x >> 6));
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const float* xp = x + row * s;
+    float acc = 0.0f;
+    for (int i = lane; i < s; i += kWave) acc += ld(xp + i);
+    acc = wave_sum(acc);
+    if (lane == 0) st(y + row, acc / (float)s);
+  }
+}
+
+// ---------------------------------------------------------------------------- elementwise
+__global__ __launch_bounds__(256) void bn_kernel(const float* x, float* y, const float* scale, const float* shift,
+                                                 long total, long c, long inner, int relu) {
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+    const long ch = (i / inner) % c;
+    float v = ld(x + i) * ld(scale + ch) + ld(shift + ch);
+    if (relu) v = fmaxf(v, 0.0f);
+    st(y + i, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void relu_kernel(const float* x, float* y, long total, float slope) {
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+    const float v = ld(x + i);
+    st(y + i, fmaxf(v, 0.0f) + slope * fminf(v, 0.0f));
+  }
+}
+
+__global__ __launch_bounds__(256) void eltwise_sum_kernel(const float* a, const float* b, float* y, long total,
+                                                          float ca, float cb) {
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads)
+    st(y + i, ca * ld(a + i) + cb * ld(b + i));
+}
+
+__global__ __launch_bounds__(256) void concat_copy_kernel(const float* x, float* y, long total, long cx, long cy,
+                                                          long c0, long inner) {
+  const long per_outer = cx * inner;
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+    const long o = i / per_outer, r = i - o * per_outer;
+    st(y + (o * cy + c0) * inner + r, ld(x + i));
+  }
+}
+
+struct PermuteArgs {
+  const float* x;
+  float* y;
+  long total;
+  int naxes;
+  int out_shape[6];
+  long in_stride_of_out_axis[6];
+};
+
+__global__ __launch_bounds__(256) void permute_kernel(const PermuteArgs a) {
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < a.total; i += (long)gridDim.x * kThreads) {
+    long rem = i, src = 0;
+    for (int ax = a.naxes - 1; ax >= 0; --ax) {
+      const long idx = rem % a.out_shape[ax];
+      rem /= a.out_shape[ax];
+      src += idx * a.in_stride_of_out_axis[ax];
+    }
+    st(a.y + i, ld(a.x + src));
+  }
+}
+
+// ---------------------------------------------------------------------------- fc / tail
+// One wave per output element: lanes stride over K, butterfly-reduce.
+__global__ __launch_bounds__(256) void inner_product_kernel(const float* x, const float* w, const float* bias,
+                                                            float* y, long m, long n, long k) {
+  const int lane = lane_id();
+  const int wave = uniform((int)(threadIdx.x >> 6));
+  const long total = m * n;
+  for (long o = (long)blockIdx.x * 4 + wave; o < total; o += (long)gridDim.x * 4) {
+    const long mi = o / n, ni = o - mi * n;
+    const float* xp = x + mi * k;
+    const float* wp = w + ni * k;
+    float acc = 0.0f;
+    for (long i = lane; i < k; i += kWave) acc += ld(xp + i) * ld(wp + i);
+    acc = wave_sum(acc);
+    if (lane == 0) st(y + o, acc + (bias ? ld(bias + ni) : 0.0f));
+  }
+}
+
+constexpr int kTailMaxC = 2048;
+constexpr int kTailOutPerBlock = 64;
+
+// grid = (ceil(n_out / 64), b).  Each workgroup pools its clip's C channels into LDS
+// (wave per channel, butterfly reduce), then its 4 waves produce 64 logits.
+__global__ __launch_bounds__(256) void global_avgpool_fc_kernel(const float* x, const float* w, const float* bias,
+                                                                float* y, int c, int s, int n_out, int wk, int c0,
+                                                                int accumulate) {
+  __shared__ float pooled[kTailMaxC];
+  const int lane = lane_id();
+  const int wave = uniform((int)(threadIdx.x >> 6));
+  const int b = (int)blockIdx.y;
+  const float* xb = x + (long)b * c * s;
+  const float inv = 1.0f / (float)s;
+  for (int ch = wave; ch < c; ch += 4) {
+    const float* xp = xb + (long)ch * s;
+    float acc = 0.0f;
+    for (int i = lane; i < s; i += kWave) acc += ld(xp + i);
+    acc = wave_sum(acc);
+    if (lane == 0) pooled[ch] = acc * inv;
+  }
+  __syncthreads();
+  const int o_begin = (int)blockIdx.x * kTailOutPerBlock;
+  const int o_end = min(o_begin + kTailOutPerBlock, n_out);
+  for (int o = o_begin + wave; o < o_end; o += 4) {
+    const float* wr = w + (long)o * wk + c0;
+    float acc = 0.0f;
+    for (int i = lane; i < c; i += kWave) acc += pooled[i] * ld(wr + i);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      float* yp = y + (long)b * n_out + o;
+      float v = acc + (bias ? ld(bias + o) : 0.0f);
+      if (accumulate) v += ld((const float*)yp);
+      st(yp, v);
+    }
+  }
+}
+
+// Softmax over axis 1 of [outer, c, inner]: one thread per (outer, inner) column.
+__global__ __launch_bounds__(256) void softmax_kernel(const float* x, float* y, long outer, long c, long inner) {
+  const long total = outer * inner;
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+    const long o = i / inner, in = i - o * inner;
+    const float* xp = x + o * c * inner + in;
+    float* yp = y + o * c * inner + in;
+    float m = -FLT_MAX;
+    for (long j = 0; j < c; ++j) m = fmaxf(m, ld(xp + j * inner));
+    float sum = 0.0f;
+    for (long j = 0; j < c; ++j) sum += expf(ld(xp + j * inner) - m);
+    for (long j = 0; j < c; ++j) st(yp + j * inner, expf(ld(xp + j * inner) - m) / sum);
+  }
+}
+
+}  // namespace eco
+
+using namespace eco;
+
+extern "C" int eco_pool_forward(const eco_pool_geom* g, const float* x, float* y, void* stream) {
+  clear_error();
+  ECO_REQUIRE(g && x && y, "pool: null argument");
+  ECO_REQUIRE(g->n > 0 && g->c > 0, "pool: n and c must be positive");
+  ECO_REQUIRE(g->method == ECO_POOL_MAX || g->method == ECO_POOL_AVE, "pool: unknown pooling method %d", g->method);
+  bool global = true;
+  for (int i = 0; i < 3; ++i) {
+    ECO_REQUIRE(g->in[i] > 0 && g->kernel[i] > 0 && g->stride[i] > 0 && g->pad[i] >= 0 && g->out[i] > 0,
+                "pool: bad geometry on axis %d", i);
+    ECO_REQUIRE(g->pad[i] < g->kernel[i], "pool: pad must be smaller than kernel (axis %d)", i);
+    // ceil rule + last-window clip (pooling_layer.cpp:131-147); float division as the reference does
+    int o = (int)ceilf((float)(g->in[i] + 2 * g->pad[i] - g->kernel[i]) / (float)g->stride[i]) + 1;
+    if (g->pad[i] && (o - 1) * g->stride[i] >= g->in[i] + g->pad[i]) --o;
+    ECO_REQUIRE(o == g->out[i], "pool: output dim %d is %d, expected %d", i, g->out[i], o);
+    global = global && g->kernel[i] == g->in[i] && g->pad[i] == 0 && g->out[i] == 1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const long rows = (long)g->n * g->c;
+  const long s_in = (long)g->in[0] * g->in[1] * g->in[2];
+  if (global && g->method == ECO_POOL_AVE && s_in >= 32 && s_in < 2147483647l) {
+    hipLaunchKernelGGL((global_avg_kernel), dim3(grid_for(rows, 4)), dim3(kThreads), 0, s, x, y, rows, (int)s_in);
+    return check_launch("eco_pool_forward(global)");
+  }
+  PoolArgs a;
+  a.x = x; a.y = y;
+  a.Di = g->in[0]; a.Hi = g->in[1]; a.Wi = g->in[2];
+  a.Do = g->out[0]; a.Ho = g->out[1]; a.Wo = g->out[2];
+  a.kd = g->kernel[0]; a.kh = g->kernel[1]; a.kw = g->kernel[2];
+  a.sd = g->stride[0]; a.sh = g->stride[1]; a.sw = g->stride[2];
+  a.pd = g->pad[0]; a.ph = g->pad[1]; a.pw = g->pad[2];
+  a.method = g->method;
+  a.total = rows * a.Do * a.Ho * a.Wo;
+  hipLaunchKernelGGL((pool_kernel), dim3(grid_for(a.total)), dim3(kThreads), 0, s, a);
+  return check_launch("eco_pool_forward");
+}
+
+extern "C" int eco_bn_forward(const float* x, float* y, const float* scale, const float* shift, int64_t n, int64_t c,
+                              int64_t inner, int relu, void* stream) {
+  clear_error();
+  ECO_REQUIRE(x && y && scale && shift, "bn: null argument");
+  ECO_REQUIRE(n > 0 && c > 0 && inner > 0, "bn: bad shape");
+  const long total = n * c * inner;
+  hipLaunchKernelGGL((bn_kernel), dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, x, y, scale, shift,
+                     total, (long)c, (long)inner, relu);
+  return check_launch("eco_bn_forward");
+}
+
+extern "C" int eco_relu_forward(const float* x, float* y, int64_t count, float negative_slope, void* stream) {
+  clear_error();
+  ECO_REQUIRE(x && y && count > 0, "relu: bad argument");
+  hipLaunchKernelGGL((relu_kernel), dim3(grid_for(count)), dim3(kThreads), 0, (hipStream_t)stream, x, y, (long)count,
+                     negative_slope);
+  return check_launch("eco_relu_forward");
+}
+
+extern "C" int eco_eltwise_sum_forward(const float* a, const float* b, float* y, int64_t count, float ca, float cb,
+                                       void* stream) {
+  clear_error();
+  ECO_REQUIRE(a && b && y && count > 0, "eltwise: bad argument");
+  hipLaunchKernelGGL((eltwise_sum_kernel), dim3(grid_for(count)), dim3(kThreads), 0, (hipStream_t)stream, a, b, y,
+                     (long)count, ca, cb);
+  return check_launch("eco_eltwise_sum_forward");
+}
+
+extern "C" int eco_concat_copy(const float* x, float* y, int64_t outer, int64_t cx, int64_t cy, int64_t c0,
+                               int64_t inner, void* stream) {
+  clear_error();
+  ECO_REQUIRE(x && y, "concat: null argument");
+  ECO_REQUIRE(outer > 0 && cx > 0 && inner > 0 && c0 >= 0 && c0 + cx <= cy, "concat: slice [%ld,%ld) outside %ld channels",
+              (long)c0, (long)(c0 + cx), (long)cy);
+  const long total = outer * cx * inner;
+  hipLaunchKernelGGL((concat_copy_kernel), dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, x, y, total,
+                     (long)cx, (long)cy, (long)c0, (long)inner);
+  return check_launch("eco_concat_copy");
+}
+
+extern "C" int eco_permute_forward(const float* x, float* y, int32_t naxes, const int32_t* in_shape,
+                                   const int32_t* order, void* stream) {
+  clear_error();
+  ECO_REQUIRE(x && y && in_shape && order, "permute: null argument");
+  ECO_REQUIRE(naxes >= 1 && naxes <= 6, "permute: %d axes unsupported (1..6)", naxes);
+  long in_stride[6];
+  long s = 1;
+  for (int i = naxes - 1; i >= 0; --i) {
+    ECO_REQUIRE(in_shape[i] > 0, "permute: bad shape");
+    in_stride[i] = s;
+    s *= in_shape[i];
+  }
+  PermuteArgs a;
+  a.x = x; a.y = y; a.total = s; a.naxes = naxes;
+  unsigned seen = 0;
+  for (int i = 0; i < naxes; ++i) {
+    ECO_REQUIRE(order[i] >= 0 && order[i] < naxes && !(seen & (1u << order[i])), "permute: there are duplicate orders");
+    seen |= 1u << order[i];
+    a.out_shape[i] = in_shape[order[i]];
+    a.in_stride_of_out_axis[i] = in_stride[order[i]];
+  }
+  hipLaunchKernelGGL((permute_kernel), dim3(grid_for(a.total)), dim3(kThreads), 0, (hipStream_t)stream, a);
+  return check_launch("eco_permute_forward");
+}
+
+extern "C" int eco_inner_product_forward(const float* x, const float* w, const float* bias, float* y, int64_t m,
+                                         int64_t n, int64_t k, void* stream) {
+  clear_error();
+  ECO_REQUIRE(x && w && y, "inner_product: null argument");
+  ECO_REQUIRE(m > 0 && n > 0 && k > 0, "inner_product: bad shape");
+  hipLaunchKernelGGL((inner_product_kernel), dim3(grid_for(m * n, 4)), dim3(kThreads), 0, (hipStream_t)stream, x, w,
+                     bias, y, (long)m, (long)n, (long)k);
+  return check_launch("eco_inner_product_forward");
+}
+
+extern "C" int eco_global_avgpool_fc_forward(const float* x, const float* w, const float* bias, float* y, int64_t b,
+                                             int64_t c, int64_t s, int64_t n_out, int64_t wk, int64_t c0,
+                                             int accumulate, void* stream) {
+  clear_error();
+  ECO_REQUIRE(x && w && y, "global_avgpool_fc: null argument");
+  ECO_REQUIRE(b > 0 && c > 0 && s > 0 && n_out > 0, "global_avgpool_fc: bad shape");
+  ECO_REQUIRE(c <= kTailMaxC, "global_avgpool_fc: %ld channels exceed the %d-channel LDS buffer", (long)c, kTailMaxC);
+  ECO_REQUIRE(c0 >= 0 && c0 + c <= wk, "global_avgpool_fc: weight columns [%ld,%ld) outside row length %ld", (long)c0,
+              (long)(c0 + c), (long)wk);
+  ECO_REQUIRE(b <= 65535 && s < 2147483647l, "global_avgpool_fc: batch too large for one launch");
+  dim3 grid((unsigned)ceil_div(n_out, kTailOutPerBlock), (unsigned)b);
+  hipLaunchKernelGGL((global_avgpool_fc_kernel), grid, dim3(kThreads), 0, (hipStream_t)stream, x, w, bias, y, (int)c,
+                     (int)s, (int)n_out, (int)wk, (int)c0, accumulate);
+  return check_launch("eco_global_avgpool_fc_forward");
+}
+
+extern "C" int eco_softmax_forward(const float* x, float* y, int64_t outer, int64_t c, int64_t inner, void* stream) {
+  clear_error();
+  ECO_REQUIRE(x && y && outer > 0 && c > 0 && inner > 0, "softmax: bad argument");
+  hipLaunchKernelGGL((softmax_kernel), dim3(grid_for(outer * inner)), dim3(kThreads), 0, (hipStream_t)stream, x, y,
+                     (long)outer, (long)c, (long)inner);
+  return check_launch("eco_softmax_forward");
+}

@@ -1,0 +1,229 @@
+"""ctypes binding of the C ABI declared in ``include/eco_hip.h``.
+
+``load()`` opens the in-tree gfx950 build (``libeco_hip.so`` next to this
+file) and *fails loudly* if it is missing or is not a device build -- there is
+no CPU fallback anywhere in the product path.  ``EcoLib(path)`` can be pointed
+at another build of the same ABI; the CPU test-suite uses that to bind
+``tests/emu/libeco_emu.so`` (the fiber-emulated build of the same kernel
+sources), never the product.
+
+All pointer arguments are raw integer addresses (``tensor.data_ptr()`` /
+``ndarray.ctypes.data``): the binding is agnostic of who owns the memory.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+ECO_OK = 0
+ECO_ERR_INVALID = -1
+ECO_ERR_RUNTIME = -2
+POOL_MAX = 0
+POOL_AVE = 1
+ABI_VERSION = 1
+
+_i32x3 = C.c_int32 * 3
+
+
+class EcoError(RuntimeError):
+    """A C-ABI call returned an error code (the reference would CHECK-fail)."""
+
+    def __init__(self, code: int, msg: str) -> None:
+        super().__init__(f"[eco_hip {code}] {msg}")
+        self.code = code
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [("n", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("in_", _i32x3), ("kernel", _i32x3), ("stride", _i32x3),
+                ("pad", _i32x3), ("out", _i32x3)]
+
+
+class ConvPlan(C.Structure):
+    _fields_ = [("bm", C.c_int32), ("bn", C.c_int32), ("kc", C.c_int32), ("k", C.c_int32),
+                ("kpad", C.c_int32), ("mpad", C.c_int32),
+                ("wp_elems", C.c_int64), ("ktab_elems", C.c_int64)]
+
+
+class View(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("stride_b", C.c_int64), ("stride_t", C.c_int64),
+                ("stride_c", C.c_int64), ("t", C.c_int32)]
+
+
+class ConvEpilogue(C.Structure):
+    _fields_ = [("bias", C.c_void_p), ("residual", View), ("raw", View),
+                ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p),
+                ("relu", C.c_int32), ("act", View)]
+
+
+class PoolGeom(C.Structure):
+    _fields_ = [("n", C.c_int32), ("c", C.c_int32), ("in_", _i32x3), ("kernel", _i32x3),
+                ("stride", _i32x3), ("pad", _i32x3), ("out", _i32x3), ("method", C.c_int32)]
+
+
+def _pad3(vals: Sequence[int], fill: int) -> "_i32x3":
+    vals = list(vals)
+    if not 1 <= len(vals) <= 3:
+        raise ValueError("1..3 spatial dims supported")
+    return _i32x3(*([fill] * (3 - len(vals)) + [int(v) for v in vals]))
+
+
+def conv_geom(n: int, cin: int, cout: int, in_sp, kernel, stride, pad, out_sp) -> ConvGeom:
+    return ConvGeom(int(n), int(cin), int(cout), _pad3(in_sp, 1), _pad3(kernel, 1),
+                    _pad3(stride, 1), _pad3(pad, 0), _pad3(out_sp, 1))
+
+
+def pool_geom(n: int, c: int, in_sp, kernel, stride, pad, out_sp, method: str) -> PoolGeom:
+    return PoolGeom(int(n), int(c), _pad3(in_sp, 1), _pad3(kernel, 1), _pad3(stride, 1),
+                    _pad3(pad, 0), _pad3(out_sp, 1), {"MAX": POOL_MAX, "AVE": POOL_AVE}[method])
+
+
+def plain_view(ptr: int, channels: int, spatial: int) -> View:
+    """Dense [N, C, S] tensor."""
+    return View(ptr, int(channels) * int(spatial), 0, int(spatial), 1)
+
+
+def null_view() -> View:
+    return View(None, 0, 0, 0, 1)
+
+
+_SIGNATURES = {
+    "eco_abi_version": (C.c_int, []),
+    "eco_is_device_build": (C.c_int, []),
+    "eco_last_error": (C.c_char_p, []),
+    "eco_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "eco_set_device": (C.c_int, [C.c_int]),
+    "eco_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "eco_conv_plan_create": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvPlan)]),
+    "eco_conv_pack_weights": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvPlan), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eco_conv_forward": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvPlan), C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(ConvEpilogue), C.c_void_p]),
+    "eco_pool_forward": (C.c_int, [C.POINTER(PoolGeom), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eco_bn_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                 C.c_int, C.c_void_p]),
+    "eco_relu_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "eco_eltwise_sum_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                          C.c_void_p]),
+    "eco_concat_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                  C.c_void_p]),
+    "eco_permute_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                      C.c_void_p]),
+    "eco_inner_product_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                            C.c_int64, C.c_void_p]),
+    "eco_global_avgpool_fc_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                                C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    "eco_softmax_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class EcoLib:
+    """One loaded build of the ECO C ABI."""
+
+    def __init__(self, path: str) -> None:
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.path = path
+        self._dll = C.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError as e:
+                raise ImportError(f"{path} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        v = self._dll.eco_abi_version()
+        if v != ABI_VERSION:
+            raise ImportError(f"{path}: ABI version {v}, binding expects {ABI_VERSION}")
+        self.is_device_build = bool(self._dll.eco_is_device_build())
+
+    # -- plumbing -------------------------------------------------------------
+    def _check(self, rc: int) -> None:
+        if rc != ECO_OK:
+            raise EcoError(rc, (self._dll.eco_last_error() or b"").decode("utf-8", "replace"))
+
+    def last_error(self) -> str:
+        return (self._dll.eco_last_error() or b"").decode("utf-8", "replace")
+
+    # -- device ---------------------------------------------------------------
+    def device_count(self) -> int:
+        n = C.c_int(0)
+        self._check(self._dll.eco_device_count(C.byref(n)))
+        return n.value
+
+    def set_device(self, dev: int) -> None:
+        self._check(self._dll.eco_set_device(int(dev)))
+
+    def device_info(self, dev: int) -> dict:
+        name = C.create_string_buffer(256)
+        cu = C.c_int(0)
+        mem = C.c_uint64(0)
+        self._check(self._dll.eco_device_info(int(dev), name, 256, C.byref(cu), C.byref(mem)))
+        return {"name": name.value.decode(), "num_cu": cu.value, "hbm_bytes": mem.value}
+
+    # -- convolution ----------------------------------------------------------
+    def conv_plan(self, g: ConvGeom) -> ConvPlan:
+        p = ConvPlan()
+        self._check(self._dll.eco_conv_plan_create(C.byref(g), C.byref(p)))
+        return p
+
+    def conv_pack_weights(self, g: ConvGeom, p: ConvPlan, w_ptr: int, wp_ptr: int, ktab_ptr: int) -> None:
+        self._check(self._dll.eco_conv_pack_weights(C.byref(g), C.byref(p), w_ptr, wp_ptr, ktab_ptr))
+
+    def conv_forward(self, g: ConvGeom, p: ConvPlan, x: int, wp: int, ktab: int, ep: ConvEpilogue,
+                     stream: Optional[int] = None) -> None:
+        self._check(self._dll.eco_conv_forward(C.byref(g), C.byref(p), x, wp, ktab, C.byref(ep), stream))
+
+    # -- stand-alone operators -----------------------------------------------
+    def pool_forward(self, g: PoolGeom, x: int, y: int, stream=None) -> None:
+        self._check(self._dll.eco_pool_forward(C.byref(g), x, y, stream))
+
+    def bn_forward(self, x, y, scale, shift, n, c, inner, relu, stream=None) -> None:
+        self._check(self._dll.eco_bn_forward(x, y, scale, shift, n, c, inner, int(relu), stream))
+
+    def relu_forward(self, x, y, count, negative_slope=0.0, stream=None) -> None:
+        self._check(self._dll.eco_relu_forward(x, y, count, float(negative_slope), stream))
+
+    def eltwise_sum_forward(self, a, b, y, count, ca=1.0, cb=1.0, stream=None) -> None:
+        self._check(self._dll.eco_eltwise_sum_forward(a, b, y, count, float(ca), float(cb), stream))
+
+    def concat_copy(self, x, y, outer, cx, cy, c0, inner, stream=None) -> None:
+        self._check(self._dll.eco_concat_copy(x, y, outer, cx, cy, c0, inner, stream))
+
+    def permute_forward(self, x, y, in_shape: Sequence[int], order: Sequence[int], stream=None) -> None:
+        n = len(in_shape)
+        shp = (C.c_int32 * n)(*[int(s) for s in in_shape])
+        ordr = (C.c_int32 * n)(*[int(o) for o in order])
+        self._check(self._dll.eco_permute_forward(x, y, n, shp, ordr, stream))
+
+    def inner_product_forward(self, x, w, bias, y, m, n, k, stream=None) -> None:
+        self._check(self._dll.eco_inner_product_forward(x, w, bias, y, m, n, k, stream))
+
+    def global_avgpool_fc_forward(self, x, w, bias, y, b, c, s, n_out, wk, c0=0, accumulate=False, stream=None) -> None:
+        self._check(self._dll.eco_global_avgpool_fc_forward(x, w, bias, y, b, c, s, n_out, wk, c0,
+                                                            int(accumulate), stream))
+
+    def softmax_forward(self, x, y, outer, c, inner, stream=None) -> None:
+        self._check(self._dll.eco_softmax_forward(x, y, outer, c, inner, stream))
+
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libeco_hip.so")
+_lib: Optional[EcoLib] = None
+
+
+def load() -> EcoLib:
+    """The product library.  No fallback: a missing or non-device build is an error."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C {os.path.join(_PKG_DIR, 'csrc')}`. The ECO path has no CPU fallback.")
+        lib = EcoLib(LIB_PATH)
+        if not lib.is_device_build:
+            raise ImportError(f"{LIB_PATH} is not a gfx950 device build")
+        _lib = lib
+    return _lib

@@ -1,0 +1,186 @@
+/*
+ * eco_hip.h -- C ABI of libeco_hip.so: MI355X (gfx950) HIP kernels for the ECO
+ * inference forward path (BN-Inception 2-D head -> r2Dto3D -> 3D-ResNet-18 trunk
+ * -> global_pool -> fc).
+ *
+ * Drop-in boundary.  Each entry point replaces the GPU forward of one reference
+ * operator (caffe_3d `Layer<Dtype>::Forward_gpu`, include/caffe/layer.hpp:444-477)
+ * or a fused group of them; the reference file:line each one stands in for is
+ * given at its declaration.  The contract mirrors the Layer plug-point:
+ *
+ *   - plain pointers and PODs only (no torch / HIP types in signatures; the
+ *     stream is passed as an opaque `void*` that must be a hipStream_t or NULL),
+ *   - tensors are fp32, row-major N,C,[D,]H,W exactly like caffe `Blob`
+ *     (include/caffe/blob.hpp:24-282); weights keep the reference layouts
+ *     ([Cout,Cin,(kd,)kh,kw], BN 4 x [1,C], fc [out,in]),
+ *   - every function returns ECO_OK or a negative error code and never aborts,
+ *     allocates, or synchronises: the caller owns memory and the stream
+ *     (the reference LOG(FATAL)s instead; `eco_last_error()` carries the text a
+ *     CHECK would have printed),
+ *   - thread-compatible: no global state except the thread-local error string.
+ *
+ * A second build of the same sources against a CPU fiber emulator
+ * (tests/emu/, libeco_emu.so) exports the identical symbols; it exists only so
+ * that the CPU test-suite can exercise kernel index math without a GPU and is
+ * never loaded by the product package.
+ */
+#ifndef ECO_HIP_H_
+#define ECO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECO_ABI_VERSION 1
+
+#define ECO_OK 0
+#define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
+#define ECO_ERR_RUNTIME (-2) /* HIP runtime error (launch failure, bad device)     */
+
+#define ECO_POOL_MAX 0
+#define ECO_POOL_AVE 1
+
+/* ---- library / device ------------------------------------------------------------ */
+
+/* ABI version of the loaded library (== ECO_ABI_VERSION of the header it was built from). */
+int eco_abi_version(void);
+/* 1 when this is the gfx950 HIP build, 0 for the CPU emulator build (tests only). */
+int eco_is_device_build(void);
+/* Text of the last error on this thread ("" if none). Replaces glog CHECK/LOG(FATAL) output. */
+const char* eco_last_error(void);
+/* Caffe::SetDevice / device_query (caffe_3d/src/caffe/common.cpp:140-190). */
+int eco_device_count(int* count);
+int eco_set_device(int device);
+/* Fills name (NUL-terminated, <= name_len), compute-unit count and HBM bytes of `device`. */
+int eco_device_info(int device, char* name, size_t name_len, int* num_cu, uint64_t* hbm_bytes);
+
+/* ---- convolution (+ fused bias / residual / BN / ReLU epilogue) -------------------- */
+
+/* Geometry of one N-D cross-correlation, as resolved by
+ * BaseConvolutionLayer::LayerSetUp/Reshape (layers/base_conv_layer.cpp:13-261) and
+ * ConvolutionLayer::compute_output_shape (layers/conv_layer.cpp:12-25).
+ * 2-D layers use in[0]=out[0]=kernel[0]=stride[0]=1, pad[0]=0.  group=1, dilation=1. */
+typedef struct eco_conv_geom {
+  int32_t n;         /* images (2-D) or clips (3-D)           */
+  int32_t cin, cout;
+  int32_t in[3];     /* input  D,H,W                           */
+  int32_t kernel[3]; /* kd,kh,kw                               */
+  int32_t stride[3];
+  int32_t pad[3];
+  int32_t out[3];    /* output D,H,W = (in+2*pad-kernel)/stride+1 (validated) */
+} eco_conv_geom;
+
+/* Tiling chosen for a geometry; fixes the packed-weight layout. */
+typedef struct eco_conv_plan {
+  int32_t bm, bn, kc; /* block tile: bm output channels x bn output positions, kc reduction rows per stage */
+  int32_t k;          /* cin*kd*kh*kw                                   */
+  int32_t kpad;       /* k rounded up to a multiple of kc               */
+  int32_t mpad;       /* cout rounded up to a multiple of 128           */
+  int64_t wp_elems;   /* floats in the packed weight buffer  (kpad*mpad) */
+  int64_t ktab_elems; /* int32 entries in the gather table   (kpad)      */
+} eco_conv_plan;
+
+/* Strided view of an N,C,[D,]H,W output (or residual) tensor.  Element
+ * (img, c, sp) with sp the row-major index over the spatial dims lives at
+ *   ptr[(img / t)*stride_b + (img % t)*stride_t + c*stride_c + sp].
+ * Plain tensor: t=1, stride_b=C*S, stride_c=S.  Writing into a channel slice of a
+ * Concat top (layers/concat_layer.cpp:54-70) = larger stride_b + offset ptr.
+ * Writing through r2Dto3D+Permute [B*T,C,H,W] -> [B,C,T,H,W]
+ * (layers/reshape_layer.cpp:88, layers/permute_layer.cpp:9-26) = t=T,
+ * stride_b=C*T*S, stride_t=S, stride_c=T*S. */
+typedef struct eco_view {
+  float* ptr;
+  int64_t stride_b, stride_t, stride_c;
+  int32_t t;
+} eco_view;
+
+/* Fused epilogue, applied per output element v = conv(x,w)[img,c,sp]:
+ *   v += bias[c]                       (forward_cpu_bias, base_conv_layer.cpp:282-287)
+ *   v += residual(img,c,sp)            (Eltwise SUM, layers/eltwise_layer.cpp:66-72)
+ *   raw(img,c,sp) = v                  (the conv / eltwise top itself)
+ *   a = v*bn_scale[c] + bn_shift[c]    (BN TEST branch folded: scale=gamma/sqrt(var+eps),
+ *                                       shift=beta-mean*scale; bn_layer.cpp:93-207,
+ *                                       same algebra as python/gen_bn_inference.py:121-134)
+ *   act(img,c,sp) = relu ? max(a,0) : a   (layers/relu_layer.cpp:10-20)
+ * Any of bias / residual.ptr / raw.ptr / act.ptr may be NULL (that step is skipped);
+ * bn_scale==NULL means a = v.  At least one of raw.ptr / act.ptr must be non-NULL. */
+typedef struct eco_conv_epilogue {
+  const float* bias;
+  eco_view residual; /* read-only */
+  eco_view raw;
+  const float* bn_scale;
+  const float* bn_shift;
+  int32_t relu;
+  eco_view act;
+} eco_conv_epilogue;
+
+/* Validates `g` (fills nothing) and chooses the tiling. */
+int eco_conv_plan_create(const eco_conv_geom* g, eco_conv_plan* plan);
+/* HOST function.  Re-lays caffe weights w[cout][cin][kd][kh][kw] (host pointer) into the
+ * kernel's K-major image wp[kpad][mpad] (zero padded) and builds the gather table
+ * ktab[kpad] (host pointers, sizes from the plan).  The caller uploads both. */
+int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan* plan,
+                          const float* w, float* wp, int32_t* ktab);
+/* ConvolutionLayer::Forward_gpu (layers/conv_layer.cu, cudnn_conv_layer.cu:15-65) as one
+ * implicit-GEMM MFMA kernel, optionally fused with the BN / ReLU / Eltwise / Concat /
+ * Permute layers that follow it.  x, wp, ktab and all epilogue pointers are DEVICE pointers. */
+int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* plan, const float* x,
+                     const float* wp, const int32_t* ktab, const eco_conv_epilogue* ep,
+                     void* stream);
+
+/* ---- stand-alone operators (one per reference layer type) -------------------------- */
+
+/* PoolingLayer::Forward_gpu (layers/pooling_layer.cu:12-81; N-D via cuDNN,
+ * layers/cudnn_pooling_layer.cu:13-22).  x: [n,c,in...] -> y: [n,c,out...]; nsp spatial
+ * dims (1..3, leading entries of the arrays unused when nsp<3 are given as size 1).
+ * MAX clips windows to the image; AVE divides by the window size including padding
+ * clipped to in+pad (pooling_layer.cpp:199-262).  out[] must equal the ceil-rule
+ * pooled shape (pooling_layer.cpp:131-147). */
+typedef struct eco_pool_geom {
+  int32_t n, c;
+  int32_t in[3], kernel[3], stride[3], pad[3], out[3];
+  int32_t method; /* ECO_POOL_MAX | ECO_POOL_AVE */
+} eco_pool_geom;
+int eco_pool_forward(const eco_pool_geom* g, const float* x, float* y, void* stream);
+
+/* BNLayer TEST/frozen forward with folded statistics (+ optional in-place ReLU):
+ * y = x*scale[c] + shift[c]; relu -> max(y,0).  x,y: [n,c,inner]; y may alias x.
+ * (layers/bn_layer.cu:12-125, cudnn_bn_layer.cu:17-37, relu_layer.cu:10-15) */
+int eco_bn_forward(const float* x, float* y, const float* scale, const float* shift,
+                   int64_t n, int64_t c, int64_t inner, int relu, void* stream);
+/* ReLULayer::Forward_gpu (layers/relu_layer.cu:10-15): y = max(x,0) + slope*min(x,0). */
+int eco_relu_forward(const float* x, float* y, int64_t count, float negative_slope, void* stream);
+/* EltwiseLayer SUM of two bottoms: y = ca*a + cb*b (layers/eltwise_layer.cu:49-53). */
+int eco_eltwise_sum_forward(const float* a, const float* b, float* y, int64_t count,
+                            float ca, float cb, void* stream);
+/* ConcatLayer::Forward_gpu for one bottom (layers/concat_layer.cu:10-46): copies
+ * x[outer][cx][inner] into y[outer][cy][inner] at channel offset c0. */
+int eco_concat_copy(const float* x, float* y, int64_t outer, int64_t cx, int64_t cy, int64_t c0,
+                    int64_t inner, void* stream);
+/* PermuteLayer::Forward_gpu (layers/permute_layer.cu:11-50): y[i0..] = x permuted,
+ * top axis k = bottom axis order[k]; naxes <= 6. */
+int eco_permute_forward(const float* x, float* y, int32_t naxes, const int32_t* in_shape,
+                        const int32_t* order, void* stream);
+/* InnerProductLayer::Forward_gpu (layers/inner_product_layer.cu:14-25):
+ * y[m][n] = sum_k x[m][k]*w[n][k] + bias[n] (bias may be NULL). */
+int eco_inner_product_forward(const float* x, const float* w, const float* bias, float* y,
+                              int64_t m, int64_t n, int64_t k, void* stream);
+/* Fused tail global_pool (AVE over the whole D*H*W volume) -> reshape -> dropout(TEST) -> fc:
+ * y[b][o] = bias[o] + sum_c w[o][c0 + c] * mean_s x[b][c][s]   (c in [0,c), w row length wk).
+ * accumulate != 0 adds into y instead of overwriting (used for the ECO-Full concat+fc8N split).
+ * (cudnn_pooling_layer.cu:13-22 + reshape_layer.cpp:88 + dropout_layer.cpp:46-48 +
+ *  inner_product_layer.cu:14-25) */
+int eco_global_avgpool_fc_forward(const float* x, const float* w, const float* bias, float* y,
+                                  int64_t b, int64_t c, int64_t s, int64_t n_out, int64_t wk,
+                                  int64_t c0, int accumulate, void* stream);
+/* SoftmaxLayer::Forward_gpu over axis 1 of [outer, c, inner] (layers/softmax_layer.cu:14-71). */
+int eco_softmax_forward(const float* x, float* y, int64_t outer, int64_t c, int64_t inner,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECO_HIP_H_ */
