@@ -1,0 +1,600 @@
+"""Execution plan for an ECO ``NetSpec`` on the HIP C ABI.
+
+Replaces the reference's per-layer virtual dispatch (``Net::ForwardFromTo``,
+caffe_3d/src/caffe/net.cpp:566-583 -> ``Layer::Forward``, layer.hpp:444-477)
+with a static list of C-ABI launches built once per shape:
+
+* ``fuse=False`` -- one launch per prototxt layer (Convolution, BN, ReLU, Pooling,
+  Concat, Eltwise, Permute, InnerProduct, Softmax; Reshape/Split/Dropout(TEST) are
+  aliases exactly as in the reference: reshape_layer.cpp:88, split_layer.cpp:26-32,
+  dropout_layer.cpp:46-48).  Every blob of the prototxt is materialised and
+  observable, like pycaffe.
+* ``fuse=True`` (default) -- the MI355X plan: each Convolution absorbs the layers
+  that follow it into its epilogue (bias, Eltwise-SUM residual, BN folded to a
+  per-channel affine, ReLU), writes straight into its channel slice of a Concat
+  top or through r2Dto3D+Permute with permuted strides, and the
+  global_pool->reshape->dropout->fc tail is one launch.  Blobs that only exist
+  inside a fused group are not materialised (asking for them raises).
+
+Memory: every materialised blob gets its own HBM allocation (no in-place
+sharing tricks like the reference's MemoryOptimize, net.cpp:1079+: 15 GB at
+N=16 B=32 against 288 GB of HBM3E).  All launches go to one stream in layer
+order; nothing synchronises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import hip
+from .netspec import LayerSpec, NetSpec, NetSpecError, param_shapes
+
+_ALIAS_TYPES = ("Split", "Reshape", "Dropout")
+
+
+def _prod(xs) -> int:
+    p = 1
+    for x in xs:
+        p *= int(x)
+    return p
+
+
+class TorchAllocator:
+    """Device memory + stream plumbing through PyTorch-ROCm (plumbing only)."""
+
+    def __init__(self, device: Optional[int] = None) -> None:
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible to PyTorch-ROCm; the ECO path has no CPU fallback")
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+
+    def empty(self, nelems: int, dtype=np.float32):
+        tdt = {np.dtype(np.float32): self.torch.float32, np.dtype(np.int32): self.torch.int32}[np.dtype(dtype)]
+        return self.torch.empty(max(int(nelems), 1), dtype=tdt, device=self.device)
+
+    @staticmethod
+    def ptr(h) -> int:
+        return h.data_ptr()
+
+    def upload(self, h, arr: np.ndarray) -> None:
+        a = np.ascontiguousarray(arr).reshape(-1)
+        h[: a.size].copy_(self.torch.from_numpy(a), non_blocking=False)
+
+    def download(self, h, nelems: int) -> np.ndarray:
+        return h[:nelems].detach().cpu().numpy()
+
+    def stream(self) -> Optional[int]:
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def synchronize(self) -> None:
+        self.torch.cuda.synchronize(self.device)
+
+
+class _Tensor:
+    """A materialised blob: storage handle + logical shape (aliases share a handle)."""
+
+    __slots__ = ("handle", "shape", "owner")
+
+    def __init__(self, handle, shape, owner: str) -> None:
+        self.handle = handle
+        self.shape = tuple(int(s) for s in shape)
+        self.owner = owner  # blob name that owns the storage
+
+    @property
+    def count(self) -> int:
+        return _prod(self.shape)
+
+
+def fold_bn(blobs: Sequence[np.ndarray], eps: float) -> Tuple[np.ndarray, np.ndarray]:
+    """BN TEST branch as y = x*a + b: a = gamma/sqrt(var+eps), b = beta - mean*a
+    (bn_layer.cpp:93-207; same algebra as python/gen_bn_inference.py:121-134).
+    Folded in float64, stored fp32."""
+    gamma, beta, mean, var = (np.asarray(b, np.float64).reshape(-1) for b in blobs[:4])
+    a = gamma / np.sqrt(var + eps)
+    b = beta - mean * a
+    return a.astype(np.float32), b.astype(np.float32)
+
+
+def bn_eps(L: LayerSpec) -> float:
+    # 5-D blobs only run through cuDNN in the reference: eps = max(eps, CUDNN_BN_MIN_EPSILON)
+    # (cudnn_bn_layer.cu:24); <=4-D uses bn_param.eps as is (bn_layer.cpp:159).
+    e = L.geom["eps"]
+    return max(e, 1e-5) if len(L.bottom_shapes[0]) > 4 else e
+
+
+class Engine:
+    def __init__(self, spec: NetSpec, lib: hip.EcoLib, alloc, fuse: bool = True) -> None:
+        self.spec = spec
+        self.lib = lib
+        self.alloc = alloc
+        self.fuse = fuse
+        self.params: Dict[str, List[np.ndarray]] = {}
+        self._param_dev: Dict[str, dict] = {}    # layer name -> device-side state
+        self._dirty_params: set = set()
+        self.tensors: Dict[str, _Tensor] = {}
+        self.fused_away: Dict[str, str] = {}     # blob -> reason
+        # (layer idx, label, fn(stream), meta {"kernel": str, "flops": int, "bytes": int})
+        self.ops: List[Tuple[int, str, Callable[[Optional[int]], None], dict]] = []
+        self._keep = []                          # ctypes structs referenced by closures
+        self._built = False
+
+    # ------------------------------------------------------------------ params
+    def set_params(self, params: Dict[str, List[np.ndarray]]) -> None:
+        for L in self.spec.layers:
+            shapes = param_shapes(L)
+            if not shapes:
+                continue
+            if L.name not in params:
+                raise KeyError(f"no parameters for layer {L.name!r}")
+            blobs = params[L.name]
+            if len(blobs) != len(shapes):  # net.cpp:869-870
+                raise ValueError(f"Incompatible number of blobs for layer {L.name}: {len(blobs)} vs {len(shapes)}")
+            out = []
+            for b, s in zip(blobs, shapes):
+                b = np.asarray(b, dtype=np.float32)
+                if b.size != _prod(s):
+                    raise ValueError(f"layer {L.name}: parameter shape {b.shape} does not match {s}")
+                out.append(np.ascontiguousarray(b.reshape(s)))
+            self.params[L.name] = out
+            self._dirty_params.add(L.name)
+
+    def mark_param_dirty(self, layer_name: str) -> None:
+        self._dirty_params.add(layer_name)
+
+    def _upload_f32(self, arr: np.ndarray):
+        h = self.alloc.empty(arr.size, np.float32)
+        self.alloc.upload(h, arr.astype(np.float32, copy=False))
+        return h
+
+    def _sync_params(self) -> None:
+        """(Re)upload parameters whose host copy changed; repack conv weights."""
+        if not self._dirty_params:
+            return
+        for name in list(self._dirty_params):
+            L = self.spec.layer(name)
+            st = self._param_dev.setdefault(name, {})
+            blobs = self.params[name]
+            if L.type == "Convolution":
+                g: hip.ConvGeom = st["geom"]
+                plan: hip.ConvPlan = st["plan"]
+                wp = np.empty(plan.wp_elems, np.float32)
+                kt = np.empty(plan.ktab_elems, np.int32)
+                w = np.ascontiguousarray(blobs[0], np.float32)
+                self.lib.conv_pack_weights(g, plan, w.ctypes.data, wp.ctypes.data, kt.ctypes.data)
+                self.alloc.upload(st["wp"], wp)
+                self.alloc.upload(st["ktab"], kt)
+                if L.geom["bias_term"]:
+                    self.alloc.upload(st["bias"], blobs[1])
+            elif L.type == "BN":
+                a, b = fold_bn(blobs, bn_eps(L))
+                self.alloc.upload(st["scale"], a)
+                self.alloc.upload(st["shift"], b)
+            elif L.type == "InnerProduct":
+                self.alloc.upload(st["w"], blobs[0])
+                if L.geom["bias_term"]:
+                    self.alloc.upload(st["bias"], blobs[1])
+            self._dirty_params.discard(name)
+
+    # ------------------------------------------------------------------ build
+    def build(self) -> None:
+        """Allocate blobs and record the launch list for the spec's current shapes."""
+        spec = self.spec
+        self.tensors = {}
+        self.fused_away = {}
+        self.ops = []
+        self._keep = []
+        # device-side parameter storage (sizes depend on geometry)
+        for L in spec.layers:
+            st = self._param_dev.setdefault(L.name, {})
+            if L.type == "Convolution":
+                g = L.geom
+                geom = hip.conv_geom(L.bottom_shapes[0][0], g["cin"], g["cout"], L.bottom_shapes[0][2:], g["kernel"],
+                                     g["stride"], g["pad"], L.top_shapes[0][2:])
+                plan = self.lib.conv_plan(geom)
+                old = st.get("plan")
+                if old is None or (old.wp_elems, old.ktab_elems) != (plan.wp_elems, plan.ktab_elems):
+                    st["wp"] = self.alloc.empty(plan.wp_elems, np.float32)
+                    st["ktab"] = self.alloc.empty(plan.ktab_elems, np.int32)
+                    if g["bias_term"]:
+                        st["bias"] = self.alloc.empty(g["cout"], np.float32)
+                st["geom"], st["plan"] = geom, plan
+                self._dirty_params.add(L.name)  # the gather table depends on the input dims
+            elif L.type == "BN" and "scale" not in st:
+                st["scale"] = self.alloc.empty(L.geom["channels"], np.float32)
+                st["shift"] = self.alloc.empty(L.geom["channels"], np.float32)
+                self._dirty_params.add(L.name)
+            elif L.type == "InnerProduct" and "w" not in st:
+                st["w"] = self.alloc.empty(L.geom["num_output"] * L.geom["K"], np.float32)
+                if L.geom["bias_term"]:
+                    st["bias"] = self.alloc.empty(L.geom["num_output"], np.float32)
+                self._dirty_params.add(L.name)
+        for n in spec.inputs:
+            self._materialize(n, spec.blob_shapes[n])
+        if self.fuse:
+            self._build_fused()
+        else:
+            for i, L in enumerate(spec.layers):
+                self._emit_unfused(i, L)
+        self._built = True
+
+    # -- storage helpers -------------------------------------------------------
+    def _materialize(self, name: str, shape) -> _Tensor:
+        if name in self.tensors:
+            t = self.tensors[name]
+            if _prod(t.shape) != _prod(shape):
+                raise NetSpecError(f"blob {name}: storage of {t.shape} reused for {shape}")
+            return t
+        t = _Tensor(self.alloc.empty(_prod(shape), np.float32), shape, name)
+        self.tensors[name] = t
+        return t
+
+    def _alias(self, name: str, src: str, shape) -> None:
+        s = self.tensors[src]
+        self.tensors[name] = _Tensor(s.handle, shape, s.owner)
+
+    def _ptr(self, name: str, offset_elems: int = 0) -> int:
+        if name not in self.tensors:
+            why = self.fused_away.get(name, "not produced")
+            raise KeyError(f"blob {name!r} is not materialised ({why}); build the net with fuse=False to observe it")
+        return self.alloc.ptr(self.tensors[name].handle) + 4 * int(offset_elems)
+
+    def _pdev(self, layer: str, key: str) -> int:
+        return self.alloc.ptr(self._param_dev[layer][key])
+
+    def _add(self, idx: int, label: str, fn: Callable[[Optional[int]], None], meta: Optional[dict] = None) -> None:
+        self.ops.append((idx, label, fn, meta or {"kernel": label.split("[")[0], "flops": 0, "bytes": 0}))
+
+    # ------------------------------------------------------------------ unfused
+    def _emit_unfused(self, i: int, L: LayerSpec) -> None:
+        lib = self.lib
+        t = L.type
+        bshape = L.bottom_shapes[0] if L.bottom_shapes else None
+        if t in _ALIAS_TYPES:
+            if L.bottoms[0] not in self.tensors:  # alias of a blob that lives only inside a fused group
+                for top in L.tops:
+                    self.fused_away[top] = self.fused_away.get(L.bottoms[0], "alias of a non-materialised blob")
+                return
+            for top, shp in zip(L.tops, L.top_shapes):
+                if top != L.bottoms[0]:
+                    self._alias(top, L.bottoms[0], shp)
+                else:
+                    self.tensors[top] = _Tensor(self.tensors[top].handle, shp, self.tensors[top].owner)
+            return
+        top = L.tops[0]
+        inplace = top in L.bottoms
+        if not inplace:
+            self._materialize(top, L.top_shapes[0])
+        if t == "Convolution":
+            st = self._param_dev[L.name]
+            ep = hip.ConvEpilogue()
+            ep.bias = self._pdev(L.name, "bias") if L.geom["bias_term"] else None
+            ep.residual = hip.null_view()
+            ep.raw = hip.plain_view(self._ptr(top), L.geom["cout"], _prod(L.top_shapes[0][2:]))
+            ep.bn_scale = None
+            ep.bn_shift = None
+            ep.relu = 0
+            ep.act = hip.null_view()
+            self._emit_conv(i, L, ep, L.name)
+        elif t == "BN":
+            x, y = self._ptr(L.bottoms[0]), self._ptr(top)
+            n, c, inner = bshape[0], bshape[1], _prod(bshape[2:])
+            sc, sh = self._pdev(L.name, "scale"), self._pdev(L.name, "shift")
+            self._add(i, L.name, lambda s, x=x, y=y, sc=sc, sh=sh, n=n, c=c, inner=inner:
+                      lib.bn_forward(x, y, sc, sh, n, c, inner, 0, s))
+        elif t == "ReLU":
+            x, y, cnt, slope = self._ptr(L.bottoms[0]), self._ptr(top), _prod(bshape), L.geom["negative_slope"]
+            self._add(i, L.name, lambda s, x=x, y=y, cnt=cnt, slope=slope: lib.relu_forward(x, y, cnt, slope, s))
+        elif t == "Pooling":
+            self._emit_pool(i, L, self._ptr(L.bottoms[0]), self._ptr(top))
+        elif t == "Concat":
+            self._emit_concat(i, L, skip=())
+        elif t == "Eltwise":
+            cf = L.geom["coeff"]
+            y, cnt = self._ptr(top), _prod(bshape)
+            a, b = self._ptr(L.bottoms[0]), self._ptr(L.bottoms[1])
+            self._add(i, L.name, lambda s, a=a, b=b, y=y, cnt=cnt, ca=cf[0], cb=cf[1]:
+                      lib.eltwise_sum_forward(a, b, y, cnt, ca, cb, s))
+            for k in range(2, len(L.bottoms)):  # y += c_k * bottom_k
+                bk = self._ptr(L.bottoms[k])
+                self._add(i, L.name, lambda s, bk=bk, y=y, cnt=cnt, ck=cf[k]:
+                          lib.eltwise_sum_forward(y, bk, y, cnt, 1.0, ck, s))
+        elif t == "Permute":
+            x, y = self._ptr(L.bottoms[0]), self._ptr(top)
+            shp, order = list(bshape), list(L.geom["order"])
+            if len(shp) > 6:
+                raise NetSpecError(f"{L.name}: Permute of {len(shp)} axes unsupported")
+            self._add(i, L.name, lambda s, x=x, y=y, shp=shp, order=order: lib.permute_forward(x, y, shp, order, s))
+        elif t == "InnerProduct":
+            g = L.geom
+            x, y = self._ptr(L.bottoms[0]), self._ptr(top)
+            w = self._pdev(L.name, "w")
+            b = self._pdev(L.name, "bias") if g["bias_term"] else None
+            self._add(i, L.name, lambda s, x=x, w=w, b=b, y=y, m=g["M"], n=g["num_output"], k=g["K"]:
+                      lib.inner_product_forward(x, w, b, y, m, n, k, s))
+        elif t == "Softmax":
+            ax = L.geom["axis"]
+            x, y = self._ptr(L.bottoms[0]), self._ptr(top)
+            outer, c, inner = _prod(bshape[:ax]), bshape[ax], _prod(bshape[ax + 1:])
+            self._add(i, L.name, lambda s, x=x, y=y, outer=outer, c=c, inner=inner:
+                      lib.softmax_forward(x, y, outer, c, inner, s))
+        else:  # pragma: no cover
+            raise NetSpecError(f"no HIP launcher for layer type {t}")
+
+    def _emit_conv(self, i: int, L: LayerSpec, ep: "hip.ConvEpilogue", label: str) -> None:
+        st = self._param_dev[L.name]
+        g, plan = st["geom"], st["plan"]
+        x = self._ptr(L.bottoms[0])
+        wp, kt = self.alloc.ptr(st["wp"]), self.alloc.ptr(st["ktab"])
+        self._keep.append((g, plan, ep))
+        lib = self.lib
+        n_out = _prod(L.top_shapes[0])
+        k = L.geom["cin"] * _prod(L.geom["kernel"])
+        # algorithmic bytes (fused model): input + weights + each tensor the epilogue touches, once
+        nbytes = 4 * (_prod(L.bottom_shapes[0]) + k * L.geom["cout"]
+                      + n_out * (bool(ep.raw.ptr) + bool(ep.act.ptr) + bool(ep.residual.ptr)))
+        meta = {"kernel": f"conv_igemm_bm{plan.bm}_bn{plan.bn}_kc{plan.kc}", "flops": 2 * n_out * k, "bytes": nbytes}
+        self._add(i, label, lambda s, g=g, plan=plan, x=x, wp=wp, kt=kt, ep=ep: lib.conv_forward(g, plan, x, wp, kt, ep, s),
+                  meta)
+
+    def _emit_pool(self, i: int, L: LayerSpec, x: int, y: int) -> None:
+        g = L.geom
+        b = L.bottom_shapes[0]
+        pg = hip.pool_geom(b[0], b[1], b[2:], g["kernel"], g["stride"], g["pad"], L.top_shapes[0][2:], g["method"])
+        self._keep.append(pg)
+        lib = self.lib
+        self._add(i, L.name, lambda s, pg=pg, x=x, y=y: lib.pool_forward(pg, x, y, s),
+                  {"kernel": "pool_" + g["method"].lower(), "flops": 0,
+                   "bytes": 4 * (_prod(b) + _prod(L.top_shapes[0]))})
+
+    def _emit_concat(self, i: int, L: LayerSpec, skip: Sequence[int]) -> None:
+        ax = L.geom["axis"]
+        tshape = L.top_shapes[0]
+        outer, cy, inner = _prod(tshape[:ax]), tshape[ax], _prod(tshape[ax + 1:])
+        y = self._ptr(L.tops[0])
+        c0 = 0
+        lib = self.lib
+        for k, (b, bs) in enumerate(zip(L.bottoms, L.bottom_shapes)):
+            cx = bs[ax]
+            if k not in skip:
+                x = self._ptr(b)
+                self._add(i, f"{L.name}[{k}]", lambda s, x=x, y=y, outer=outer, cx=cx, cy=cy, c0=c0, inner=inner:
+                          lib.concat_copy(x, y, outer, cx, cy, c0, inner, s))
+            c0 += cx
+
+    # ------------------------------------------------------------------ fused plan
+    def _resolve(self, blob: str) -> str:
+        """Follow Split aliases back to the blob that a real layer produced."""
+        return self._alias_src.get(blob, blob)
+
+    def _build_fused(self) -> None:
+        spec = self.spec
+        layers = spec.layers
+        # --- dataflow over "real" blobs: Split tops are names for their bottom -------------
+        self._alias_src: Dict[str, str] = {}
+        for L in layers:
+            if L.type == "Split":
+                for t in L.tops:
+                    self._alias_src[t] = self._resolve(L.bottoms[0])
+        consumers: Dict[str, List[int]] = {}
+        for i, L in enumerate(layers):
+            if L.type == "Split":
+                continue
+            for b in L.bottoms:
+                consumers.setdefault(self._resolve(b), []).append(i)
+        outputs = set(spec.outputs)
+
+        def sole_consumer(blob: str, typ: str) -> Optional[int]:
+            cs = consumers.get(blob, [])
+            if len(cs) == 1 and layers[cs[0]].type == typ and blob not in outputs:
+                return cs[0]
+            return None
+
+        def bn_relu_after(blob: str) -> Optional[Tuple[int, int]]:
+            """(bn idx, relu idx) if `blob` feeds a non-in-place BN whose top is first hit by an in-place ReLU."""
+            for ci in consumers.get(blob, []):
+                Lb = layers[ci]
+                if Lb.type != "BN" or Lb.inplace:
+                    continue
+                tb = Lb.tops[0]
+                cs = consumers.get(tb, [])
+                if cs and layers[cs[0]].type == "ReLU" and layers[cs[0]].inplace and \
+                        layers[cs[0]].geom["negative_slope"] == 0.0 and cs[0] > ci:
+                    return ci, cs[0]
+            return None
+
+        absorbed: Dict[int, str] = {}       # layer idx -> label of the group that runs it
+        concat_skip: Dict[int, List[int]] = {}
+        # act-destination overrides decided per conv: blob name -> (dest blob, View factory)
+        for i, L in enumerate(layers):
+            if i in absorbed:
+                continue
+            if L.type == "Convolution":
+                self._fuse_conv(i, L, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed, concat_skip)
+            elif L.type == "Pooling" and self._try_fuse_tail(i, L, layers, sole_consumer, absorbed):
+                pass
+            elif L.type == "Concat":
+                if L.tops[0] not in self.tensors:
+                    self._materialize(L.tops[0], L.top_shapes[0])
+                self._emit_concat(i, L, skip=concat_skip.get(i, ()))
+            else:
+                self._emit_unfused(i, L)
+
+    def _fuse_conv(self, i, L, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed, concat_skip) -> None:
+        cout = L.geom["cout"]
+        S = _prod(L.top_shapes[0][2:])
+        ep = hip.ConvEpilogue()
+        ep.bias = self._pdev(L.name, "bias") if L.geom["bias_term"] else None
+        ep.residual = hip.null_view()
+        ep.raw = hip.null_view()
+        ep.act = hip.null_view()
+        ep.bn_scale = None
+        ep.bn_shift = None
+        ep.relu = 0
+        label = L.name
+        value = L.tops[0]  # blob holding "v" of the epilogue
+        # 1. Eltwise SUM absorbed when this conv's top feeds nothing else and the other operand exists already
+        ei = sole_consumer(value, "Eltwise")
+        if ei is not None and ei not in absorbed:
+            E = layers[ei]
+            others = [b for b in E.bottoms if self._resolve(b) != value]
+            if len(E.bottoms) == 2 and len(others) == 1 and all(c == 1.0 for c in E.geom["coeff"]) \
+                    and self._resolve(others[0]) in self.tensors:
+                r = self._resolve(others[0])
+                ep.residual = hip.plain_view(self._ptr(r), cout, S)
+                self.fused_away[value] = f"summed into {E.tops[0]} inside the epilogue of {L.name}"
+                absorbed[ei] = L.name
+                value = E.tops[0]
+                label += "+" + E.name
+        # 2. BN + in-place ReLU on the value
+        br = bn_relu_after(value)
+        act_blob = None
+        if br is not None and br[0] not in absorbed:
+            bi, ri = br
+            Lb = layers[bi]
+            ep.bn_scale = self._pdev(Lb.name, "scale")
+            ep.bn_shift = self._pdev(Lb.name, "shift")
+            ep.relu = 1
+            absorbed[bi] = L.name
+            absorbed[ri] = L.name
+            act_blob = Lb.tops[0]
+            label += "+" + Lb.name + "+" + layers[ri].name
+        # 3. raw output: needed if anything else reads the value
+        rest = [c for c in consumers.get(value, []) if absorbed.get(c) != L.name]
+        if act_blob is None or rest or value in outputs:
+            self._materialize(value, L.top_shapes[0])
+            ep.raw = hip.plain_view(self._ptr(value), cout, S)
+        else:
+            self.fused_away[value] = f"only exists inside the fused epilogue of {L.name}"
+        # 4. activated output and its destination
+        if act_blob is not None:
+            dest = self._act_destination(act_blob, L, layers, consumers, outputs, absorbed, concat_skip)
+            if dest is None:
+                self._materialize(act_blob, L.top_shapes[0])
+                ep.act = hip.plain_view(self._ptr(act_blob), cout, S)
+            else:
+                ep.act = dest
+        self._emit_conv(i, L, ep, label)
+
+    def _act_destination(self, act_blob, L, layers, consumers, outputs, absorbed, concat_skip):
+        """Strided destination for a fused conv's activated output, or None for a dense tensor."""
+        if act_blob in outputs:
+            return None
+        cs = [c for c in consumers.get(act_blob, []) if absorbed.get(c) != L.name]
+        if len(cs) != 1:
+            return None
+        Lc = layers[cs[0]]
+        cout = L.geom["cout"]
+        tshape = L.top_shapes[0]
+        S = _prod(tshape[2:])
+        # (a) channel slice of a Concat top
+        if Lc.type == "Concat" and Lc.geom["axis"] == 1:
+            k = [self._resolve(b) for b in Lc.bottoms].index(act_blob)
+            if [self._resolve(b) for b in Lc.bottoms].count(act_blob) != 1:
+                return None
+            ctot = Lc.top_shapes[0][1]
+            c0 = sum(bs[1] for bs in Lc.bottom_shapes[:k])
+            if Lc.tops[0] not in self.tensors:
+                self._materialize(Lc.tops[0], Lc.top_shapes[0])
+            concat_skip.setdefault(cs[0], []).append(k)
+            self.fused_away[act_blob] = f"written directly into channels [{c0},{c0 + cout}) of {Lc.tops[0]}"
+            return hip.View(self._ptr(Lc.tops[0], c0 * S), ctot * S, 0, S, 1)
+        # (b) r2Dto3D Reshape [-1,T,C,H,W] followed by Permute [0,2,1,3,4]
+        if Lc.type == "Reshape" and len(tshape) == 4 and len(Lc.top_shapes[0]) == 5:
+            rs = Lc.top_shapes[0]
+            if tuple(rs[2:]) != tuple(tshape[1:]):
+                return None
+            pcs = consumers.get(Lc.tops[0], [])
+            if len(pcs) != 1 or Lc.tops[0] in outputs:
+                return None
+            Lp = layers[pcs[0]]
+            if Lp.type != "Permute" or list(Lp.geom["order"]) != [0, 2, 1, 3, 4]:
+                return None
+            T, Cc = rs[1], rs[2]
+            self._materialize(Lp.tops[0], Lp.top_shapes[0])
+            absorbed[cs[0]] = L.name
+            absorbed[pcs[0]] = L.name
+            self.fused_away[act_blob] = f"written through {Lc.name}+{Lp.name} directly into {Lp.tops[0]}"
+            self.fused_away[Lc.tops[0]] = self.fused_away[act_blob]
+            return hip.View(self._ptr(Lp.tops[0]), Cc * T * S, S, T * S, T)
+        return None
+
+    def _try_fuse_tail(self, i, L, layers, sole_consumer, absorbed) -> bool:
+        """global AVE pool -> Reshape [-1,C] -> (Dropout) -> InnerProduct as one launch."""
+        g = L.geom
+        b = L.bottom_shapes[0]
+        if g["method"] != "AVE" or list(g["kernel"]) != list(b[2:]) or any(p != 0 for p in g["pad"]) \
+                or any(o != 1 for o in L.top_shapes[0][2:]):
+            return False
+        ri = sole_consumer(L.tops[0], "Reshape")
+        if ri is None:
+            return False
+        Lr = layers[ri]
+        if tuple(Lr.top_shapes[0]) != (b[0], b[1]):
+            return False
+        chain = [ri]
+        blob = Lr.tops[0]
+        # in-place Dropout (TEST = identity) may sit on the reshaped blob
+        cs = [c for c in self._consumers_of(blob)]
+        drop = [c for c in cs if layers[c].type == "Dropout" and layers[c].inplace]
+        fcs = [c for c in cs if layers[c].type == "InnerProduct"]
+        if len(fcs) != 1 or len(cs) != len(drop) + 1 or blob in self.spec.outputs:
+            return False
+        Lf = layers[fcs[0]]
+        if Lf.geom["K"] != b[1] or Lf.geom["M"] != b[0]:
+            return False
+        chain += drop + fcs
+        for c in chain:
+            absorbed[c] = L.name
+        for nm in (L.tops[0], blob):
+            self.fused_away[nm] = f"only exists inside the fused {L.name}+{Lf.name} tail"
+        self._materialize(Lf.tops[0], Lf.top_shapes[0])
+        x, y = self._ptr(L.bottoms[0]), self._ptr(Lf.tops[0])
+        w = self._pdev(Lf.name, "w")
+        bias = self._pdev(Lf.name, "bias") if Lf.geom["bias_term"] else None
+        B, Cc, S, n_out = b[0], b[1], _prod(b[2:]), Lf.geom["num_output"]
+        lib = self.lib
+        self._add(i, f"{L.name}+{Lf.name}", lambda s, x=x, w=w, bias=bias, y=y, B=B, Cc=Cc, S=S, n_out=n_out:
+                  lib.global_avgpool_fc_forward(x, w, bias, y, B, Cc, S, n_out, Cc, 0, False, s))
+        return True
+
+    def _consumers_of(self, blob: str) -> List[int]:
+        return [i for i, L in enumerate(self.spec.layers)
+                if L.type != "Split" and any(self._resolve(b) == blob for b in L.bottoms)]
+
+    # ------------------------------------------------------------------ run
+    def forward(self, start: int = 0, end: Optional[int] = None, stream: Optional[int] = None) -> None:
+        if not self._built:
+            self.build()
+        self._sync_params()
+        end = len(self.spec.layers) - 1 if end is None else end
+        if stream is None and hasattr(self.alloc, "stream"):
+            stream = self.alloc.stream()
+        for idx, _label, fn, _meta in self.ops:
+            if start <= idx <= end:
+                fn(stream)
+
+    def op_labels(self) -> List[str]:
+        return [op[1] for op in self.ops]
+
+    def profile(self, iters: int = 3) -> List[dict]:
+        """Per-launch device time (ms, mean over ``iters``) measured with HIP events on the
+        launch stream (the tools/caffe.cpp:276-360 `caffe time` idea, per launch instead of
+        per layer).  Needs the torch allocator (events are torch.cuda.Event on its stream)."""
+        torch = self.alloc.torch
+        self._sync_params()
+        stream = self.alloc.stream()
+        n = len(self.ops)
+        tot = [0.0] * n
+        for _ in range(iters):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+            evs[0].record()
+            for j, (_i, _l, fn, _m) in enumerate(self.ops):
+                fn(stream)
+                evs[j + 1].record()
+            torch.cuda.synchronize()
+            for j in range(n):
+                tot[j] += evs[j].elapsed_time(evs[j + 1])
+        return [dict(label=op[1], ms=tot[j] / iters, **op[3]) for j, op in enumerate(self.ops)]

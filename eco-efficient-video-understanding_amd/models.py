@@ -24,8 +24,13 @@ _BN_FILL = "slope_filler { type: \"constant\" value: 1 } bias_filler { type: \"c
 
 
 class _Builder:
-    def __init__(self) -> None:
+    def __init__(self, width_div: int = 1) -> None:
         self.out: List[str] = []
+        self.width_div = int(width_div)
+
+    def ch(self, c: int) -> int:
+        """Channel count after the (test-only) width divisor."""
+        return c if self.width_div == 1 else max(4, c // self.width_div)
 
     def emit(self, s: str) -> None:
         self.out.append(s)
@@ -39,7 +44,7 @@ class _Builder:
         self.emit(
             f'layer {{ name: "{name}" type: "Convolution" bottom: "{bottom}" top: "{top}" '
             f"param {{ lr_mult: 1 decay_mult: 1 }} param {{ lr_mult: 2 decay_mult: 0 }} "
-            f"convolution_param {{ num_output: {cout} {rep('pad', p, 0)}{rep('kernel_size', k, None)}"
+            f"convolution_param {{ num_output: {self.ch(cout)} {rep('pad', p, 0)}{rep('kernel_size', k, None)}"
             f"{rep('stride', s, 1)}{_XAVIER} }} }}")
 
     def bn(self, name: str, bottom: str, top: str, frozen_field: bool = False) -> None:
@@ -119,9 +124,9 @@ def _head_2d(b: _Builder) -> str:
     return t
 
 
-def _trunk_3d(b: _Builder, bottom_2d: str, num_segments: int) -> str:
+def _trunk_3d(b: _Builder, bottom_2d: str, num_segments: int, sp: int = 28) -> str:
     """r2Dto3D + Permute + 3D-ResNet-18 res3a..res5b (pre-activation residuals)."""
-    b.reshape("r2Dto3D", bottom_2d, "res2b_bn_pre", [-1, num_segments, 96, 28, 28])
+    b.reshape("r2Dto3D", bottom_2d, "res2b_bn_pre", [-1, num_segments, b.ch(96), sp, sp])
     b.emit('layer { name: "Transpose1" type: "Permute" bottom: "res2b_bn_pre" top: "res2b_bn" '
            "permute_param { order: [0,2,1,3,4] } }")
     b.res_conv("res3a_2n", "res2b_bn", "res3a", 128, 1)
@@ -158,26 +163,28 @@ def _header(name: str, frames: int, size: int) -> str:
             f"input_dim: {size}\ninput_dim: {size}\n")
 
 
-def _check_segments(num_segments: int) -> None:
+def _check_segments(num_segments: int, input_size: int) -> None:
     if num_segments < 4 or num_segments % 4:
         raise ValueError("num_segments must be a positive multiple of 4 (global_pool depth = N/4)")
+    if input_size < 32 or input_size % 32:
+        raise ValueError("input_size must be a positive multiple of 32 (224 in every reference net)")
 
 
 def eco_lite_deploy(num_segments: int = 16, num_clips: int = 5, num_classes: int = 400,
                     dropout_ratio: float = 0.3, fc_name: str = "fc8", net_name: str = "ECOLite",
-                    input_size: int = 224) -> str:
-    """ECO-Lite deploy graph (models_ECO_Lite/kinetics/deploy.prototxt for the defaults)."""
-    _check_segments(num_segments)
-    if input_size != 224:
-        raise ValueError("the ECO graphs hard-code 28x28 at r2Dto3D: input must be 224x224")
-    b = _Builder()
+                    input_size: int = 224, width_div: int = 1) -> str:
+    """ECO-Lite deploy graph (models_ECO_Lite/kinetics/deploy.prototxt for the defaults).
+    ``input_size`` != 224 / ``width_div`` != 1 give geometrically similar small nets for tests."""
+    _check_segments(num_segments, input_size)
+    b = _Builder(width_div)
+    sp = input_size // 8
     t = _head_2d(b)
     t = b.conv_bn_relu_2d("inception_3c", "double_3x3_reduce", t, 64, 1)
     t = b.conv_bn_relu_2d("inception_3c", "double_3x3_1", t, 96, 3, 1, 1)
-    t = _trunk_3d(b, t, num_segments)
+    t = _trunk_3d(b, t, num_segments, sp)
     b.pool("global_pool", t, "global_pool", "AVE",
-           f"kernel_size: [{num_segments // 4}, 7, 7] stride: [1, 1, 1]")
-    b.reshape("global_pool_reshape", "global_pool", "global_pool_reshape", [-1, 512])
+           f"kernel_size: [{num_segments // 4}, {sp // 4}, {sp // 4}] stride: [1, 1, 1]")
+    b.reshape("global_pool_reshape", "global_pool", "global_pool_reshape", [-1, b.ch(512)])
     b.dropout("dropout", "global_pool_reshape", dropout_ratio)
     _fc(b, fc_name, "global_pool_reshape", num_classes)
     return _header(net_name, num_clips * num_segments, input_size) + "\n".join(b.out) + "\n"
@@ -185,21 +192,21 @@ def eco_lite_deploy(num_segments: int = 16, num_clips: int = 5, num_classes: int
 
 def eco_full_deploy(num_segments: int = 16, num_clips: int = 5, num_classes: int = 400,
                     dropout_ratio_3d: float = 0.5, dropout_ratio_2d: float = 0.6,
-                    fc_name: str = "fc8N", net_name: str = "o3d", input_size: int = 224) -> str:
+                    fc_name: str = "fc8N", net_name: str = "o3d", input_size: int = 224,
+                    width_div: int = 1) -> str:
     """ECO-Full deploy graph (models_ECO_Full/kinetics/deploy.prototxt for the defaults):
     2D head -> {3D trunk, rest of BN-Inception 3c..5b as a per-frame 2D stream with
     segment consensus} -> concat(1024 + 512) -> fc."""
-    _check_segments(num_segments)
-    if input_size != 224:
-        raise ValueError("the ECO graphs hard-code 28x28 at r2Dto3D: input must be 224x224")
-    b = _Builder()
+    _check_segments(num_segments, input_size)
+    b = _Builder(width_div)
+    sp = input_size // 8
     t3b = _head_2d(b)
     # inception_3c (stride-2 block); its double_3x3_1 output also feeds the 3D trunk
     r = b.conv_bn_relu_2d("inception_3c", "3x3_reduce", t3b, 128, 1)
     c3 = b.conv_bn_relu_2d("inception_3c", "3x3", r, 160, 3, 2, 1)
     r = b.conv_bn_relu_2d("inception_3c", "double_3x3_reduce", t3b, 64, 1)
     d1 = b.conv_bn_relu_2d("inception_3c", "double_3x3_1", r, 96, 3, 1, 1)
-    t3d = _trunk_3d(b, d1, num_segments)
+    t3d = _trunk_3d(b, d1, num_segments, sp)
     d2 = b.conv_bn_relu_2d("inception_3c", "double_3x3_2", d1, 96, 3, 2, 1)
     b.pool("inception_3c_pool", t3b, "inception_3c_pool", "MAX", "kernel_size: 3 stride: 2")
     b.concat("inception_3c_output", [c3, d2, "inception_3c_pool"], "inception_3c_output")
@@ -218,15 +225,16 @@ def eco_full_deploy(num_segments: int = 16, num_clips: int = 5, num_classes: int
     b.concat("inception_4e_output", [c3, d2, "inception_4e_pool"], "inception_4e_output")
     t = b.inception("inception_5a", "inception_4e_output", 352, 192, 320, 160, 224, "AVE", 128)
     t = b.inception("inception_5b", t, 352, 192, 320, 192, 224, "MAX", 128)
-    b.pool("global_pool2D", t, "global_pool2D", "AVE", "kernel_size: 7 stride: 1")
+    b.pool("global_pool2D", t, "global_pool2D", "AVE", f"kernel_size: {sp // 4} stride: 1")
     b.dropout("dropout2D", "global_pool2D", dropout_ratio_2d)
-    b.reshape("reshape_fc_st2", "global_pool2D", "reshape_fc_st2", [-1, 1, num_segments, 1024])
+    c2d = b.ch(352) + b.ch(320) + b.ch(224) + b.ch(128)  # inception_5b_output channels (1024)
+    b.reshape("reshape_fc_st2", "global_pool2D", "reshape_fc_st2", [-1, 1, num_segments, c2d])
     b.pool("segment_consensus_st2", "reshape_fc_st2", "pool_fusion_st2", "AVE",
            f"kernel_h: {num_segments} kernel_w: 1")
-    b.reshape("global_pool_reshape2D", "pool_fusion_st2", "pool_fusion_st2D", [-1, 1024])
+    b.reshape("global_pool_reshape2D", "pool_fusion_st2", "pool_fusion_st2D", [-1, c2d])
     b.pool("global_pool", t3d, "global_pool", "AVE",
-           f"kernel_size: [{num_segments // 4}, 7, 7] stride: [1, 1, 1]")
-    b.reshape("global_pool_reshape", "global_pool", "global_pool_reshape", [-1, 512])
+           f"kernel_size: [{num_segments // 4}, {sp // 4}, {sp // 4}] stride: [1, 1, 1]")
+    b.reshape("global_pool_reshape", "global_pool", "global_pool_reshape", [-1, b.ch(512)])
     b.dropout("dropout", "global_pool_reshape", dropout_ratio_3d)
     b.concat("gn02_concat", ["pool_fusion_st2D", "global_pool_reshape"], "global_pool_gn02_reshape", axis=1)
     _fc(b, fc_name, "global_pool_gn02_reshape", num_classes)

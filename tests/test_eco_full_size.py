@@ -1,0 +1,92 @@
+"""Full-size ECO parity on a real MI355X (`-m gpu`), through the pycaffe-style Net -> C ABI.
+
+* ECO-Lite at BASELINE.json configs[0] (num_segments=4, 1 clip, 224x224): logits and every
+  materialised blob vs the CPU oracle, fused and unfused plans.
+* ECO-Full (configs[3] topology) at num_segments=4, 1 clip.
+* configs[1] size (num_segments=16, 32 clips): the oracle is too slow for 32 clips, so the check is
+  (a) 1 clip vs the oracle and (b) size-independent properties: clips are independent units
+  (batch row i == the same clip run alone; permuting clips permutes logits), and the fused and
+  unfused plans agree.
+Tolerance: 1e-3 relative to max|logit| (north_star), in practice ~1e-6.
+"""
+import numpy as np
+import pytest
+
+import eco_oracle as orc
+from eco_amd import fillers, models
+from eco_amd.net import Net
+from eco_amd.netspec import NetSpec
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def relerr(got, ref):
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
+@pytest.mark.parametrize("variant", ["lite", "full"])
+def test_eco_n4_b1_vs_oracle(variant):
+    gen = models.eco_lite_deploy if variant == "lite" else models.eco_full_deploy
+    proto = gen(num_segments=4, num_clips=1)
+    spec = NetSpec.from_prototxt(proto)
+    params = fillers.synthetic_params(spec)
+    x = fillers.synthetic_frames(4)
+    ref = orc.forward(spec, params, {"data": x}, keep="all")
+    for fuse in (True, False):
+        net = Net(proto, params=params, fuse=fuse)
+        net.blobs["data"].data[...] = x
+        out = net.forward()["fc8"]
+        assert np.isfinite(out).all()
+        assert relerr(out, ref["fc8"]) < TOL
+        assert out.argmax() == ref["fc8"].argmax()
+        worst = 0.0
+        for name in net.blobs:
+            if name in net._engine.tensors:
+                got = net.blobs[name].data
+                worst = max(worst, relerr(got, ref[name].reshape(got.shape)))
+        assert worst < TOL, worst
+
+
+def test_eco_lite_c2_properties():
+    N, B = 16, 32
+    proto = models.eco_lite_deploy(num_segments=N, num_clips=B)
+    spec = NetSpec.from_prototxt(proto)
+    assert abs(spec.conv_fc_flops() / 1e9 - 2975.13) < 0.01
+    params = fillers.synthetic_params(spec)
+    x = fillers.synthetic_frames(B * N)
+    net = Net(proto, params=params)
+    out = net.forward(data=x)["fc8"].copy()
+    assert out.shape == (B, 400) and np.isfinite(out).all()
+    scale = np.abs(out).max()
+    # (a) one clip against the CPU oracle
+    spec1 = NetSpec.from_prototxt(models.eco_lite_deploy(num_segments=N, num_clips=1))
+    ref0 = orc.forward(spec1, params, {"data": x[:N]})["fc8"]
+    assert relerr(out[:1], ref0) < TOL and out[0].argmax() == ref0.argmax()
+    # (b1) clips are independent: row 17 of the batch == that clip alone
+    net1 = Net(models.eco_lite_deploy(num_segments=N, num_clips=1), params=params)
+    alone = net1.forward(data=x[17 * N:18 * N])["fc8"]
+    assert np.abs(alone[0] - out[17]).max() < 1e-5 * scale
+    # (b2) permuting clips permutes the logits
+    perm = np.random.default_rng(0).permutation(B)
+    xp = x.reshape(B, N, 3, 224, 224)[perm].reshape(B * N, 3, 224, 224)
+    outp = net.forward(data=xp)["fc8"]
+    assert np.abs(outp - out[perm]).max() < 1e-5 * scale
+    # (b3) the layer-by-layer plan agrees with the fused plan
+    del net1
+    netu = Net(proto, params=params, fuse=False)
+    outu = netu.forward(data=x)["fc8"]
+    assert np.abs(outu - out).max() < 1e-5 * scale
+
+
+def test_eco_lite_n32_shapes():
+    """configs[4] geometry (num_segments=32: r2Dto3D dim 32, global_pool 8x7x7; README.md:85-95), 2 clips, fp32."""
+    proto = models.eco_lite_deploy(num_segments=32, num_clips=2)
+    spec = NetSpec.from_prototxt(proto)
+    assert spec.blob_shapes["res2b_bn"] == (2, 96, 32, 28, 28) and spec.blob_shapes["res5b_bn"] == (2, 512, 8, 7, 7)
+    params = fillers.synthetic_params(spec)
+    x = fillers.synthetic_frames(64)
+    out = Net(proto, params=params).forward(data=x)["fc8"]
+    spec1 = NetSpec.from_prototxt(models.eco_lite_deploy(num_segments=32, num_clips=1))
+    ref = orc.forward(spec1, params, {"data": x[:32]})["fc8"]
+    assert relerr(out[:1], ref) < TOL

@@ -1,0 +1,262 @@
+"""Parity of every C-ABI operator against the CPU oracle, on both backends:
+`emu` (CPU fiber emulator, small shapes, runs in the CPU suite) and `hip` (real MI355X,
+`-m gpu`, larger shapes incl. the real ECO layer geometries).
+
+Tolerance: fp32 results, relative to the tensor's max magnitude, 1e-5 (summation order is
+the only difference between the MFMA fmaf chain and the oracle's sgemm)."""
+import numpy as np
+import pytest
+
+import eco_oracle as orc
+from eco_amd import hip
+
+TOL = 1e-5
+
+
+def relerr(got, ref):
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
+def run_conv(be, n, cin, cout, insp, k, s, p, mode="plain", seed=0):
+    rng = np.random.default_rng(seed)
+    nd = len(insp)
+    x = rng.standard_normal((n, cin) + tuple(insp)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin) + tuple(k)) / np.sqrt(cin * np.prod(k))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = orc.convolution(x, w, b, k, s, p)
+    outsp = ref.shape[2:]
+    S = int(np.prod(outsp))
+    lib = be.lib
+    g = hip.conv_geom(n, cin, cout, insp, k, s, p, outsp)
+    plan = lib.conv_plan(g)
+    wp = np.zeros(plan.wp_elems, np.float32)
+    kt = np.zeros(plan.ktab_elems, np.int32)
+    lib.conv_pack_weights(g, plan, w.ctypes.data, wp.ctypes.data, kt.ctypes.data)
+    dx, dwp, dkt, db = be.dev(x), be.dev(wp), be.dev(kt), be.dev(b)
+    ep = hip.ConvEpilogue()
+    ep.bias = be.ptr(db)
+    ep.residual, ep.raw, ep.act = hip.null_view(), hip.null_view(), hip.null_view()
+    ep.bn_scale = ep.bn_shift = None
+    ep.relu = 0
+    bshape = (1, cout) + (1,) * nd
+    if mode == "plain":
+        raw = be.empty(ref.shape)
+        ep.raw = hip.plain_view(be.ptr(raw), cout, S)
+        lib.conv_forward(g, plan, be.ptr(dx), be.ptr(dwp), be.ptr(dkt), ep)
+        assert relerr(be.host(raw, ref.shape), ref) < TOL
+    elif mode == "fused":  # bias + residual + raw + BN + ReLU -> act
+        res = rng.standard_normal(ref.shape).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        sh = rng.standard_normal(cout).astype(np.float32)
+        dres, dsc, dsh = be.dev(res), be.dev(sc), be.dev(sh)
+        raw, act = be.empty(ref.shape), be.empty(ref.shape)
+        ep.residual = hip.plain_view(be.ptr(dres), cout, S)
+        ep.raw = hip.plain_view(be.ptr(raw), cout, S)
+        ep.act = hip.plain_view(be.ptr(act), cout, S)
+        ep.bn_scale, ep.bn_shift, ep.relu = be.ptr(dsc), be.ptr(dsh), 1
+        lib.conv_forward(g, plan, be.ptr(dx), be.ptr(dwp), be.ptr(dkt), ep)
+        exp_raw = ref + res
+        exp_act = np.maximum(exp_raw * sc.reshape(bshape) + sh.reshape(bshape), 0)
+        assert relerr(be.host(raw, ref.shape), exp_raw) < TOL
+        assert relerr(be.host(act, ref.shape), exp_act) < TOL
+    elif mode == "concat":  # act-only, written into channels [c0, c0+cout) of a wider tensor
+        c0, ctot = 3, cout + 7
+        big = be.dev(np.full((n, ctot) + tuple(outsp), 7.0, np.float32))
+        ep.act = hip.View(be.ptr(big, c0 * S), ctot * S, 0, S, 1)
+        ep.relu = 1
+        lib.conv_forward(g, plan, be.ptr(dx), be.ptr(dwp), be.ptr(dkt), ep)
+        got = be.host(big, (n, ctot) + tuple(outsp))
+        assert relerr(got[:, c0:c0 + cout], np.maximum(ref, 0)) < TOL
+        assert (got[:, :c0] == 7.0).all() and (got[:, c0 + cout:] == 7.0).all()
+    elif mode == "permute":  # [B*T, C, H, W] conv output stored as [B, C, T, H, W]
+        T = 2
+        assert n % T == 0 and nd == 2
+        out = be.empty(ref.shape)
+        ep.act = hip.View(be.ptr(out), cout * T * S, S, T * S, T)
+        lib.conv_forward(g, plan, be.ptr(dx), be.ptr(dwp), be.ptr(dkt), ep)
+        exp = ref.reshape((n // T, T, cout) + tuple(outsp)).transpose(0, 2, 1, 3, 4)
+        assert relerr(be.host(out, exp.shape), exp) < TOL
+    return plan
+
+
+# (n, cin, cout, in spatial, kernel, stride, pad) -- small enough for the emulator.
+SMALL_CONVS = [
+    (2, 3, 4, (6, 4), (3, 3), (2, 2), (0, 0)),             # reference TestSimpleConvolution shape
+    (2, 3, 4, (5, 6, 4), (3, 3, 3), (2, 2, 2), (0, 0, 0)),  # reference TestSimple3DConvolution shape
+    (2, 3, 4, (6, 4), (1, 1), (1, 1), (0, 0)),             # reference Test1x1Convolution
+    (1, 8, 128, (4, 7, 7), (3, 3, 3), (1, 1, 1), (1, 1, 1)),  # bm=128 variant, res-block geometry
+    (1, 6, 130, (3, 5, 5), (3, 3, 3), (2, 2, 2), (1, 1, 1)),  # 2 M-blocks, ragged cout, stride 2
+    (3, 5, 96, (9, 9), (3, 3), (1, 1), (1, 1)),            # bm=96
+    (2, 3, 64, (20, 20), (7, 7), (2, 2), (3, 3)),          # conv1 geometry (7x7 s2 p3), K=147 -> padded to 160
+    (2, 16, 32, (7, 7), (1, 1), (1, 1), (0, 0)),           # 1x1, bm=32
+    (1, 8, 160, (5, 5), (3, 3), (2, 2), (1, 1)),           # 2D stride 2 (ECO-Full 3c/4e), bm=96 x2
+    (5, 4, 20, (3, 3), (3, 3), (1, 1), (1, 1)),            # tile spans several images (S_out=9)
+]
+
+
+@pytest.mark.parametrize("cfg", SMALL_CONVS)
+def test_conv_plain(backend, cfg):
+    run_conv(backend, *cfg, mode="plain")
+
+
+@pytest.mark.parametrize("cfg", [SMALL_CONVS[3], SMALL_CONVS[5], SMALL_CONVS[6], SMALL_CONVS[9]])
+def test_conv_fused_epilogue(backend, cfg):
+    run_conv(backend, *cfg, mode="fused", seed=1)
+
+
+def test_conv_concat_slice_store(backend):
+    run_conv(backend, 2, 6, 33, (6, 6), (3, 3), (1, 1), (1, 1), mode="concat", seed=2)
+
+
+def test_conv_permuted_store(backend):
+    run_conv(backend, 4, 6, 12, (5, 5), (3, 3), (1, 1), (1, 1), mode="permute", seed=3)
+
+
+def test_conv_plan_choice(backend):
+    lib = backend.lib
+    for cout, bm in [(32, 32), (64, 64), (96, 96), (128, 128), (160, 96), (192, 96), (224, 128), (256, 128),
+                     (320, 64), (352, 128), (512, 128)]:
+        p = lib.conv_plan(hip.conv_geom(1, 8, cout, (8, 8), (3, 3), (1, 1), (1, 1), (8, 8)))
+        assert p.bm == bm and p.kpad % p.kc == 0 and p.mpad >= cout and p.mpad % 4 == 0
+
+
+def test_conv_rejects_bad_geometry(backend):
+    lib = backend.lib
+    with pytest.raises(hip.EcoError):  # wrong output size
+        lib.conv_plan(hip.conv_geom(1, 3, 4, (6, 4), (3, 3), (2, 2), (0, 0), (3, 2)))
+    with pytest.raises(hip.EcoError):  # 8x8 = 64 taps > 62
+        lib.conv_plan(hip.conv_geom(1, 3, 4, (16, 16), (8, 8), (1, 1), (0, 0), (9, 9)))
+    with pytest.raises(hip.EcoError):  # zero stride
+        lib.conv_plan(hip.conv_geom(1, 3, 4, (6, 4), (3, 3), (0, 1), (0, 0), (2, 1)))
+    assert "conv" in lib.last_error()
+
+
+# ---- the real ECO layer geometries (GPU only: too slow for the emulator) --------------------
+ECO_CONVS = [
+    (8, 3, 64, (224, 224), (7, 7), (2, 2), (3, 3)),           # conv1_7x7_s2
+    (8, 64, 192, (56, 56), (3, 3), (1, 1), (1, 1)),           # conv2_3x3
+    (8, 192, 64, (28, 28), (1, 1), (1, 1), (0, 0)),           # inception_3a_1x1
+    (8, 64, 96, (28, 28), (3, 3), (1, 1), (1, 1)),            # inception_3x_double_3x3_1
+    (8, 192, 32, (28, 28), (1, 1), (1, 1), (0, 0)),           # inception_3a_pool_proj
+    (1, 96, 128, (16, 28, 28), (3, 3, 3), (1, 1, 1), (1, 1, 1)),   # res3a_2n (one clip)
+    (2, 128, 256, (16, 28, 28), (3, 3, 3), (2, 2, 2), (1, 1, 1)),  # res4a_1 / res4a_down
+    (2, 256, 512, (8, 14, 14), (3, 3, 3), (2, 2, 2), (1, 1, 1)),   # res5a_1 / res5a_down
+    (2, 512, 512, (4, 7, 7), (3, 3, 3), (1, 1, 1), (1, 1, 1)),     # res5b_*
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ECO_CONVS)
+def test_conv_eco_geometries(hip_backend, cfg):
+    run_conv(hip_backend, *cfg, mode="fused", seed=4)
+
+
+# ---- pooling ------------------------------------------------------------------------------
+POOLS = [
+    ("MAX", (2, 3), (7, 9), (3, 3), (2, 2), (0, 0)),            # pool1/pool2 style, ceil mode
+    ("MAX", (1, 2), (3, 5), (2, 2), (1, 1), (0, 0)),            # reference TestForwardMax
+    ("MAX", (2, 2), (6, 6), (3, 3), (2, 2), (2, 2)),            # padded max (reference :475-518 geometry)
+    ("MAX", (1, 3), (7, 7), (3, 3), (1, 1), (1, 1)),            # inception_5b_pool (ECO-Full)
+    ("AVE", (2, 3), (6, 6), (3, 3), (1, 1), (1, 1)),            # inception_3a_pool
+    ("AVE", (1, 1), (3, 3, 3), (3, 3, 3), (1, 1, 1), (1, 1, 1)),  # reference 3-D AVE golden geometry
+    ("AVE", (2, 5), (4, 7, 7), (4, 7, 7), (1, 1, 1), (0, 0, 0)),  # global_pool (wave-reduction kernel)
+    ("AVE", (2, 1), (4, 10), (4, 1), (1, 1), (0, 0)),           # segment_consensus_st2 (kernel_h=N, kernel_w=1)
+    ("AVE", (2, 6), (2, 2), (2, 2), (1, 1), (0, 0)),            # tiny global (generic kernel path)
+    ("MAX", (1, 2), (5, 6, 7), (3, 3, 3), (2, 2, 2), (1, 1, 1)),  # 3-D max
+]
+
+
+@pytest.mark.parametrize("method,nc,insp,k,s,p", POOLS)
+def test_pool(backend, method, nc, insp, k, s, p):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(nc + tuple(insp)).astype(np.float32)
+    ref = orc.pooling(x, method, k, s, p)
+    assert np.allclose(ref, orc.pooling_fast(x, method, k, s, p), rtol=1e-6, atol=1e-6)
+    g = hip.pool_geom(nc[0], nc[1], insp, k, s, p, ref.shape[2:], method)
+    y = backend.empty(ref.shape)
+    backend.lib.pool_forward(g, backend.ptr(backend.dev(x)), backend.ptr(y))
+    assert relerr(backend.host(y, ref.shape), ref) < TOL
+
+
+def test_pool_rejects_wrong_output_shape(backend):
+    g = hip.pool_geom(1, 1, (7, 7), (3, 3), (2, 2), (0, 0), (3, 3), "MAX")  # caffe ceil rule gives 4x4
+    with pytest.raises(hip.EcoError):
+        backend.lib.pool_forward(g, 0, 0)
+
+
+# ---- elementwise / glue ----------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 5, 3, 4), (2, 3, 2, 3, 4)])
+def test_bn_relu(backend, shape):
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal(shape).astype(np.float32)
+    C = shape[1]
+    gamma, beta = rng.uniform(0.5, 1.5, C).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+    mean, var = rng.standard_normal(C).astype(np.float32), rng.uniform(0.5, 1.5, C).astype(np.float32)
+    from eco_amd.engine import fold_bn
+    a, b = fold_bn([gamma, beta, mean, var], 1e-5)
+    ref = orc.bn_inference(x, gamma, beta, mean, var, 1e-5)
+    inner = int(np.prod(shape[2:]))
+    for relu in (0, 1):
+        y = backend.empty(shape)
+        backend.lib.bn_forward(backend.ptr(backend.dev(x)), backend.ptr(y), backend.ptr(backend.dev(a)),
+                               backend.ptr(backend.dev(b)), shape[0], C, inner, relu)
+        exp = orc.relu(ref) if relu else ref
+        assert relerr(backend.host(y, shape), exp) < TOL
+
+
+def test_relu_eltwise_concat_permute(backend):
+    rng = np.random.default_rng(7)
+    lib = backend.lib
+    x = rng.standard_normal((3, 4, 5)).astype(np.float32)
+    y = backend.empty(x.shape)
+    lib.relu_forward(backend.ptr(backend.dev(x)), backend.ptr(y), x.size, 0.0)
+    assert np.array_equal(backend.host(y, x.shape), orc.relu(x))
+    lib.relu_forward(backend.ptr(backend.dev(x)), backend.ptr(y), x.size, 0.1)
+    assert relerr(backend.host(y, x.shape), orc.relu(x, 0.1)) < TOL
+    b = rng.standard_normal(x.shape).astype(np.float32)
+    lib.eltwise_sum_forward(backend.ptr(backend.dev(x)), backend.ptr(backend.dev(b)), backend.ptr(y), x.size, 1.0, 1.0)
+    assert np.array_equal(backend.host(y, x.shape), orc.eltwise_sum([x, b]))
+    # concat along channels of two [2, c, 3, 2] tensors
+    a1, a2 = rng.standard_normal((2, 3, 3, 2)).astype(np.float32), rng.standard_normal((2, 5, 3, 2)).astype(np.float32)
+    out = backend.empty((2, 8, 3, 2))
+    lib.concat_copy(backend.ptr(backend.dev(a1)), backend.ptr(out), 2, 3, 8, 0, 6)
+    lib.concat_copy(backend.ptr(backend.dev(a2)), backend.ptr(out), 2, 5, 8, 3, 6)
+    assert np.array_equal(backend.host(out, (2, 8, 3, 2)), orc.concat([a1, a2], 1))
+    with pytest.raises(hip.EcoError):
+        lib.concat_copy(backend.ptr(backend.dev(a2)), backend.ptr(out), 2, 5, 8, 4, 6)
+    # the ECO Transpose1 permutation
+    z = rng.standard_normal((2, 4, 3, 2, 5)).astype(np.float32)
+    zp = backend.empty((2, 3, 4, 2, 5))
+    lib.permute_forward(backend.ptr(backend.dev(z)), backend.ptr(zp), z.shape, [0, 2, 1, 3, 4])
+    assert np.array_equal(backend.host(zp, (2, 3, 4, 2, 5)), orc.permute(z, [0, 2, 1, 3, 4]))
+    with pytest.raises(hip.EcoError):
+        lib.permute_forward(backend.ptr(backend.dev(z)), backend.ptr(zp), z.shape, [0, 2, 2, 3, 4])
+
+
+def test_inner_product_tail_softmax(backend):
+    rng = np.random.default_rng(8)
+    lib = backend.lib
+    M, N, K = 3, 10, 70
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = rng.standard_normal((N, K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    ref = orc.inner_product(x, w, b)
+    y = backend.empty((M, N))
+    lib.inner_product_forward(backend.ptr(backend.dev(x)), backend.ptr(backend.dev(w)), backend.ptr(backend.dev(b)),
+                              backend.ptr(y), M, N, K)
+    assert relerr(backend.host(y, (M, N)), ref) < TOL
+    # fused global_pool + fc, including the column-offset/accumulate form used for concat(a, b) -> fc
+    B, C, S, NO = 2, 12, 2 * 3 * 3, 70
+    f = rng.standard_normal((B, C, 2, 3, 3)).astype(np.float32)
+    w2 = rng.standard_normal((NO, C + 5)).astype(np.float32)
+    b2 = rng.standard_normal(NO).astype(np.float32)
+    pooled = orc.pooling(f, "AVE", (2, 3, 3), (1, 1, 1), (0, 0, 0)).reshape(B, C)
+    ref2 = orc.inner_product(pooled, w2[:, 5:], b2)
+    y2 = backend.empty((B, NO))
+    lib.global_avgpool_fc_forward(backend.ptr(backend.dev(f)), backend.ptr(backend.dev(w2)),
+                                  backend.ptr(backend.dev(b2)), backend.ptr(y2), B, C, S, NO, C + 5, 5, False)
+    assert relerr(backend.host(y2, (B, NO)), ref2) < TOL
+    sm = rng.standard_normal((2, 7, 3)).astype(np.float32)
+    ys = backend.empty(sm.shape)
+    lib.softmax_forward(backend.ptr(backend.dev(sm)), backend.ptr(ys), 2, 7, 3)
+    assert relerr(backend.host(ys, sm.shape), orc.softmax(sm, 1)) < TOL

@@ -1,0 +1,137 @@
+"""Whole-graph parity: geometrically-reduced ECO-Lite / ECO-Full nets (same topology and layer
+names as the reference prototxts, 32x32 frames, channels / 8) run through the pycaffe-style
+``Net`` on both backends and compared blob-by-blob with the CPU oracle; plus the drop-in API
+behaviours of ``Net`` / ``Blob`` (caffe_3d/python/caffe/pycaffe.py, _caffe.cpp)."""
+import numpy as np
+import pytest
+
+import eco_oracle as orc
+from eco_amd import fillers, models
+from eco_amd.net import Net
+from eco_amd.netspec import NetSpec, NetSpecError
+
+TOL = 2e-5
+
+
+def mini(variant, num_segments=4, num_clips=2, **kw):
+    gen = models.eco_lite_deploy if variant == "lite" else models.eco_full_deploy
+    return gen(num_segments=num_segments, num_clips=num_clips, num_classes=10, input_size=32, width_div=8, **kw)
+
+
+def make_net(backend, proto, params, fuse):
+    if backend.kind == "emu":
+        return Net(proto, params=params, fuse=fuse, _backend=(backend.lib, backend.alloc))
+    return Net(proto, params=params, fuse=fuse)
+
+
+def relerr(got, ref):
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
+@pytest.mark.parametrize("variant", ["lite", "full"])
+@pytest.mark.parametrize("fuse", [False, True])
+def test_mini_eco_matches_oracle(backend, variant, fuse):
+    proto = mini(variant)
+    spec = NetSpec.from_prototxt(proto)
+    params = fillers.synthetic_params(spec, seed=7)
+    x = fillers.synthetic_frames(8, 32, 32, seed=3)
+    ref = orc.forward(spec, params, {"data": x}, keep="all", fast_pool=False)
+    net = make_net(backend, proto, params, fuse)
+    net.blobs["data"].data[...] = x
+    out = net.forward()
+    assert list(out) == ["fc8"] and out["fc8"].shape == (2, 10)
+    assert relerr(out["fc8"], ref["fc8"]) < TOL
+    seen = 0
+    for name in net.blobs:
+        if name in net._engine.tensors:
+            got = net.blobs[name].data
+            assert relerr(got, ref[name].reshape(got.shape)) < TOL, name
+            seen += 1
+        else:
+            assert fuse, name
+            with pytest.raises(KeyError, match="fuse=False"):
+                net.blobs[name].data
+    if fuse:
+        assert seen < len(net.blobs)
+        n_conv = sum(L.type == "Convolution" for L in spec.layers)
+        # every BN/ReLU/Eltwise and the Lite Concat/Permute copies are gone
+        assert len(net.op_labels()) < n_conv + 25
+    else:
+        assert seen == len(net.blobs)
+
+
+def test_fused_plan_structure(backend):
+    """The MI355X plan for ECO-Lite: 32 conv launches carry every BN/ReLU/Eltwise/Concat/Permute."""
+    proto = mini("lite")
+    spec = NetSpec.from_prototxt(proto)
+    net = make_net(backend, proto, fillers.synthetic_params(spec), True)
+    labels = net.op_labels()
+    assert len(labels) == 37  # 32 convs + 4 pools + fused tail
+    assert "res3b_2+res3b+res3b_bn+res3b_relu" in labels
+    assert "res4a_down+res4a+res4a_bn+res4a_relu" in labels       # eltwise rides on the later operand
+    assert "inception_3c_double_3x3_1+inception_3c_double_3x3_1_bn+inception_3c_relu_double_3x3_1_inp" in labels
+    assert labels[-1] == "global_pool+fc8"
+    fa = net._engine.fused_away
+    assert "res2b_bn_pre" in fa and "inception_3a_1x1_bn" in fa and "res3b_2" in fa
+    for keep in ("res3a", "res4a", "res5a", "res2b_bn", "inception_3a_output", "fc8"):
+        assert keep in net._engine.tensors, keep  # dual outputs / concat tops / permuted volume exist
+
+
+def test_pycaffe_surface(backend):
+    proto = mini("lite")
+    spec = NetSpec.from_prototxt(proto)
+    params = fillers.synthetic_params(spec, seed=11)
+    net = make_net(backend, proto, params, False)
+    assert net.inputs == ["data"] and net.outputs == ["fc8"]
+    assert list(net.blobs)[0] == "data" and list(net.blobs)[-1] == "fc8"
+    assert net.blobs["data"].shape == (8, 3, 32, 32)
+    assert (net.blobs["data"].num, net.blobs["data"].channels, net.blobs["data"].height) == (8, 3, 32)
+    with pytest.raises(NetSpecError):
+        net.blobs["res3a"].num  # legacy accessors CHECK-fail on 5-D blobs (blob.hpp:140-142)
+    assert list(net.params["conv1_7x7_s2"][0].data.shape) == [8, 3, 7, 7]
+    assert [b.data.shape for b in net.params["conv1_7x7_s2_bn"]] == [(1, 8)] * 4
+    assert net.params["fc8"][0].data.shape == (10, 64)
+    assert net._layer_names[0] == "conv1_7x7_s2" and len(net.layers) == len(spec.layers)
+    x = fillers.synthetic_frames(8, 32, 32, seed=5)
+    out1 = net.forward(data=x)["fc8"].copy()
+    # kwargs form must name exactly the inputs; batch must match (pycaffe.py:83-90)
+    with pytest.raises(Exception):
+        net.forward(wrong=x)
+    with pytest.raises(Exception):
+        net.forward(data=x[:4])
+    # extra blobs on request, and forward(end=...) returns that layer's top
+    o = net.forward(blobs=["res5b_bn"])
+    assert set(o) == {"fc8", "res5b_bn"}
+    o = net.forward(end="pool1_3x3_s2")
+    assert list(o) == ["pool1_3x3_s2"]
+    # editing a parameter through .data is seen by the next forward (mutable_cpu_data semantics)
+    net.params["fc8"][1].data[...] += 1.0
+    out2 = net.forward()["fc8"]
+    assert np.allclose(out2, out1 + 1.0, rtol=1e-5, atol=1e-4 * np.abs(out1).max())
+    # reshape to 1 clip: blob.reshape + net.reshape (_caffe.cpp:193-205,224)
+    net.blobs["data"].reshape(4, 3, 32, 32)
+    net.reshape()
+    assert net.blobs["fc8"].shape == (1, 10) and net.blobs["res2b_bn"].shape == (1, 12, 4, 4, 4)
+    out3 = net.forward(data=x[:4])["fc8"]
+    assert np.allclose(out3, out2[:1], rtol=1e-4, atol=1e-4 * np.abs(out2).max())
+    # B*N not a multiple of N: r2Dto3D CHECK-fails (reshape_layer.cpp:79-81)
+    net.blobs["data"].reshape(6, 3, 32, 32)
+    with pytest.raises(NetSpecError, match="divisible"):
+        net.reshape()
+
+
+def test_filler_init_and_bad_params(backend):
+    proto = mini("lite")
+    spec = NetSpec.from_prototxt(proto)
+    p = fillers.filler_params(spec, seed=0)
+    w = p["conv1_7x7_s2"][0]
+    assert abs(w).max() <= np.sqrt(3.0 / (3 * 49)) + 1e-6 and (p["conv1_7x7_s2"][1] == 0).all()  # xavier / constant 0
+    assert (p["res3a_bn"][0] == 1).all() and (p["res3a_bn"][3] == 0).all()  # bn_layer.cpp:24-41 defaults
+    bad = dict(p)
+    bad["fc8"] = [p["fc8"][0]]
+    with pytest.raises(ValueError, match="Incompatible number of blobs"):
+        make_net(backend, proto, bad, True)
+    bad = dict(p)
+    bad["fc8"] = [p["fc8"][0][:, :5], p["fc8"][1]]
+    with pytest.raises(ValueError, match="does not match"):
+        make_net(backend, proto, bad, True)
