@@ -222,6 +222,10 @@ def load() -> EcoLib:
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"or `make -C {os.path.join(_PKG_DIR, 'csrc')}`. The ECO path has no CPU fallback.")
+        # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1 (same sonames as
+        # /opt/rocm/lib).  Whichever is dlopen'ed first serves the whole process, and torch only
+        # works with its own copy -- so bring torch's runtime in before our library binds to it.
+        import torch  # noqa: F401
         lib = EcoLib(LIB_PATH)
         if not lib.is_device_build:
             raise ImportError(f"{LIB_PATH} is not a gfx950 device build")
