@@ -59,6 +59,75 @@ __device__ __forceinline__ long view_base(const eco_view& v, int img, int sp) {
   return (long)b * v.stride_b + (long)t * v.stride_t + sp;
 }
 
+// Epilogue shared by both kernels: bias, Eltwise-SUM residual, raw store, folded BN, ReLU,
+// activated store.  `acc[i][j]` is the wave's (i,j) 32x32 tile: register r of lane l holds
+// channel mw + i*32 + (r&3) + 8*(r>>2) + 4*(l>>5) at position nw + j*32 + (l&31).
+// Work is ordered tile-row (i) -> 4-channel register group (g) -> tile-column (j) so that only
+// 12 per-channel parameters and 8 values are live at a time (keeps the kernel at the main
+// loop's register budget), and every batch of loads is issued before the stores that follow.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw,
+                                              int half, int l31) {
+  long e_res[TN], e_raw[TN], e_act[TN];
+  bool e_ok[TN];
+  const bool has_bias = a.bias != nullptr, has_bn = a.bn_scale != nullptr, has_res = a.residual.ptr != nullptr;
+  const bool has_raw = a.raw.ptr != nullptr, has_act = a.act.ptr != nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = nw + j * 32 + l31;
+    e_ok[j] = n < a.ntot;
+    const int nn = e_ok[j] ? n : 0;
+    const int img = nn / a.s_out, sp = nn - img * a.s_out;
+    e_res[j] = has_res ? view_base(a.residual, img, sp) : 0;
+    e_raw[j] = has_raw ? view_base(a.raw, img, sp) : 0;
+    e_act[j] = has_act ? view_base(a.act, img, sp) : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int chg = mw + i * 32 + 8 * g + 4 * half;  // first of this group's 4 consecutive channels
+      float pb[4], ps[4], ph[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int chs = (chg + q) < a.cout ? (chg + q) : 0;
+        pb[q] = has_bias ? ld(a.bias + chs) : 0.0f;
+        ps[q] = has_bn ? ld(a.bn_scale + chs) : 1.0f;
+        ph[q] = has_bn ? ld(a.bn_shift + chs) : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!e_ok[j]) continue;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q] + pb[q];
+        if (has_res) {
+          float rv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            rv[q] = ld((const float*)a.residual.ptr + e_res[j] +
+                       (long)((chg + q) < a.cout ? (chg + q) : 0) * a.residual.stride_c);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += rv[q];
+        }
+        if (has_raw) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (chg + q < a.cout) st(a.raw.ptr + e_raw[j] + (long)(chg + q) * a.raw.stride_c, v[q]);
+        }
+        if (has_act) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float y = v[q] * ps[q] + ph[q];
+            if (a.relu) y = fmaxf(y, 0.0f);
+            if (chg + q < a.cout) st(a.act.ptr + e_act[j] + (long)(chg + q) * a.act.stride_c, y);
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int TM, int TN, int WM, int WN, int KC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKernelArgs a) {
   constexpr int BM = 32 * TM * WM;
@@ -110,39 +179,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKernelArgs a)
   }
 
   float4 areg[A_ITERS];
-  float breg[EPT];
+  float breg[EPT];     // raw gathered values; the padding select is deferred to store_stage so
+  unsigned okbits = 0; // that no instruction touches them until the MFMAs of this stage are issued
 
   auto load_stage = [&](int chunk) {
     const int k0 = chunk * KC;
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
       const int idx = tid + i * 256;
-      if (idx < A_F4) {
+      if (A_F4 % 256 == 0 || idx < A_F4) {
         const int row = idx / (BM / 4), c4 = idx % (BM / 4);
         areg[i] = ld((const float4*)(a.wp + (long)(k0 + row) * a.mpad + m0 + c4 * 4));
       }
     }
+    okbits = 0;
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
       const int kt = ld(a.ktab + k0 + kg + j * KG);
       const int off = kt & kKoffMask;
       const unsigned tap = (unsigned)kt >> kKoffBits;
-      const bool ok = (mask >> tap) & 1ull;
-      const float v = ld(a.x + (ok ? in_base + off : 0l));
-      breg[j] = ok ? v : 0.0f;
+      const unsigned ok = (unsigned)(mask >> tap) & 1u;
+      okbits |= ok << j;
+      breg[j] = ld(a.x + (ok ? in_base + off : 0l));
     }
   };
   auto store_stage = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
       const int idx = tid + i * 256;
-      if (idx < A_F4) {
+      if (A_F4 % 256 == 0 || idx < A_F4) {
         const int row = idx / (BM / 4), c4 = idx % (BM / 4);
         *(float4*)&As[buf][row][c4 * 4] = areg[i];
       }
     }
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) Bs[buf][kg + j * KG][pos_l] = breg[j];
+    for (int j = 0; j < EPT; ++j) Bs[buf][kg + j * KG][pos_l] = ((okbits >> j) & 1u) ? breg[j] : 0.0f;
   };
 
   f32x16 acc[TM][TN];
@@ -176,33 +247,168 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKernelArgs a)
     __syncthreads();
   }
 
-  // ---- epilogue: bias, residual, raw store, folded BN, ReLU, activated store ----
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + l31;
-    if (n >= a.ntot) continue;
-    const int img = n / a.s_out, sp = n - img * a.s_out;
-    const long res_base = a.residual.ptr ? view_base(a.residual, img, sp) : 0;
-    const long raw_base = a.raw.ptr ? view_base(a.raw, img, sp) : 0;
-    const long act_base = a.act.ptr ? view_base(a.act, img, sp) : 0;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ch = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (ch >= a.cout) continue;
-        float v = acc[i][j][r];
-        if (a.bias) v += ld(a.bias + ch);
-        if (a.residual.ptr) v += ld((const float*)a.residual.ptr + res_base + (long)ch * a.residual.stride_c);
-        if (a.raw.ptr) st(a.raw.ptr + raw_base + (long)ch * a.raw.stride_c, v);
-        if (a.act.ptr) {
-          float y = a.bn_scale ? v * ld(a.bn_scale + ch) + ld(a.bn_shift + ch) : v;
-          if (a.relu) y = fmaxf(y, 0.0f);
-          st(a.act.ptr + act_base + (long)ch * a.act.stride_c, y);
-        }
-      }
+  conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+}
+
+// ------------------------------------------------------------------------------------------
+// "Channel-tile / constant-tap" variant (cin % KC == 0; every ECO conv except conv1_7x7_s2).
+// Reduction order k' = (cc*taps + tap)*KC + ci with channel c = cc*KC + ci: all KC rows of a
+// stage share one kernel tap, so
+//   * the zero-padding predicate is one bit test per thread per stage (not per element),
+//   * the gather address is  x + [uniform: (cc*KC + ci)*s_in + tap offset] + [per-thread: base(n)]
+//     -> a scalar base + one 32-bit vector offset per load, no per-element VALU and no table,
+//   * consecutive stages walk the 27 (9, 1) taps of the same KC channels, i.e. the same cache
+//     lines shifted by a tap -> the im2col re-reads are L1/L2 hits.
+// The next stage's global loads are issued *between* the MFMAs of the current stage (one or two
+// loads per k-pair step), so a wave goes from the barrier straight into MFMA issue; the only
+// non-overlapped work per stage is the LDS write of the prefetched registers and the barrier.
+template <int TM, int TN, int WM, int WN, int KC>
+__global__ __launch_bounds__(256) void conv_ctap_kernel(const ConvKernelArgs a) {
+  constexpr int BM = 32 * TM * WM;
+  constexpr int BN = 32 * TN * WN;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(BN == 128 || BN == 256, "");
+  constexpr int KG = 256 / BN;         // threads sharing one output position in the gather
+  constexpr int EPT = KC / KG;         // gathered elements per thread per stage
+  constexpr int KSTEPS = KC / 2;       // MFMA k-pair steps per stage
+  constexpr int BPS = EPT / KSTEPS;    // gather loads issued per k-pair step (1 or 2)
+  static_assert(EPT % KSTEPS == 0 && BPS >= 1, "");
+  constexpr int A_F4 = KC * BM / 4;
+  constexpr int A_ITERS = (A_F4 + 255) / 256;
+  static_assert(A_ITERS <= KSTEPS, "");
+
+  __shared__ __attribute__((aligned(16))) float As[2][KC][BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][KC][BN];
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
+  const int m0 = mblk * BM, n0 = nblk * BN;
+
+  const int pos_l = tid % BN;
+  const int kg = uniform(tid / BN);
+  int in_base = 0;
+  unsigned long long mask = 0ull;
+  {
+    const int n = n0 + pos_l;
+    if (n < a.ntot) {
+      const int img = n / a.s_out, sp = n - img * a.s_out;
+      const int ow = sp % a.Wo, t = sp / a.Wo;
+      const int oh = t % a.Ho, od = t / a.Ho;
+      const int id0 = od * a.sd - a.pd, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
+      in_base = (int)((long)img * a.img_stride_in + ((long)id0 * a.Hi + ih0) * a.Wi + iw0);
+      int tap = 0;
+      for (int z = 0; z < a.kd; ++z)
+        for (int y = 0; y < a.kh; ++y)
+          for (int xx = 0; xx < a.kw; ++xx, ++tap) {
+            const bool ok = (unsigned)(id0 + z) < (unsigned)a.Di && (unsigned)(ih0 + y) < (unsigned)a.Hi &&
+                            (unsigned)(iw0 + xx) < (unsigned)a.Wi;
+            mask |= (unsigned long long)ok << tap;
+          }
     }
   }
+
+  // ---- stage being loaded: uniform (cc, tap) walk + this thread's predicate/offset ----
+  int l_cc = 0, l_tap = 0, l_kz = 0, l_ky = 0, l_kx = 0;
+  const float* l_xb = a.x;           // uniform: x + cc*KC*s_in + tap offset
+  const float* l_wp = a.wp + m0;     // uniform: packed-weight rows of the stage
+  int l_voff = 0;                    // per thread: base(n) if the tap is inside the image, else the
+  bool l_ok = false;                 // offset back to the start of the channel plane (always in bounds)
+  auto begin_stage = [&]() {
+    const int toff = (l_kz * a.Hi + l_ky) * a.Wi + l_kx;
+    l_xb = a.x + ((long)l_cc * KC * a.s_in + toff);
+    l_ok = (mask >> l_tap) & 1ull;
+    l_voff = l_ok ? in_base : -toff;
+  };
+  auto next_stage = [&]() {
+    l_wp += (long)KC * a.mpad;
+    ++l_tap;
+    if (++l_kx == a.kw) {
+      l_kx = 0;
+      if (++l_ky == a.kh) {
+        l_ky = 0;
+        if (++l_kz == a.kd) { l_kz = 0; l_tap = 0; ++l_cc; }
+      }
+    }
+    begin_stage();
+  };
+
+  float4 areg[A_ITERS];
+  float breg[EPT];
+  auto load_a = [&](int i) {
+    const int idx = tid + i * 256;
+    if (A_F4 % 256 == 0 || idx < A_F4) {
+      const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+      areg[i] = ld((const float4*)(l_wp + (long)row * a.mpad + c4 * 4));
+    }
+  };
+  auto load_b = [&](int j) { breg[j] = ld(l_xb + (long)(kg + j * KG) * a.s_in + l_voff); };
+  auto store_stage = [&](int buf, bool ok) {
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int idx = tid + i * 256;
+      if (A_F4 % 256 == 0 || idx < A_F4) {
+        const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+        *(float4*)&As[buf][row][c4 * 4] = areg[i];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) Bs[buf][kg + j * KG][pos_l] = ok ? breg[j] : 0.0f;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto mfma_step = [&](int buf, int kk) {
+    float af[TM], bf[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = As[buf][2 * kk + half][(wm * TM + i) * 32 + l31];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][2 * kk + half][(wn * TN + j) * 32 + l31];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(af[i], bf[j], acc[i][j]);
+  };
+
+  const int nchunks = a.kpad / KC;
+  begin_stage();
+#pragma unroll
+  for (int i = 0; i < A_ITERS; ++i) load_a(i);
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) load_b(j);
+  store_stage(0, l_ok);
+  __syncthreads();
+  for (int c = 0; c + 1 < nchunks; ++c) {
+    const int buf = c & 1;
+    next_stage();
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      if (kk < A_ITERS) load_a(kk);
+#pragma unroll
+      for (int q = 0; q < BPS; ++q) load_b(kk * BPS + q);
+      mfma_step(buf, kk);
+      sched_fence();
+    }
+    store_stage(buf ^ 1, l_ok);
+    __syncthreads();
+  }
+  {
+    const int buf = (nchunks - 1) & 1;
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) mfma_step(buf, kk);
+  }
+  conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
 }
 
 static int validate_geom(const eco_conv_geom* g) {
@@ -251,6 +457,7 @@ extern "C" int eco_conv_plan_create(const eco_conv_geom* g, eco_conv_plan* plan)
   plan->bm = bm;
   plan->bn = (bm == 128) ? 128 : 256;
   plan->kc = 16;
+  plan->mode = (g->cin % plan->kc == 0) ? ECO_CONV_MODE_CTAP : ECO_CONV_MODE_TABLE;
   plan->k = g->cin * g->kernel[0] * g->kernel[1] * g->kernel[2];
   plan->kpad = (int)(ceil_div(plan->k, plan->kc) * plan->kc);
   plan->mpad = (int)(ceil_div(g->cout, 128) * 128);
@@ -269,6 +476,8 @@ extern "C" int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan
   const int taps = g->kernel[0] * g->kernel[1] * g->kernel[2];
   const int K = g->cin * taps;
   ECO_REQUIRE(plan->k == K && plan->kpad >= K && plan->mpad >= g->cout, "conv pack: plan does not match geometry");
+  ECO_REQUIRE(plan->mode == ECO_CONV_MODE_TABLE || (plan->mode == ECO_CONV_MODE_CTAP && g->cin % plan->kc == 0),
+              "conv pack: bad plan mode");
   const long s_in = (long)g->in[0] * g->in[1] * g->in[2];
   memset(wp, 0, sizeof(float) * (size_t)plan->wp_elems);
   for (int k = 0; k < plan->kpad; ++k) {
@@ -276,20 +485,32 @@ extern "C" int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan
       ktab[k] = (int32_t)((unsigned)kNeverTap << kKoffBits);
       continue;
     }
-    const int c = k / taps, tap = k % taps;
+    int c, tap;
+    if (plan->mode == ECO_CONV_MODE_CTAP) {  // k' = (cc*taps + tap)*kc + ci, channel c = cc*kc + ci
+      const int ci = k % plan->kc, rest = k / plan->kc;
+      tap = rest % taps;
+      c = (rest / taps) * plan->kc + ci;
+    } else {                                  // k = c*taps + tap (the reference's own weight order)
+      c = k / taps;
+      tap = k % taps;
+    }
     const int kx = tap % g->kernel[2], ky = (tap / g->kernel[2]) % g->kernel[1], kz = tap / (g->kernel[2] * g->kernel[1]);
     const long off = (long)c * s_in + ((long)kz * g->in[1] + ky) * g->in[2] + kx;
     ktab[k] = (int32_t)(((unsigned)tap << kKoffBits) | (unsigned)off);
     float* row = wp + (long)k * plan->mpad;
-    for (int m = 0; m < g->cout; ++m) row[m] = w[(long)m * K + k];
+    const long wk = (long)c * taps + tap;  // column of w[cout][cin*taps]
+    for (int m = 0; m < g->cout; ++m) row[m] = w[(long)m * K + wk];
   }
   return ECO_OK;
 }
 
 template <int TM, int TN, int WM, int WN, int KC>
-static int launch_conv(const ConvKernelArgs& a, hipStream_t stream) {
+static int launch_conv(const ConvKernelArgs& a, int mode, hipStream_t stream) {
   const int grid = a.nblk_m * a.nblk_n;
-  hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WM, WN, KC>), dim3(grid), dim3(256), 0, stream, a);
+  if (mode == ECO_CONV_MODE_CTAP)
+    hipLaunchKernelGGL((conv_ctap_kernel<TM, TN, WM, WN, KC>), dim3(grid), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WM, WN, KC>), dim3(grid), dim3(256), 0, stream, a);
   return check_launch("eco_conv_forward");
 }
 
@@ -328,12 +549,16 @@ extern "C" int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* pla
   a.nblk_m = (int)ceil_div(g->cout, plan->bm);
   a.nblk_n = (int)ceil_div(a.ntot, plan->bn);
   ECO_REQUIRE((long)a.nblk_m * plan->bm <= plan->mpad, "conv: plan mpad too small for bm");
+  ECO_REQUIRE(plan->mode == ECO_CONV_MODE_TABLE || (plan->mode == ECO_CONV_MODE_CTAP && g->cin % plan->kc == 0),
+              "conv: bad plan mode");
+  ECO_REQUIRE((long)g->n * a.img_stride_in < 2147483647l, "conv: input tensor too large for int32 gather offsets");
+  const int mode = plan->mode;
   hipStream_t s = (hipStream_t)stream;
   switch (plan->bm) {
-    case 128: ECO_REQUIRE(plan->bn == 128, "conv: bad plan"); return launch_conv<2, 2, 2, 2, 16>(a, s);
-    case 96: ECO_REQUIRE(plan->bn == 256, "conv: bad plan"); return launch_conv<3, 2, 1, 4, 16>(a, s);
-    case 64: ECO_REQUIRE(plan->bn == 256, "conv: bad plan"); return launch_conv<2, 2, 1, 4, 16>(a, s);
-    case 32: ECO_REQUIRE(plan->bn == 256, "conv: bad plan"); return launch_conv<1, 2, 1, 4, 16>(a, s);
+    case 128: ECO_REQUIRE(plan->bn == 128, "conv: bad plan"); return launch_conv<2, 2, 2, 2, 16>(a, mode, s);
+    case 96: ECO_REQUIRE(plan->bn == 256, "conv: bad plan"); return launch_conv<3, 2, 1, 4, 16>(a, mode, s);
+    case 64: ECO_REQUIRE(plan->bn == 256, "conv: bad plan"); return launch_conv<2, 2, 1, 4, 16>(a, mode, s);
+    case 32: ECO_REQUIRE(plan->bn == 256, "conv: bad plan"); return launch_conv<1, 2, 1, 4, 16>(a, mode, s);
     default: return fail(ECO_ERR_INVALID, "conv: unsupported block tile bm=%d", plan->bm);
   }
 }

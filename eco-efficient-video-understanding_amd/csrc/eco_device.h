@@ -39,6 +39,14 @@ __device__ __forceinline__ int uniform(int v) {
 #endif
 }
 
+// Scheduling fence: keeps the compiler from moving instructions across this point (used to pin
+// the load / MFMA interleave of the conv main loop).  No code is emitted.
+__device__ __forceinline__ void sched_fence() {
+#ifndef ECO_EMU
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 __device__ __forceinline__ int lane_id() {
 #ifdef ECO_EMU
   return emu::tls_cur->lane;

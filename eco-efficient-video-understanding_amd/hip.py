@@ -43,7 +43,8 @@ class ConvGeom(C.Structure):
 class ConvPlan(C.Structure):
     _fields_ = [("bm", C.c_int32), ("bn", C.c_int32), ("kc", C.c_int32), ("k", C.c_int32),
                 ("kpad", C.c_int32), ("mpad", C.c_int32),
-                ("wp_elems", C.c_int64), ("ktab_elems", C.c_int64)]
+                ("wp_elems", C.c_int64), ("ktab_elems", C.c_int64),
+                ("mode", C.c_int32), ("reserved", C.c_int32)]
 
 
 class View(C.Structure):

@@ -40,6 +40,10 @@ extern "C" {
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
 #define ECO_ERR_RUNTIME (-2) /* HIP runtime error (launch failure, bad device)     */
 
+/* reduction (K) order of a packed convolution */
+#define ECO_CONV_MODE_TABLE 0 /* k = c*taps + tap, per-k gather table (any cin)            */
+#define ECO_CONV_MODE_CTAP 1  /* k = (c/kc*taps + tap)*kc + c%kc, one tap per stage (cin%kc==0) */
+
 #define ECO_POOL_MAX 0
 #define ECO_POOL_AVE 1
 
@@ -81,6 +85,8 @@ typedef struct eco_conv_plan {
   int32_t mpad;       /* cout rounded up to a multiple of 128           */
   int64_t wp_elems;   /* floats in the packed weight buffer  (kpad*mpad) */
   int64_t ktab_elems; /* int32 entries in the gather table   (kpad)      */
+  int32_t mode;       /* ECO_CONV_MODE_*: reduction order of the packed weights / kernel family */
+  int32_t reserved;
 } eco_conv_plan;
 
 /* Strided view of an N,C,[D,]H,W output (or residual) tensor.  Element

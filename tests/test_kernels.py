@@ -91,6 +91,13 @@ SMALL_CONVS = [
     (2, 16, 32, (7, 7), (1, 1), (1, 1), (0, 0)),           # 1x1, bm=32
     (1, 8, 160, (5, 5), (3, 3), (2, 2), (1, 1)),           # 2D stride 2 (ECO-Full 3c/4e), bm=96 x2
     (5, 4, 20, (3, 3), (3, 3), (1, 1), (1, 1)),            # tile spans several images (S_out=9)
+    # cin % 16 == 0 -> the constant-tap kernel family (ECO_CONV_MODE_CTAP)
+    (1, 16, 128, (4, 7, 7), (3, 3, 3), (1, 1, 1), (1, 1, 1)),  # res-block geometry, bm=128
+    (1, 32, 130, (3, 5, 5), (3, 3, 3), (2, 2, 2), (1, 1, 1)),  # stride 2, ragged cout, 2 channel tiles
+    (2, 16, 96, (9, 9), (3, 3), (1, 1), (1, 1)),               # bm=96
+    (2, 32, 64, (10, 10), (3, 3), (2, 2), (1, 1)),             # bm=64, 2-D stride 2
+    (3, 16, 20, (3, 3), (3, 3), (1, 1), (1, 1)),               # bm=32, tile spans images
+    (1, 48, 40, (6, 6), (1, 1), (1, 1), (0, 0)),               # 1x1 with 3 channel tiles
 ]
 
 
@@ -99,17 +106,20 @@ def test_conv_plain(backend, cfg):
     run_conv(backend, *cfg, mode="plain")
 
 
-@pytest.mark.parametrize("cfg", [SMALL_CONVS[3], SMALL_CONVS[5], SMALL_CONVS[6], SMALL_CONVS[9]])
+@pytest.mark.parametrize("cfg", [SMALL_CONVS[3], SMALL_CONVS[5], SMALL_CONVS[6], SMALL_CONVS[9], SMALL_CONVS[10],
+                                 SMALL_CONVS[11], SMALL_CONVS[12], SMALL_CONVS[14]])
 def test_conv_fused_epilogue(backend, cfg):
     run_conv(backend, *cfg, mode="fused", seed=1)
 
 
-def test_conv_concat_slice_store(backend):
-    run_conv(backend, 2, 6, 33, (6, 6), (3, 3), (1, 1), (1, 1), mode="concat", seed=2)
+@pytest.mark.parametrize("cin", [6, 16])
+def test_conv_concat_slice_store(backend, cin):
+    run_conv(backend, 2, cin, 33, (6, 6), (3, 3), (1, 1), (1, 1), mode="concat", seed=2)
 
 
-def test_conv_permuted_store(backend):
-    run_conv(backend, 4, 6, 12, (5, 5), (3, 3), (1, 1), (1, 1), mode="permute", seed=3)
+@pytest.mark.parametrize("cin", [6, 16])
+def test_conv_permuted_store(backend, cin):
+    run_conv(backend, 4, cin, 12, (5, 5), (3, 3), (1, 1), (1, 1), mode="permute", seed=3)
 
 
 def test_conv_plan_choice(backend):
@@ -118,6 +128,8 @@ def test_conv_plan_choice(backend):
                      (320, 64), (352, 128), (512, 128)]:
         p = lib.conv_plan(hip.conv_geom(1, 8, cout, (8, 8), (3, 3), (1, 1), (1, 1), (8, 8)))
         assert p.bm == bm and p.kpad % p.kc == 0 and p.mpad >= cout and p.mpad % 4 == 0
+        assert p.mode == 0  # cin=8: table mode
+    assert lib.conv_plan(hip.conv_geom(1, 64, 64, (8, 8), (3, 3), (1, 1), (1, 1), (8, 8))).mode == 1
 
 
 def test_conv_rejects_bad_geometry(backend):
