@@ -54,13 +54,12 @@ def main() -> None:
 
     import eco_amd as caffe
     from eco_amd import models, fillers
+    from eco_amd import dist as eco_dist
     from eco_amd.netspec import NetSpec
 
     caffe.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    eco_dist.init_process_group("nccl", device=dev)  # RCCL over xGMI; no-op at world 1
 
     B, N = args.clips_per_gpu, args.segments
     gen = models.eco_lite_deploy if args.variant == "lite" else models.eco_full_deploy
@@ -78,7 +77,7 @@ def main() -> None:
     def step() -> None:
         net.forward_device()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, logits)
+            eco_dist.all_gather_logits(logits, out=gathered)
 
     def fence() -> None:
         if world > 1:
@@ -101,8 +100,8 @@ def main() -> None:
     clips_per_s = world * B * args.steps / elapsed
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.barrier()  # keep the communicator alive until rank 0 has finished reporting
+        dist.destroy_process_group()
         return
 
     # ---- roofline of the dominant kernel: per-launch HIP-event times on the launch stream ----
@@ -138,7 +137,7 @@ def main() -> None:
     # ---- CPU baseline: the NumPy oracle (caffe cost structure: per-image im2col + SGEMM) ----
     cpu = None
     parity = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import eco_oracle  # checker/baseline only; never on the product path
         try:
@@ -180,6 +179,7 @@ def main() -> None:
     }
     print(json.dumps(line))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

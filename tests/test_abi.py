@@ -1,0 +1,68 @@
+"""The C-ABI libraries load and export every symbol that include/eco_hip.h declares (no compute:
+this runs without a GPU), and the product loader refuses anything but the device build."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from tests.conftest import ROOT
+from eco_amd import hip
+
+HEADER = os.path.join(ROOT, "include", "eco_hip.h")
+
+
+def declared_symbols():
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(eco_[a-z0-9_]+)\s*\(", src)))
+
+
+def exported_symbols(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+
+
+def test_header_matches_binding():
+    assert declared_symbols() == sorted(hip.EXPORTED_SYMBOLS)
+
+
+def test_product_library_exports_every_declared_symbol():
+    if not os.path.exists(hip.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    exp = exported_symbols(hip.LIB_PATH)
+    missing = [s for s in declared_symbols() if s not in exp]
+    assert not missing, missing
+    lib = hip.EcoLib(hip.LIB_PATH)  # dlopen + ctypes resolution of every entry point
+    assert lib.is_device_build and lib._dll.eco_abi_version() == hip.ABI_VERSION
+    assert lib.last_error() == ""
+    # plan / pack are host functions: they work without a device
+    g = hip.conv_geom(1, 16, 128, (4, 7, 7), (3, 3, 3), (1, 1, 1), (1, 1, 1), (4, 7, 7))
+    p = lib.conv_plan(g)
+    assert (p.bm, p.bn, p.kc, p.k, p.mode) == (128, 128, 16, 16 * 27, 1)
+
+
+def test_emulator_build_is_not_accepted_as_product(monkeypatch):
+    from tests.emu.backend import build_emu
+    emu = hip.EcoLib(build_emu())
+    assert not emu.is_device_build
+    assert not [s for s in declared_symbols() if s not in exported_symbols(emu.path)]
+    with pytest.raises(hip.EcoError, match="emulator"):
+        emu.set_device(0)
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "LIB_PATH", emu.path)
+    with pytest.raises(ImportError, match="not a gfx950 device build"):
+        hip.load()
+    monkeypatch.setattr(hip, "LIB_PATH", os.path.join(ROOT, "does_not_exist.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        hip.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "eco-efficient-video-understanding_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "eco_oracle" not in txt and "import oracle" not in txt, f
+                assert "libeco_emu" not in txt or f == "hip.py", f
