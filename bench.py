@@ -123,6 +123,17 @@ def main() -> None:
         ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
+    # HBM traffic of that kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate passes, gfx950 FETCH half-count corrected; tools/summarize_profiles.py) -- bench.py cannot run
+    # the profiler on itself, so this is the figure of the last profiled build, or null.
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")) as f:
+            tr = json.load(f)
+        roofline["traffic"] = round(tr["kernels"][dom_name]["hbm_bytes_per_launch"] / 1e9, 4)
+        roofline["traffic_unit"] = "GB per launch (PMC, " + tr["source"] + ")"
+        roofline["algorithmic_gb_per_launch"] = round(dom["bytes"] / dom["launches"] / 1e9, 4)
+    except Exception:
+        roofline["traffic"] = None
     roofline.update({
         "kernel": dom_name, "launches_per_step": dom["launches"],
         "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
@@ -146,7 +157,7 @@ def main() -> None:
             cores = os.cpu_count()
         spec1 = NetSpec.from_prototxt(gen(num_segments=N, num_clips=1))
         done, t_cpu, refs = 0, 0.0, []
-        max_clips = args.cpu_clips or 4
+        max_clips = args.cpu_clips or 8
         while done < max_clips:
             x1 = frames[done * N:(done + 1) * N]
             t1 = time.perf_counter()

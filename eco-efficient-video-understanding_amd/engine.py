@@ -335,7 +335,7 @@ class Engine:
         # algorithmic bytes (fused model): input + weights + each tensor the epilogue touches, once
         nbytes = 4 * (_prod(L.bottom_shapes[0]) + k * L.geom["cout"]
                       + n_out * (bool(ep.raw.ptr) + bool(ep.act.ptr) + bool(ep.residual.ptr)))
-        meta = {"kernel": f"conv_igemm_bm{plan.bm}_bn{plan.bn}_kc{plan.kc}", "flops": 2 * n_out * k, "bytes": nbytes}
+        meta = {"kernel": hip.conv_kernel_name(plan), "flops": 2 * n_out * k, "bytes": nbytes}
         self._add(i, label, lambda s, g=g, plan=plan, x=x, wp=wp, kt=kt, ep=ep: lib.conv_forward(g, plan, x, wp, kt, ep, s),
                   meta)
 
@@ -346,7 +346,7 @@ class Engine:
         self._keep.append(pg)
         lib = self.lib
         self._add(i, L.name, lambda s, pg=pg, x=x, y=y: lib.pool_forward(pg, x, y, s),
-                  {"kernel": "pool_" + g["method"].lower(), "flops": 0,
+                  {"kernel": "eco::pool_kernel", "flops": 0,
                    "bytes": 4 * (_prod(b) + _prod(L.top_shapes[0]))})
 
     def _emit_concat(self, i: int, L: LayerSpec, skip: Sequence[int]) -> None:
@@ -557,7 +557,9 @@ class Engine:
         B, Cc, S, n_out = b[0], b[1], _prod(b[2:]), Lf.geom["num_output"]
         lib = self.lib
         self._add(i, f"{L.name}+{Lf.name}", lambda s, x=x, w=w, bias=bias, y=y, B=B, Cc=Cc, S=S, n_out=n_out:
-                  lib.global_avgpool_fc_forward(x, w, bias, y, B, Cc, S, n_out, Cc, 0, False, s))
+                  lib.global_avgpool_fc_forward(x, w, bias, y, B, Cc, S, n_out, Cc, 0, False, s),
+                  {"kernel": "eco::global_avgpool_fc_kernel", "flops": 2 * B * n_out * Cc,
+                   "bytes": 4 * (B * Cc * S + n_out * Cc + B * n_out)})
         return True
 
     def _consumers_of(self, blob: str) -> List[int]:

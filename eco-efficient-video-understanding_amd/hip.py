@@ -80,6 +80,16 @@ def pool_geom(n: int, c: int, in_sp, kernel, stride, pad, out_sp, method: str) -
                     _pad3(pad, 0), _pad3(out_sp, 1), {"MAX": POOL_MAX, "AVE": POOL_AVE}[method])
 
 
+_CONV_TILES = {128: (2, 2, 2, 2), 96: (3, 2, 1, 4), 64: (2, 2, 1, 4), 32: (1, 2, 1, 4)}  # bm -> TM,TN,WM,WN
+
+
+def conv_kernel_name(plan: ConvPlan) -> str:
+    """Name of the device kernel eco_conv_forward launches for this plan, as rocprofv3 prints it."""
+    tm, tn, wm, wn = _CONV_TILES[plan.bm]
+    fam = "conv_ctap_kernel" if plan.mode == 1 else "conv_igemm_kernel"
+    return f"eco::{fam}<{tm}, {tn}, {wm}, {wn}, {plan.kc}>"
+
+
 def plain_view(ptr: int, channels: int, spatial: int) -> View:
     """Dense [N, C, S] tensor."""
     return View(ptr, int(channels) * int(spatial), 0, int(spatial), 1)
