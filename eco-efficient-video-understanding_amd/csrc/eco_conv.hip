@@ -48,11 +48,14 @@ struct ConvKernelArgs {
   long img_stride_in;   // cin * s_in
   int ntot;             // n * s_out output positions
   int nblk_m, nblk_n;
+  int ksplit;           // >1: the reduction is cut into ksplit slices, partial sums go to ws[slice][cout][ntot]
+  float* ws;
 };
 
 constexpr int kKoffBits = 26;
 constexpr int kKoffMask = (1 << kKoffBits) - 1;
 constexpr int kNeverTap = 63;  // validity-mask bit that is never set (used by K padding)
+constexpr int kNumCU = 256;    // MI355X
 
 __device__ __forceinline__ long view_base(const eco_view& v, int img, int sp) {
   const int b = img / v.t, t = img - b * v.t;
@@ -250,6 +253,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKernelArgs a)
   conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
 }
 
+// Split-K: a workgroup that only covered a slice of the reduction stores its raw accumulators to
+// ws[slice][channel][position] (positions contiguous: 128 B per half-wave, like the real epilogue).
+template <int TM, int TN>
+__device__ __forceinline__ void conv_store_partial(const ConvKernelArgs& a, f32x16 (&acc)[TM][TN], int slice, int mw,
+                                                   int nw, int half, int l31) {
+  float* base = a.ws + (long)slice * a.cout * a.ntot;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = nw + j * 32 + l31;
+    if (n >= a.ntot) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (ch < a.cout) st(base + (long)ch * a.ntot + n, acc[i][j][r]);
+      }
+  }
+}
+
+// Second pass of split-K: sum the slices in a fixed order (deterministic) and apply the epilogue.
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKernelArgs a) {
+  const long total = (long)a.cout * a.ntot;
+  const long slice_stride = total;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int ch = (int)(idx / a.ntot), n = (int)(idx - (long)ch * a.ntot);
+    float v = 0.0f;
+    for (int sidx = 0; sidx < a.ksplit; ++sidx) v += ld((const float*)a.ws + sidx * slice_stride + idx);
+    const int img = n / a.s_out, sp = n - img * a.s_out;
+    if (a.bias) v += ld(a.bias + ch);
+    if (a.residual.ptr) v += ld((const float*)a.residual.ptr + view_base(a.residual, img, sp) + (long)ch * a.residual.stride_c);
+    if (a.raw.ptr) st(a.raw.ptr + view_base(a.raw, img, sp) + (long)ch * a.raw.stride_c, v);
+    if (a.act.ptr) {
+      float y = a.bn_scale ? v * ld(a.bn_scale + ch) + ld(a.bn_shift + ch) : v;
+      if (a.relu) y = fmaxf(y, 0.0f);
+      st(a.act.ptr + view_base(a.act, img, sp) + (long)ch * a.act.stride_c, y);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // "Channel-tile / constant-tap" variant (cin % KC == 0; every ECO conv except conv1_7x7_s2).
 // Reduction order k' = (cc*taps + tap)*KC + ci with channel c = cc*KC + ci: all KC rows of a
@@ -262,8 +305,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKernelArgs a)
 // The next stage's global loads are issued *between* the MFMAs of the current stage (one or two
 // loads per k-pair step), so a wave goes from the barrier straight into MFMA issue; the only
 // non-overlapped work per stage is the LDS write of the prefetched registers and the barrier.
+// Register budget: 64 accumulators per 2x2 wave tile leave 104 VGPRs for three workgroups per CU
+// (512 / 168); the second launch-bound argument (waves per SIMD) holds the allocator to that.
 template <int TM, int TN, int WM, int WN, int KC>
-__global__ __launch_bounds__(256) void conv_ctap_kernel(const ConvKernelArgs a) {
+__global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_ctap_kernel(const ConvKernelArgs a) {
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
   static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -286,9 +331,14 @@ __global__ __launch_bounds__(256) void conv_ctap_kernel(const ConvKernelArgs a) 
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, l31 = lane & 31;
 
-  const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int ntiles = a.nblk_m * a.nblk_n;
+  const int slice = bid / ntiles, tile = bid - slice * ntiles;  // slice-major: neighbours share the K range
   const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
   const int m0 = mblk * BM, n0 = nblk * BN;
+  const int nstages_all = a.kpad / KC;
+  const int c_begin = (int)((long)slice * nstages_all / a.ksplit);
+  const int c_end = (int)((long)(slice + 1) * nstages_all / a.ksplit);
 
   const int pos_l = tid % BN;
   const int kg = uniform(tid / BN);
@@ -314,9 +364,11 @@ __global__ __launch_bounds__(256) void conv_ctap_kernel(const ConvKernelArgs a) 
   }
 
   // ---- stage being loaded: uniform (cc, tap) walk + this thread's predicate/offset ----
-  int l_cc = 0, l_tap = 0, l_kz = 0, l_ky = 0, l_kx = 0;
+  const int taps = a.kd * a.kh * a.kw;
+  int l_cc = c_begin / taps, l_tap = c_begin % taps;
+  int l_kx = l_tap % a.kw, l_ky = (l_tap / a.kw) % a.kh, l_kz = l_tap / (a.kw * a.kh);
   const float* l_xb = a.x;           // uniform: x + cc*KC*s_in + tap offset
-  const float* l_wp = a.wp + m0;     // uniform: packed-weight rows of the stage
+  const float* l_wp = a.wp + m0 + (long)c_begin * KC * a.mpad;  // uniform: packed-weight rows of the stage
   int l_voff = 0;                    // per thread: base(n) if the tap is inside the image, else the
   bool l_ok = false;                 // offset back to the start of the channel plane (always in bounds)
   auto begin_stage = [&]() {
@@ -369,19 +421,22 @@ __global__ __launch_bounds__(256) void conv_ctap_kernel(const ConvKernelArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  auto mfma_step = [&](int buf, int kk) {
-    float af[TM], bf[TN];
+  // Fragment registers are double-buffered across k-pair steps: the ds_reads of step kk+1 are issued
+  // before the MFMAs of step kk, so a wave does not sit on LDS latency between MFMA groups.
+  float af[2][TM], bf[2][TN];
+  auto read_frags = [&](int buf, int kk, int slot) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = As[buf][2 * kk + half][(wm * TM + i) * 32 + l31];
+    for (int i = 0; i < TM; ++i) af[slot][i] = As[buf][2 * kk + half][(wm * TM + i) * 32 + l31];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][2 * kk + half][(wn * TN + j) * 32 + l31];
+    for (int j = 0; j < TN; ++j) bf[slot][j] = Bs[buf][2 * kk + half][(wn * TN + j) * 32 + l31];
+  };
+  auto mfma_step = [&](int slot) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(af[i], bf[j], acc[i][j]);
+      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(af[slot][i], bf[slot][j], acc[i][j]);
   };
 
-  const int nchunks = a.kpad / KC;
   begin_stage();
 #pragma unroll
   for (int i = 0; i < A_ITERS; ++i) load_a(i);
@@ -389,26 +444,36 @@ __global__ __launch_bounds__(256) void conv_ctap_kernel(const ConvKernelArgs a) 
   for (int j = 0; j < EPT; ++j) load_b(j);
   store_stage(0, l_ok);
   __syncthreads();
-  for (int c = 0; c + 1 < nchunks; ++c) {
-    const int buf = c & 1;
+  for (int c = c_begin; c + 1 < c_end; ++c) {
+    const int buf = (c - c_begin) & 1;
     next_stage();
+    read_frags(buf, 0, 0);
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) {
+      if (kk + 1 < KSTEPS) read_frags(buf, kk + 1, (kk + 1) & 1);
       if (kk < A_ITERS) load_a(kk);
 #pragma unroll
       for (int q = 0; q < BPS; ++q) load_b(kk * BPS + q);
-      mfma_step(buf, kk);
+      mfma_step(kk & 1);
       sched_fence();
     }
     store_stage(buf ^ 1, l_ok);
     __syncthreads();
   }
   {
-    const int buf = (nchunks - 1) & 1;
+    const int buf = (c_end - 1 - c_begin) & 1;
+    read_frags(buf, 0, 0);
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) mfma_step(buf, kk);
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      if (kk + 1 < KSTEPS) read_frags(buf, kk + 1, (kk + 1) & 1);
+      mfma_step(kk & 1);
+      sched_fence();
+    }
   }
-  conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+  if (a.ksplit > 1)
+    conv_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+  else
+    conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
 }
 
 static int validate_geom(const eco_conv_geom* g) {
@@ -465,6 +530,28 @@ extern "C" int eco_conv_plan_create(const eco_conv_geom* g, eco_conv_plan* plan)
   plan->mpad = (int)(ceil_div(plan->mpad, 4) * 4);
   plan->wp_elems = (int64_t)plan->kpad * plan->mpad;
   plan->ktab_elems = plan->kpad;
+  // Split-K: with few output tiles the 256 CUs are unevenly loaded (e.g. 784 tiles = 3.06 per CU ->
+  // the busiest CU does 4) and under-occupied.  Cut the reduction into S slices so that tiles*S
+  // quantises well, as long as every slice keeps >= 8 stages; the partial sums cost S extra
+  // write+read passes over the (small) output, priced at ~4 TB/s against ~100 TFLOP/s of MFMA time.
+  plan->ksplit = 1;
+  plan->ws_bytes = 0;
+  if (plan->mode == ECO_CONV_MODE_CTAP) {
+    const long s_out = (long)g->out[0] * g->out[1] * g->out[2];
+    const long ntot = (long)g->n * s_out;
+    const long tiles = ceil_div(g->cout, bm) * ceil_div(ntot, plan->bn);
+    const int nstages = plan->kpad / plan->kc;
+    const double t_flops = 2.0 * ntot * g->cout * plan->k / 100e12;
+    double best = 1e30;
+    for (int sp = 1; sp <= 16; ++sp) {
+      if (sp > 1 && nstages / sp < 8) break;
+      const double per_cu = (double)tiles * sp / kNumCU;
+      const double eff = per_cu / (double)ceil_div(tiles * sp, kNumCU);
+      const double t = t_flops / eff + (sp > 1 ? 2.0 * sp * ntot * g->cout * 4.0 / 4e12 + 5e-6 : 0.0);
+      if (t < best * 0.97) { best = t; plan->ksplit = sp; }  // prefer fewer slices unless >3 % better
+    }
+    if (plan->ksplit > 1) plan->ws_bytes = (int64_t)plan->ksplit * g->cout * ntot * 4;
+  }
   return ECO_OK;
 }
 
@@ -506,7 +593,7 @@ extern "C" int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan
 
 template <int TM, int TN, int WM, int WN, int KC>
 static int launch_conv(const ConvKernelArgs& a, int mode, hipStream_t stream) {
-  const int grid = a.nblk_m * a.nblk_n;
+  const int grid = a.nblk_m * a.nblk_n * a.ksplit;
   if (mode == ECO_CONV_MODE_CTAP)
     hipLaunchKernelGGL((conv_ctap_kernel<TM, TN, WM, WN, KC>), dim3(grid), dim3(256), 0, stream, a);
   else
@@ -521,7 +608,7 @@ static int check_view(const eco_view& v, const char* what) {
 }
 
 extern "C" int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* plan, const float* x, const float* wp,
-                                const int32_t* ktab, const eco_conv_epilogue* ep, void* stream) {
+                                const int32_t* ktab, const eco_conv_epilogue* ep, void* workspace, void* stream) {
   clear_error();
   if (int rc = validate_geom(g)) return rc;
   ECO_REQUIRE(plan && x && wp && ktab && ep, "conv: null argument");
@@ -553,12 +640,23 @@ extern "C" int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* pla
               "conv: bad plan mode");
   ECO_REQUIRE((long)g->n * a.img_stride_in < 2147483647l, "conv: input tensor too large for int32 gather offsets");
   const int mode = plan->mode;
+  ECO_REQUIRE(plan->ksplit >= 1 && (plan->ksplit == 1 || (mode == ECO_CONV_MODE_CTAP && plan->kpad / plan->kc >= plan->ksplit)),
+              "conv: bad split-K factor %d", plan->ksplit);
+  ECO_REQUIRE(plan->ksplit == 1 || workspace != nullptr, "conv: plan needs a %ld-byte workspace", (long)plan->ws_bytes);
+  a.ksplit = plan->ksplit;
+  a.ws = (float*)workspace;
+  int rc = ECO_OK;
   hipStream_t s = (hipStream_t)stream;
   switch (plan->bm) {
-    case 128: ECO_REQUIRE(plan->bn == 128, "conv: bad plan"); return launch_conv<2, 2, 2, 2, 16>(a, mode, s);
-    case 96: ECO_REQUIRE(plan->bn == 256, "conv: bad plan"); return launch_conv<3, 2, 1, 4, 16>(a, mode, s);
-    case 64: ECO_REQUIRE(plan->bn == 256, "conv: bad plan"); return launch_conv<2, 2, 1, 4, 16>(a, mode, s);
-    case 32: ECO_REQUIRE(plan->bn == 256, "conv: bad plan"); return launch_conv<1, 2, 1, 4, 16>(a, mode, s);
+    case 128: ECO_REQUIRE(plan->bn == 128, "conv: bad plan"); rc = launch_conv<2, 2, 2, 2, 16>(a, mode, s); break;
+    case 96: ECO_REQUIRE(plan->bn == 256, "conv: bad plan"); rc = launch_conv<3, 2, 1, 4, 16>(a, mode, s); break;
+    case 64: ECO_REQUIRE(plan->bn == 256, "conv: bad plan"); rc = launch_conv<2, 2, 1, 4, 16>(a, mode, s); break;
+    case 32: ECO_REQUIRE(plan->bn == 256, "conv: bad plan"); rc = launch_conv<1, 2, 1, 4, 16>(a, mode, s); break;
     default: return fail(ECO_ERR_INVALID, "conv: unsupported block tile bm=%d", plan->bm);
   }
+  if (rc != ECO_OK || a.ksplit == 1) return rc;
+  long rblocks = ceil_div((long)a.cout * a.ntot, 256);
+  if (rblocks > 262144) rblocks = 262144;
+  hipLaunchKernelGGL((conv_splitk_reduce_kernel), dim3((unsigned)rblocks), dim3(256), 0, s, a);
+  return check_launch("eco_conv_forward(split-K reduce)");
 }

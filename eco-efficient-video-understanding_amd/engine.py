@@ -211,6 +211,11 @@ class Engine:
                 if L.geom["bias_term"]:
                     st["bias"] = self.alloc.empty(L.geom["num_output"], np.float32)
                 self._dirty_params.add(L.name)
+        # one scratch buffer serves every split-K convolution (launches are serial on one stream)
+        ws_bytes = max([st["plan"].ws_bytes for st in self._param_dev.values() if "plan" in st] + [0])
+        if ws_bytes > getattr(self, "_ws_bytes", 0):
+            self._ws = self.alloc.empty((ws_bytes + 3) // 4, np.float32)
+            self._ws_bytes = ws_bytes
         for n in spec.inputs:
             self._materialize(n, spec.blob_shapes[n])
         if self.fuse:
@@ -330,14 +335,15 @@ class Engine:
         wp, kt = self.alloc.ptr(st["wp"]), self.alloc.ptr(st["ktab"])
         self._keep.append((g, plan, ep))
         lib = self.lib
+        ws = self.alloc.ptr(self._ws) if plan.ws_bytes else None
         n_out = _prod(L.top_shapes[0])
         k = L.geom["cin"] * _prod(L.geom["kernel"])
         # algorithmic bytes (fused model): input + weights + each tensor the epilogue touches, once
         nbytes = 4 * (_prod(L.bottom_shapes[0]) + k * L.geom["cout"]
                       + n_out * (bool(ep.raw.ptr) + bool(ep.act.ptr) + bool(ep.residual.ptr)))
         meta = {"kernel": hip.conv_kernel_name(plan), "flops": 2 * n_out * k, "bytes": nbytes}
-        self._add(i, label, lambda s, g=g, plan=plan, x=x, wp=wp, kt=kt, ep=ep: lib.conv_forward(g, plan, x, wp, kt, ep, s),
-                  meta)
+        self._add(i, label, lambda s, g=g, plan=plan, x=x, wp=wp, kt=kt, ep=ep, ws=ws:
+                  lib.conv_forward(g, plan, x, wp, kt, ep, ws, s), meta)
 
     def _emit_pool(self, i: int, L: LayerSpec, x: int, y: int) -> None:
         g = L.geom

@@ -21,7 +21,7 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _i32x3 = C.c_int32 * 3
 
@@ -44,7 +44,7 @@ class ConvPlan(C.Structure):
     _fields_ = [("bm", C.c_int32), ("bn", C.c_int32), ("kc", C.c_int32), ("k", C.c_int32),
                 ("kpad", C.c_int32), ("mpad", C.c_int32),
                 ("wp_elems", C.c_int64), ("ktab_elems", C.c_int64),
-                ("mode", C.c_int32), ("reserved", C.c_int32)]
+                ("mode", C.c_int32), ("ksplit", C.c_int32), ("ws_bytes", C.c_int64)]
 
 
 class View(C.Structure):
@@ -109,7 +109,7 @@ _SIGNATURES = {
     "eco_conv_plan_create": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvPlan)]),
     "eco_conv_pack_weights": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvPlan), C.c_void_p, C.c_void_p, C.c_void_p]),
     "eco_conv_forward": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvPlan), C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.POINTER(ConvEpilogue), C.c_void_p]),
+                                   C.POINTER(ConvEpilogue), C.c_void_p, C.c_void_p]),
     "eco_pool_forward": (C.c_int, [C.POINTER(PoolGeom), C.c_void_p, C.c_void_p, C.c_void_p]),
     "eco_bn_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                  C.c_int, C.c_void_p]),
@@ -184,8 +184,8 @@ class EcoLib:
         self._check(self._dll.eco_conv_pack_weights(C.byref(g), C.byref(p), w_ptr, wp_ptr, ktab_ptr))
 
     def conv_forward(self, g: ConvGeom, p: ConvPlan, x: int, wp: int, ktab: int, ep: ConvEpilogue,
-                     stream: Optional[int] = None) -> None:
-        self._check(self._dll.eco_conv_forward(C.byref(g), C.byref(p), x, wp, ktab, C.byref(ep), stream))
+                     workspace: Optional[int] = None, stream: Optional[int] = None) -> None:
+        self._check(self._dll.eco_conv_forward(C.byref(g), C.byref(p), x, wp, ktab, C.byref(ep), workspace, stream))
 
     # -- stand-alone operators -----------------------------------------------
     def pool_forward(self, g: PoolGeom, x: int, y: int, stream=None) -> None:

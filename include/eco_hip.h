@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 1
+#define ECO_ABI_VERSION 2
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -86,7 +86,8 @@ typedef struct eco_conv_plan {
   int64_t wp_elems;   /* floats in the packed weight buffer  (kpad*mpad) */
   int64_t ktab_elems; /* int32 entries in the gather table   (kpad)      */
   int32_t mode;       /* ECO_CONV_MODE_*: reduction order of the packed weights / kernel family */
-  int32_t reserved;
+  int32_t ksplit;     /* >1: split-K, the launch needs a workspace of ws_bytes                   */
+  int64_t ws_bytes;   /* bytes of device scratch eco_conv_forward needs for this plan (0 if none) */
 } eco_conv_plan;
 
 /* Strided view of an N,C,[D,]H,W output (or residual) tensor.  Element
@@ -132,10 +133,13 @@ int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan* plan,
                           const float* w, float* wp, int32_t* ktab);
 /* ConvolutionLayer::Forward_gpu (layers/conv_layer.cu, cudnn_conv_layer.cu:15-65) as one
  * implicit-GEMM MFMA kernel, optionally fused with the BN / ReLU / Eltwise / Concat /
- * Permute layers that follow it.  x, wp, ktab and all epilogue pointers are DEVICE pointers. */
+ * Permute layers that follow it.  x, wp, ktab and all epilogue pointers are DEVICE pointers.
+ * `workspace` is caller-owned device scratch of at least plan->ws_bytes (may be NULL when that is 0;
+ * one buffer can serve every layer launched on the same stream).  When plan->ksplit > 1 a second,
+ * deterministic reduce launch follows on the same stream. */
 int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* plan, const float* x,
                      const float* wp, const int32_t* ktab, const eco_conv_epilogue* ep,
-                     void* stream);
+                     void* workspace, void* stream);
 
 /* ---- stand-alone operators (one per reference layer type) -------------------------- */
 

@@ -33,6 +33,7 @@ def run_conv(be, n, cin, cout, insp, k, s, p, mode="plain", seed=0):
     kt = np.zeros(plan.ktab_elems, np.int32)
     lib.conv_pack_weights(g, plan, w.ctypes.data, wp.ctypes.data, kt.ctypes.data)
     dx, dwp, dkt, db = be.dev(x), be.dev(wp), be.dev(kt), be.dev(b)
+    ws = be.ptr(be.empty((plan.ws_bytes // 4,))) if plan.ws_bytes else None
     ep = hip.ConvEpilogue()
     ep.bias = be.ptr(db)
     ep.residual, ep.raw, ep.act = hip.null_view(), hip.null_view(), hip.null_view()
@@ -42,7 +43,7 @@ def run_conv(be, n, cin, cout, insp, k, s, p, mode="plain", seed=0):
     if mode == "plain":
         raw = be.empty(ref.shape)
         ep.raw = hip.plain_view(be.ptr(raw), cout, S)
-        lib.conv_forward(g, plan, be.ptr(dx), be.ptr(dwp), be.ptr(dkt), ep)
+        lib.conv_forward(g, plan, be.ptr(dx), be.ptr(dwp), be.ptr(dkt), ep, ws)
         assert relerr(be.host(raw, ref.shape), ref) < TOL
     elif mode == "fused":  # bias + residual + raw + BN + ReLU -> act
         res = rng.standard_normal(ref.shape).astype(np.float32)
@@ -54,7 +55,7 @@ def run_conv(be, n, cin, cout, insp, k, s, p, mode="plain", seed=0):
         ep.raw = hip.plain_view(be.ptr(raw), cout, S)
         ep.act = hip.plain_view(be.ptr(act), cout, S)
         ep.bn_scale, ep.bn_shift, ep.relu = be.ptr(dsc), be.ptr(dsh), 1
-        lib.conv_forward(g, plan, be.ptr(dx), be.ptr(dwp), be.ptr(dkt), ep)
+        lib.conv_forward(g, plan, be.ptr(dx), be.ptr(dwp), be.ptr(dkt), ep, ws)
         exp_raw = ref + res
         exp_act = np.maximum(exp_raw * sc.reshape(bshape) + sh.reshape(bshape), 0)
         assert relerr(be.host(raw, ref.shape), exp_raw) < TOL
@@ -64,7 +65,7 @@ def run_conv(be, n, cin, cout, insp, k, s, p, mode="plain", seed=0):
         big = be.dev(np.full((n, ctot) + tuple(outsp), 7.0, np.float32))
         ep.act = hip.View(be.ptr(big, c0 * S), ctot * S, 0, S, 1)
         ep.relu = 1
-        lib.conv_forward(g, plan, be.ptr(dx), be.ptr(dwp), be.ptr(dkt), ep)
+        lib.conv_forward(g, plan, be.ptr(dx), be.ptr(dwp), be.ptr(dkt), ep, ws)
         got = be.host(big, (n, ctot) + tuple(outsp))
         assert relerr(got[:, c0:c0 + cout], np.maximum(ref, 0)) < TOL
         assert (got[:, :c0] == 7.0).all() and (got[:, c0 + cout:] == 7.0).all()
@@ -73,7 +74,7 @@ def run_conv(be, n, cin, cout, insp, k, s, p, mode="plain", seed=0):
         assert n % T == 0 and nd == 2
         out = be.empty(ref.shape)
         ep.act = hip.View(be.ptr(out), cout * T * S, S, T * S, T)
-        lib.conv_forward(g, plan, be.ptr(dx), be.ptr(dwp), be.ptr(dkt), ep)
+        lib.conv_forward(g, plan, be.ptr(dx), be.ptr(dwp), be.ptr(dkt), ep, ws)
         exp = ref.reshape((n // T, T, cout) + tuple(outsp)).transpose(0, 2, 1, 3, 4)
         assert relerr(be.host(out, exp.shape), exp) < TOL
     return plan
@@ -98,6 +99,7 @@ SMALL_CONVS = [
     (2, 32, 64, (10, 10), (3, 3), (2, 2), (1, 1)),             # bm=64, 2-D stride 2
     (3, 16, 20, (3, 3), (3, 3), (1, 1), (1, 1)),               # bm=32, tile spans images
     (1, 48, 40, (6, 6), (1, 1), (1, 1), (0, 0)),               # 1x1 with 3 channel tiles
+    (1, 64, 128, (2, 6, 6), (3, 3, 3), (1, 1, 1), (1, 1, 1)),  # 1 tile, 108 stages -> split-K (plan.ksplit > 1)
 ]
 
 
@@ -107,7 +109,7 @@ def test_conv_plain(backend, cfg):
 
 
 @pytest.mark.parametrize("cfg", [SMALL_CONVS[3], SMALL_CONVS[5], SMALL_CONVS[6], SMALL_CONVS[9], SMALL_CONVS[10],
-                                 SMALL_CONVS[11], SMALL_CONVS[12], SMALL_CONVS[14]])
+                                 SMALL_CONVS[11], SMALL_CONVS[12], SMALL_CONVS[14], SMALL_CONVS[16]])
 def test_conv_fused_epilogue(backend, cfg):
     run_conv(backend, *cfg, mode="fused", seed=1)
 
@@ -130,6 +132,22 @@ def test_conv_plan_choice(backend):
         assert p.bm == bm and p.kpad % p.kc == 0 and p.mpad >= cout and p.mpad % 4 == 0
         assert p.mode == 0  # cin=8: table mode
     assert lib.conv_plan(hip.conv_geom(1, 64, 64, (8, 8), (3, 3), (1, 1), (1, 1), (8, 8))).mode == 1
+    # split-K: chosen when the tile count quantises badly over 256 CUs and the reduction is long
+    p5 = lib.conv_plan(hip.conv_geom(32, 512, 512, (4, 7, 7), (3, 3, 3), (1, 1, 1), (1, 1, 1), (4, 7, 7)))   # res5b: 196 tiles
+    p4 = lib.conv_plan(hip.conv_geom(32, 256, 256, (8, 14, 14), (3, 3, 3), (1, 1, 1), (1, 1, 1), (8, 14, 14)))  # res4b: 784 tiles
+    p3 = lib.conv_plan(hip.conv_geom(32, 128, 128, (16, 28, 28), (3, 3, 3), (1, 1, 1), (1, 1, 1), (16, 28, 28)))  # res3b: 3136 tiles
+    assert p5.ksplit > 1 and p5.ws_bytes == p5.ksplit * 512 * 32 * 196 * 4
+    assert p4.ksplit > 1 and p3.ksplit == 1 and p3.ws_bytes == 0
+    with pytest.raises(hip.EcoError, match="workspace"):
+        lib.conv_forward(hip.conv_geom(32, 512, 512, (4, 7, 7), (3, 3, 3), (1, 1, 1), (1, 1, 1), (4, 7, 7)), p5, 8, 8, 8,
+                         _dummy_epilogue(), None)
+
+
+def _dummy_epilogue():
+    ep = hip.ConvEpilogue()
+    ep.residual, ep.act = hip.null_view(), hip.null_view()
+    ep.raw = hip.plain_view(8, 512, 196)
+    return ep
 
 
 def test_conv_rejects_bad_geometry(backend):

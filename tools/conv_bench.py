@@ -56,7 +56,9 @@ def main():
         ep.bn_scale, ep.bn_shift, ep.relu = sc.data_ptr(), sh.data_ptr(), 1
         ep.act = hip.plain_view(y.data_ptr(), g["cout"], S)
         stream = torch.cuda.current_stream().cuda_stream
-        run = lambda: lib.conv_forward(geom, plan, x.data_ptr(), dwp.data_ptr(), dkt.data_ptr(), ep, stream)
+        wsb = torch.empty(max(plan.ws_bytes // 4, 1), device=dev)
+        run = lambda: lib.conv_forward(geom, plan, x.data_ptr(), dwp.data_ptr(), dkt.data_ptr(), ep,
+                                       wsb.data_ptr() if plan.ws_bytes else None, stream)
         run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -67,15 +69,15 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.iters
         flops = 2.0 * np.prod(ts) * g["cin"] * np.prod(g["kernel"])
-        rows.append((L.name, plan.bm, plan.bn, flops / 1e9, ms, flops / ms / 1e9, key))
+        rows.append((L.name, plan.bm, plan.bn, flops / 1e9, ms, flops / ms / 1e9, key, plan.ksplit))
         del x, y
     tot_f = tot_t = 0.0
     print(f"{'layer':34s} bm  bn   GFLOP     ms    TFLOP/s  x  (frac of 157.3)")
-    for name, bm, bn, gf, ms, tf, key in rows:
+    for name, bm, bn, gf, ms, tf, key, ks in rows:
         mult = len(seen[key])
         tot_f += gf * mult
         tot_t += ms * mult
-        print(f"{name:34s} {bm:3d} {bn:3d} {gf:8.1f} {ms:7.3f} {tf:8.1f}  x{mult}  {tf / 157.3:.3f}")
+        print(f"{name:34s} {bm:3d} {bn:3d} {gf:8.1f} {ms:7.3f} {tf:8.1f}  x{mult}  {tf / 157.3:.3f}  ksplit={ks}")
     print(f"TOTAL conv: {tot_f:.1f} GFLOP in {tot_t:.2f} ms = {tot_f / tot_t:.1f} TFLOP/s ({tot_f / tot_t / 157.3:.3f} of peak)")
 
 
