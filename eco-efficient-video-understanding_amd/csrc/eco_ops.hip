@@ -64,6 +64,69 @@ __global__ __launch_bounds__(256) void pool_kernel(const PoolArgs a) {
   }
 }
 
+// 2-D MAX 3x3 stride 2, no padding (pool1 / pool2 / the ECO-Full stride-2 pools): one thread per four
+// consecutive outputs of a row.  It reads 8 (+1) consecutive input floats of each of the three rows as
+// two float4 (+1 scalar) and writes one float4 -> every global access is 16 B per lane and contiguous
+// across lanes.  Ceil-mode clipping (pooling_layer.cpp:131-147,199-225): the 9th column and the 3rd
+// row simply do not exist at the right / bottom edge.
+__global__ __launch_bounds__(256) void maxpool2d_k3s2_kernel(const float* x, float* y, long planes, int Hi, int Wi,
+                                                             int Ho, int Wo) {
+  const int wq = Wo / 4;
+  const long total = planes * Ho * wq;
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+    const int q = (int)(i % wq);
+    const long t = i / wq;
+    const int oh = (int)(t % Ho);
+    const long pl = t / Ho;
+    const float* xp = x + pl * Hi * Wi + (long)(2 * oh) * Wi + 8 * q;
+    const bool has9 = 8 * q + 8 < Wi;
+    float m[4] = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      if (2 * oh + r >= Hi) break;
+      const float4 a = ld((const float4*)(xp + (long)r * Wi));
+      const float4 b = ld((const float4*)(xp + (long)r * Wi + 4));
+      const float c = has9 ? ld(xp + (long)r * Wi + 8) : -FLT_MAX;
+      m[0] = fmaxf(m[0], fmaxf(fmaxf(a.x, a.y), a.z));
+      m[1] = fmaxf(m[1], fmaxf(fmaxf(a.z, a.w), b.x));
+      m[2] = fmaxf(m[2], fmaxf(fmaxf(b.x, b.y), b.z));
+      m[3] = fmaxf(m[3], fmaxf(fmaxf(b.z, b.w), c));
+    }
+    st((float4*)(y + (pl * Ho + oh) * Wo + 4 * q), make_float4(m[0], m[1], m[2], m[3]));
+  }
+}
+
+// 2-D AVE 3x3 stride 1 pad 1 (inception *_pool): four consecutive outputs per thread; per row one
+// float4 plus the two neighbours.  Zero padding, divisor 9 everywhere (the reference's window size
+// including padding, pooling_layer.cpp:247-262, equals 9 for every position of this geometry).
+__global__ __launch_bounds__(256) void avgpool2d_k3s1p1_kernel(const float* x, float* y, long planes, int H, int W) {
+  const int wq = W / 4;
+  const long total = planes * H * wq;
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+    const int q = (int)(i % wq);
+    const long t = i / wq;
+    const int oh = (int)(t % H);
+    const long pl = t / H;
+    const float* xp = x + pl * H * W + 4 * q;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int r = -1; r <= 1; ++r) {
+      const int h = oh + r;
+      if (h < 0 || h >= H) continue;
+      const float* row = xp + (long)h * W;
+      const float4 a = ld((const float4*)row);
+      const float l = (q > 0) ? ld(row - 1) : 0.0f;
+      const float rr = (4 * q + 4 < W) ? ld(row + 4) : 0.0f;
+      s0 += l + a.x + a.y;
+      s1 += a.x + a.y + a.z;
+      s2 += a.y + a.z + a.w;
+      s3 += a.z + a.w + rr;
+    }
+    const float inv = 1.0f / 9.0f;
+    st((float4*)(y + (pl * H + oh) * W + 4 * q), make_float4(s0 * inv, s1 * inv, s2 * inv, s3 * inv));
+  }
+}
+
 // Whole-volume average (global_pool): one wave per (n,c) row, butterfly reduction.
 __global__ __launch_bounds__(256) void global_avg_kernel(const float* x, float* y, long rows, int s) {
   const int lane = lane_id();
@@ -228,6 +291,23 @@ extern "C" int eco_pool_forward(const eco_pool_geom* g, const float* x, float* y
   if (global && g->method == ECO_POOL_AVE && s_in >= 32 && s_in < 2147483647l) {
     hipLaunchKernelGGL((global_avg_kernel), dim3(grid_for(rows, 4)), dim3(kThreads), 0, s, x, y, rows, (int)s_in);
     return check_launch("eco_pool_forward(global)");
+  }
+  const bool two_d = g->in[0] == 1 && g->kernel[0] == 1 && g->stride[0] == 1 && g->pad[0] == 0;
+  const bool aligned = (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+  if (two_d && aligned && g->method == ECO_POOL_MAX && g->kernel[1] == 3 && g->kernel[2] == 3 && g->stride[1] == 2 &&
+      g->stride[2] == 2 && g->pad[1] == 0 && g->pad[2] == 0 && g->in[2] % 4 == 0 && g->out[2] % 4 == 0 &&
+      2 * (g->out[2] - 1) + 2 <= g->in[2]) {
+    const long total = rows * g->out[1] * (g->out[2] / 4);
+    hipLaunchKernelGGL((maxpool2d_k3s2_kernel), dim3(grid_for(total)), dim3(kThreads), 0, s, x, y, rows, g->in[1],
+                       g->in[2], g->out[1], g->out[2]);
+    return check_launch("eco_pool_forward(max 3x3 s2)");
+  }
+  if (two_d && aligned && g->method == ECO_POOL_AVE && g->kernel[1] == 3 && g->kernel[2] == 3 && g->stride[1] == 1 &&
+      g->stride[2] == 1 && g->pad[1] == 1 && g->pad[2] == 1 && g->in[2] % 4 == 0 && g->in[1] >= 2 && g->in[2] >= 4) {
+    const long total = rows * g->in[1] * (g->in[2] / 4);
+    hipLaunchKernelGGL((avgpool2d_k3s1p1_kernel), dim3(grid_for(total)), dim3(kThreads), 0, s, x, y, rows, g->in[1],
+                       g->in[2]);
+    return check_launch("eco_pool_forward(ave 3x3 s1 p1)");
   }
   PoolArgs a;
   a.x = x; a.y = y;

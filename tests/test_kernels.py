@@ -193,6 +193,14 @@ POOLS = [
     ("AVE", (2, 1), (4, 10), (4, 1), (1, 1), (0, 0)),           # segment_consensus_st2 (kernel_h=N, kernel_w=1)
     ("AVE", (2, 6), (2, 2), (2, 2), (1, 1), (0, 0)),            # tiny global (generic kernel path)
     ("MAX", (1, 2), (5, 6, 7), (3, 3, 3), (2, 2, 2), (1, 1, 1)),  # 3-D max
+    # shapes that take the float4 fast paths (W % 4 == 0)
+    ("MAX", (2, 3), (10, 16), (3, 3), (2, 2), (0, 0)),          # even H: last window has only 2 rows
+    ("MAX", (1, 2), (9, 8), (3, 3), (2, 2), (0, 0)),            # odd H: full last window; 1 quad per row
+    ("MAX", (2, 2), (28, 28), (3, 3), (2, 2), (0, 0)),          # pool2-like 28 -> 14 (Wo=14: generic path)
+    ("MAX", (1, 3), (56, 56), (3, 3), (2, 2), (0, 0)),          # pool2: 56 -> 28
+    ("AVE", (2, 3), (6, 8), (3, 3), (1, 1), (1, 1)),
+    ("AVE", (1, 2), (28, 28), (3, 3), (1, 1), (1, 1)),          # inception_3a_pool geometry
+    ("AVE", (1, 2), (5, 12), (3, 3), (1, 1), (1, 1)),
 ]
 
 
