@@ -131,128 +131,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&
   }
 }
 
-template <int TM, int TN, int WM, int WN, int KC>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKernelArgs a) {
-  constexpr int BM = 32 * TM * WM;
-  constexpr int BN = 32 * TN * WN;
-  static_assert(WM * WN == 4, "4 waves per workgroup");
-  static_assert(BN == 64 || BN == 128 || BN == 256, "BN must divide 256 and be a multiple of the wave");
-  static_assert(KC % 2 == 0, "MFMA 32x32x2 consumes k in pairs");
-  constexpr int KG = 256 / BN;  // threads sharing one output position in the gather
-  constexpr int EPT = KC / KG;  // gathered elements per thread per stage
-  static_assert(KC % KG == 0, "");
-  constexpr int A_F4 = KC * BM / 4;
-  constexpr int A_ITERS = (A_F4 + 255) / 256;
-
-  __shared__ __attribute__((aligned(16))) float As[2][KC][BM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][KC][BN];
-
-  const int tid = (int)threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = uniform(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int half = lane >> 5, l31 = lane & 31;
-
-  const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
-  const int m0 = mblk * BM, n0 = nblk * BN;
-
-  // ---- gather role of this thread: one output position, EPT of the stage's KC rows ----
-  const int pos_l = tid % BN;
-  const int kg = uniform(tid / BN);
-  long in_base = 0;
-  unsigned long long mask = 0ull;
-  {
-    const int n = n0 + pos_l;
-    if (n < a.ntot) {
-      const int img = n / a.s_out, sp = n - img * a.s_out;
-      const int ow = sp % a.Wo, t = sp / a.Wo;
-      const int oh = t % a.Ho, od = t / a.Ho;
-      const int id0 = od * a.sd - a.pd, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
-      in_base = (long)img * a.img_stride_in + ((long)id0 * a.Hi + ih0) * a.Wi + iw0;
-      int tap = 0;
-      for (int z = 0; z < a.kd; ++z)
-        for (int y = 0; y < a.kh; ++y)
-          for (int xx = 0; xx < a.kw; ++xx, ++tap) {
-            const bool ok = (unsigned)(id0 + z) < (unsigned)a.Di && (unsigned)(ih0 + y) < (unsigned)a.Hi &&
-                            (unsigned)(iw0 + xx) < (unsigned)a.Wi;
-            mask |= (unsigned long long)ok << tap;
-          }
-    }
-  }
-
-  float4 areg[A_ITERS];
-  float breg[EPT];     // raw gathered values; the padding select is deferred to store_stage so
-  unsigned okbits = 0; // that no instruction touches them until the MFMAs of this stage are issued
-
-  auto load_stage = [&](int chunk) {
-    const int k0 = chunk * KC;
-#pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-      const int idx = tid + i * 256;
-      if (A_F4 % 256 == 0 || idx < A_F4) {
-        const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-        areg[i] = ld((const float4*)(a.wp + (long)(k0 + row) * a.mpad + m0 + c4 * 4));
-      }
-    }
-    okbits = 0;
-#pragma unroll
-    for (int j = 0; j < EPT; ++j) {
-      const int kt = ld(a.ktab + k0 + kg + j * KG);
-      const int off = kt & kKoffMask;
-      const unsigned tap = (unsigned)kt >> kKoffBits;
-      const unsigned ok = (unsigned)(mask >> tap) & 1u;
-      okbits |= ok << j;
-      breg[j] = ld(a.x + (ok ? in_base + off : 0l));
-    }
-  };
-  auto store_stage = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-      const int idx = tid + i * 256;
-      if (A_F4 % 256 == 0 || idx < A_F4) {
-        const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-        *(float4*)&As[buf][row][c4 * 4] = areg[i];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < EPT; ++j) Bs[buf][kg + j * KG][pos_l] = ((okbits >> j) & 1u) ? breg[j] : 0.0f;
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  const int nchunks = a.kpad / KC;
-  load_stage(0);
-  store_stage(0);
-  __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < nchunks) load_stage(c + 1);  // global loads stay in flight under the MFMAs
-#pragma unroll
-    for (int kk = 0; kk < KC / 2; ++kk) {
-      float af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = As[buf][2 * kk + half][(wm * TM + i) * 32 + l31];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][2 * kk + half][(wn * TN + j) * 32 + l31];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(af[i], bf[j], acc[i][j]);
-    }
-    if (c + 1 < nchunks) store_stage(buf ^ 1);
-    __syncthreads();
-  }
-
-  conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
-}
-
 // Split-K: a workgroup that only covered a slice of the reduction stores its raw accumulators to
 // ws[slice][channel][position] (positions contiguous: 128 B per half-wave, like the real epilogue).
 template <int TM, int TN>
@@ -294,21 +172,30 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKerne
 }
 
 // ------------------------------------------------------------------------------------------
-// "Channel-tile / constant-tap" variant (cin % KC == 0; every ECO conv except conv1_7x7_s2).
-// Reduction order k' = (cc*taps + tap)*KC + ci with channel c = cc*KC + ci: all KC rows of a
-// stage share one kernel tap, so
+// The convolution kernel.  MODE selects how the im2col rows of a stage are addressed:
+//
+// MODE = ECO_CONV_MODE_CTAP ("channel-tile / constant-tap", cin % KC == 0; every ECO conv except
+// conv1_7x7_s2).  Reduction order k' = (cc*taps + tap)*KC + ci with channel c = cc*KC + ci: all KC
+// rows of a stage share one kernel tap, so
 //   * the zero-padding predicate is one bit test per thread per stage (not per element),
 //   * the gather address is  x + [uniform: (cc*KC + ci)*s_in + tap offset] + [per-thread: base(n)]
 //     -> a scalar base + one 32-bit vector offset per load, no per-element VALU and no table,
 //   * consecutive stages walk the 27 (9, 1) taps of the same KC channels, i.e. the same cache
 //     lines shifted by a tap -> the im2col re-reads are L1/L2 hits.
-// The next stage's global loads are issued *between* the MFMAs of the current stage (one or two
-// loads per k-pair step), so a wave goes from the barrier straight into MFMA issue; the only
-// non-overlapped work per stage is the LDS write of the prefetched registers and the barrier.
-// Register budget: 64 accumulators per 2x2 wave tile leave 104 VGPRs for three workgroups per CU
-// (512 / 168); the second launch-bound argument (waves per SIMD) holds the allocator to that.
-template <int TM, int TN, int WM, int WN, int KC>
-__global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_ctap_kernel(const ConvKernelArgs a) {
+// MODE = ECO_CONV_MODE_TABLE (any cin; conv1: cin = 3, K = 147).  Reference order k = c*taps + tap;
+// each row's input offset and tap come from the int32 table ktab[k] = tap << 26 | offset, fetched
+// with scalar loads two stages ahead, and the padding predicate is per element.
+//
+// In both modes the next stage's global loads are issued *between* the MFMAs of the current stage
+// (one or two per k-pair step), the fragment registers are double-buffered so the ds_reads of step
+// kk+1 are in flight under the MFMAs of step kk, and the only non-overlapped work per stage is the
+// LDS write of the prefetched registers plus one barrier.
+//
+// Register budget: 64 accumulators per 2x2 wave tile leave ~100 VGPRs for four workgroups per CU;
+// the second launch-bound argument (waves per SIMD) holds the allocator to that.
+template <int TM, int TN, int WM, int WN, int KC, int MODE>
+__global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(const ConvKernelArgs a) {
+  constexpr bool CTAP = MODE == ECO_CONV_MODE_CTAP;
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
   static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -340,6 +227,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_ctap_kernel(
   const int c_begin = (int)((long)slice * nstages_all / a.ksplit);
   const int c_end = (int)((long)(slice + 1) * nstages_all / a.ksplit);
 
+  // ---- gather role of this thread: one output position, EPT of the stage's KC rows ----
   const int pos_l = tid % BN;
   const int kg = uniform(tid / BN);
   int in_base = 0;
@@ -363,29 +251,47 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_ctap_kernel(
     }
   }
 
-  // ---- stage being loaded: uniform (cc, tap) walk + this thread's predicate/offset ----
+  // ---- the stage being loaded ----
+  const float* l_wp = a.wp + m0 + (long)c_begin * KC * a.mpad;  // uniform: packed-weight rows of the stage
+  // CTAP: uniform (cc, tap) walk + this thread's predicate / offset
   const int taps = a.kd * a.kh * a.kw;
   int l_cc = c_begin / taps, l_tap = c_begin % taps;
   int l_kx = l_tap % a.kw, l_ky = (l_tap / a.kw) % a.kh, l_kz = l_tap / (a.kw * a.kh);
   const float* l_xb = a.x;           // uniform: x + cc*KC*s_in + tap offset
-  const float* l_wp = a.wp + m0 + (long)c_begin * KC * a.mpad;  // uniform: packed-weight rows of the stage
   int l_voff = 0;                    // per thread: base(n) if the tap is inside the image, else the
-  bool l_ok = false;                 // offset back to the start of the channel plane (always in bounds)
-  auto begin_stage = [&]() {
-    const int toff = (l_kz * a.Hi + l_ky) * a.Wi + l_kx;
-    l_xb = a.x + ((long)l_cc * KC * a.s_in + toff);
-    l_ok = (mask >> l_tap) & 1ull;
-    l_voff = l_ok ? in_base : -toff;
+  unsigned l_ok = 0;                 // offset back to the start of the channel plane (always in bounds)
+  // TABLE: this thread's table entries (uniform across the wave) for the stage being loaded and the next
+  int kt_cur[EPT], kt_nxt[EPT];
+  auto fetch_table = [&](int stage, int (&dst)[EPT]) {
+    const int sidx = stage < nstages_all ? stage : nstages_all - 1;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) dst[j] = ld(a.ktab + sidx * KC + kg + j * KG);
   };
-  auto next_stage = [&]() {
+  auto begin_stage = [&]() {
+    if (CTAP) {
+      const int toff = (l_kz * a.Hi + l_ky) * a.Wi + l_kx;
+      l_xb = a.x + ((long)l_cc * KC * a.s_in + toff);
+      l_ok = (mask >> l_tap) & 1ull ? ~0u : 0u;
+      l_voff = l_ok ? in_base : -toff;
+    } else {
+      l_ok = 0;
+    }
+  };
+  auto next_stage = [&](int stage) {  // `stage` = index of the stage that becomes "being loaded"
     l_wp += (long)KC * a.mpad;
-    ++l_tap;
-    if (++l_kx == a.kw) {
-      l_kx = 0;
-      if (++l_ky == a.kh) {
-        l_ky = 0;
-        if (++l_kz == a.kd) { l_kz = 0; l_tap = 0; ++l_cc; }
+    if (CTAP) {
+      ++l_tap;
+      if (++l_kx == a.kw) {
+        l_kx = 0;
+        if (++l_ky == a.kh) {
+          l_ky = 0;
+          if (++l_kz == a.kd) { l_kz = 0; l_tap = 0; ++l_cc; }
+        }
       }
+    } else {
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) kt_cur[j] = kt_nxt[j];
+      fetch_table(stage + 1, kt_nxt);
     }
     begin_stage();
   };
@@ -399,8 +305,18 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_ctap_kernel(
       areg[i] = ld((const float4*)(l_wp + (long)row * a.mpad + c4 * 4));
     }
   };
-  auto load_b = [&](int j) { breg[j] = ld(l_xb + (long)(kg + j * KG) * a.s_in + l_voff); };
-  auto store_stage = [&](int buf, bool ok) {
+  auto load_b = [&](int j) {
+    if (CTAP) {
+      breg[j] = ld(l_xb + (long)(kg + j * KG) * a.s_in + l_voff);
+    } else {
+      const int off = kt_cur[j] & kKoffMask;
+      const unsigned tap = (unsigned)kt_cur[j] >> kKoffBits;
+      const unsigned ok = (unsigned)(mask >> tap) & 1u;
+      l_ok |= ok << j;
+      breg[j] = ld(a.x + (ok ? in_base + off : 0));
+    }
+  };
+  auto store_stage = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
       const int idx = tid + i * 256;
@@ -410,7 +326,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_ctap_kernel(
       }
     }
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) Bs[buf][kg + j * KG][pos_l] = ok ? breg[j] : 0.0f;
+    for (int j = 0; j < EPT; ++j) Bs[buf][kg + j * KG][pos_l] = ((l_ok >> j) & 1u) ? breg[j] : 0.0f;
   };
 
   f32x16 acc[TM][TN];
@@ -437,16 +353,20 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_ctap_kernel(
       for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(af[slot][i], bf[slot][j], acc[i][j]);
   };
 
+  if (!CTAP) {
+    fetch_table(c_begin, kt_cur);
+    fetch_table(c_begin + 1, kt_nxt);
+  }
   begin_stage();
 #pragma unroll
   for (int i = 0; i < A_ITERS; ++i) load_a(i);
 #pragma unroll
   for (int j = 0; j < EPT; ++j) load_b(j);
-  store_stage(0, l_ok);
+  store_stage(0);
   __syncthreads();
   for (int c = c_begin; c + 1 < c_end; ++c) {
     const int buf = (c - c_begin) & 1;
-    next_stage();
+    next_stage(c + 1);
     read_frags(buf, 0, 0);
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) {
@@ -457,7 +377,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_ctap_kernel(
       mfma_step(kk & 1);
       sched_fence();
     }
-    store_stage(buf ^ 1, l_ok);
+    store_stage(buf ^ 1);
     __syncthreads();
   }
   {
@@ -595,9 +515,9 @@ template <int TM, int TN, int WM, int WN, int KC>
 static int launch_conv(const ConvKernelArgs& a, int mode, hipStream_t stream) {
   const int grid = a.nblk_m * a.nblk_n * a.ksplit;
   if (mode == ECO_CONV_MODE_CTAP)
-    hipLaunchKernelGGL((conv_ctap_kernel<TM, TN, WM, WN, KC>), dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, KC, ECO_CONV_MODE_CTAP>), dim3(grid), dim3(256), 0, stream, a);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WM, WN, KC>), dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, KC, ECO_CONV_MODE_TABLE>), dim3(grid), dim3(256), 0, stream, a);
   return check_launch("eco_conv_forward");
 }
 
@@ -640,7 +560,7 @@ extern "C" int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* pla
               "conv: bad plan mode");
   ECO_REQUIRE((long)g->n * a.img_stride_in < 2147483647l, "conv: input tensor too large for int32 gather offsets");
   const int mode = plan->mode;
-  ECO_REQUIRE(plan->ksplit >= 1 && (plan->ksplit == 1 || (mode == ECO_CONV_MODE_CTAP && plan->kpad / plan->kc >= plan->ksplit)),
+  ECO_REQUIRE(plan->ksplit >= 1 && (plan->ksplit == 1 || plan->kpad / plan->kc >= plan->ksplit),
               "conv: bad split-K factor %d", plan->ksplit);
   ECO_REQUIRE(plan->ksplit == 1 || workspace != nullptr, "conv: plan needs a %ld-byte workspace", (long)plan->ws_bytes);
   a.ksplit = plan->ksplit;

@@ -86,8 +86,7 @@ _CONV_TILES = {128: (2, 2, 2, 2), 96: (3, 2, 1, 4), 64: (2, 2, 1, 4), 32: (1, 2,
 def conv_kernel_name(plan: ConvPlan) -> str:
     """Name of the device kernel eco_conv_forward launches for this plan, as rocprofv3 prints it."""
     tm, tn, wm, wn = _CONV_TILES[plan.bm]
-    fam = "conv_ctap_kernel" if plan.mode == 1 else "conv_igemm_kernel"
-    return f"eco::{fam}<{tm}, {tn}, {wm}, {wn}, {plan.kc}>"
+    return f"eco::conv_mfma_kernel<{tm}, {tn}, {wm}, {wn}, {plan.kc}, {plan.mode}>"
 
 
 def plain_view(ptr: int, channels: int, spatial: int) -> View:
