@@ -57,9 +57,13 @@ def main() -> None:
     from eco_amd import dist as eco_dist
     from eco_amd.netspec import NetSpec
 
-    caffe.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    eco_dist.init_process_group("nccl", device=dev)  # RCCL over xGMI; no-op at world 1
+    # ECO_BENCH_DEVICE / ECO_BENCH_BACKEND exist only to exercise the N>1 code path on a 1-GPU box
+    # (all ranks on one device, gloo instead of RCCL); the driver's multi-GPU runs use neither.
+    dev_index = int(os.environ.get("ECO_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("ECO_BENCH_BACKEND", "nccl")
+    caffe.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    eco_dist.init_process_group(backend, device=dev if backend == "nccl" else None)  # RCCL over xGMI; no-op at world 1
 
     B, N = args.clips_per_gpu, args.segments
     gen = models.eco_lite_deploy if args.variant == "lite" else models.eco_full_deploy
