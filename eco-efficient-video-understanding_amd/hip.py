@@ -80,12 +80,13 @@ def pool_geom(n: int, c: int, in_sp, kernel, stride, pad, out_sp, method: str) -
                     _pad3(pad, 0), _pad3(out_sp, 1), {"MAX": POOL_MAX, "AVE": POOL_AVE}[method])
 
 
-_CONV_TILES = {128: (2, 2, 2, 2), 96: (3, 2, 1, 4), 64: (2, 2, 1, 4), 32: (1, 2, 1, 4)}  # bm -> TM,TN,WM,WN
+_CONV_TILES = {(128, 128): (2, 2, 2, 2), (128, 256): (2, 4, 2, 2), (96, 256): (3, 2, 1, 4), (64, 256): (2, 2, 1, 4),
+               (32, 256): (1, 2, 1, 4)}  # (bm, bn) -> TM,TN,WM,WN
 
 
 def conv_kernel_name(plan: ConvPlan) -> str:
     """Name of the device kernel eco_conv_forward launches for this plan, as rocprofv3 prints it."""
-    tm, tn, wm, wn = _CONV_TILES[plan.bm]
+    tm, tn, wm, wn = _CONV_TILES[(plan.bm, plan.bn)]
     return f"eco::conv_mfma_kernel<{tm}, {tn}, {wm}, {wn}, {plan.kc}, {plan.mode}>"
 
 

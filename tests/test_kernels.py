@@ -129,7 +129,7 @@ def test_conv_plan_choice(backend):
     for cout, bm in [(32, 32), (64, 64), (96, 96), (128, 128), (160, 96), (192, 96), (224, 128), (256, 128),
                      (320, 64), (352, 128), (512, 128)]:
         p = lib.conv_plan(hip.conv_geom(1, 8, cout, (8, 8), (3, 3), (1, 1), (1, 1), (8, 8)))
-        assert p.bm == bm and p.kpad % p.kc == 0 and p.mpad >= cout and p.mpad % 4 == 0
+        assert p.bm == bm and p.bn in (128, 256) and p.kpad % p.kc == 0 and p.mpad >= cout and p.mpad % 4 == 0
         assert p.mode == 0  # cin=8: table mode
     assert lib.conv_plan(hip.conv_geom(1, 64, 64, (8, 8), (3, 3), (1, 1), (1, 1), (8, 8))).mode == 1
     # split-K: chosen when the tile count quantises badly over 256 CUs and the reduction is long
@@ -138,6 +138,7 @@ def test_conv_plan_choice(backend):
     p3 = lib.conv_plan(hip.conv_geom(32, 128, 128, (16, 28, 28), (3, 3, 3), (1, 1, 1), (1, 1, 1), (16, 28, 28)))  # res3b: 3136 tiles
     assert p5.ksplit > 1 and p5.ws_bytes == p5.ksplit * 512 * 32 * 196 * 4
     assert p4.ksplit > 1 and p3.ksplit == 1 and p3.ws_bytes == 0
+    assert (p3.bm, p3.bn) == (128, 128) and (p4.bm, p4.bn) == (128, 256) and (p5.bm, p5.bn) == (128, 256)
     with pytest.raises(hip.EcoError, match="workspace"):
         lib.conv_forward(hip.conv_geom(32, 512, 512, (4, 7, 7), (3, 3, 3), (1, 1, 1), (1, 1, 1), (4, 7, 7)), p5, 8, 8, 8,
                          _dummy_epilogue(), None)
