@@ -250,6 +250,34 @@ __global__ __launch_bounds__(256) void global_avgpool_fc_kernel(const float* x, 
   }
 }
 
+// VideoData output contract on the GPU: uint8 HWC (interleaved BGR) -> cropped, mean-subtracted, scaled
+// planar fp32.  One thread per 4 consecutive output pixels of a row (12 contiguous input bytes, 4 floats
+// into each of the three colour planes).  HBM-bound: 3 B read + 12 B written per pixel.
+__global__ __launch_bounds__(256) void video_input_kernel(const uint8_t* frames, float* y, long num_frames, int H, int W,
+                                                          int ch, int cw, int h_off, int w_off, float m0, float m1,
+                                                          float m2, float scale, int mirror) {
+  const int wq = (cw + 3) / 4;
+  const long total = num_frames * ch * wq;
+  const float mean[3] = {m0, m1, m2};
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+    const int q = (int)(i % wq);
+    const long t = i / wq;
+    const int h = (int)(t % ch);
+    const long f = t / ch;
+    const uint8_t* src = frames + ((f * H + (h_off + h)) * (long)W + w_off) * 3;
+    float* dst = y + f * 3 * ch * cw + (long)h * cw;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int w = 4 * q + e;  // output column
+      if (w >= cw) break;
+      const int ws = mirror ? (cw - 1 - w) : w;  // source column inside the crop (data_transformer.cpp:272-276)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        st(dst + (long)c * ch * cw + w, ((float)ld(src + (long)ws * 3 + c) - mean[c]) * scale);
+    }
+  }
+}
+
 // Softmax over axis 1 of [outer, c, inner]: one thread per (outer, inner) column.
 __global__ __launch_bounds__(256) void softmax_kernel(const float* x, float* y, long outer, long c, long inner) {
   const long total = outer * inner;
@@ -411,6 +439,22 @@ extern "C" int eco_global_avgpool_fc_forward(const float* x, const float* w, con
   hipLaunchKernelGGL((global_avgpool_fc_kernel), grid, dim3(kThreads), 0, (hipStream_t)stream, x, w, bias, y, (int)c,
                      (int)s, (int)n_out, (int)wk, (int)c0, accumulate);
   return check_launch("eco_global_avgpool_fc_forward");
+}
+
+extern "C" int eco_video_input_forward(const uint8_t* frames, float* y, int64_t num_frames, int32_t height,
+                                       int32_t width, int32_t crop_h, int32_t crop_w, int32_t h_off, int32_t w_off,
+                                       const float mean[3], float scale, int32_t mirror, void* stream) {
+  clear_error();
+  ECO_REQUIRE(frames && y && mean, "video_input: null argument");
+  ECO_REQUIRE(num_frames > 0 && height > 0 && width > 0 && crop_h > 0 && crop_w > 0, "video_input: bad shape");
+  // DataTransformer CHECK_GE(datum_height, crop_size) / CHECK_GE(datum_width, crop_size)
+  ECO_REQUIRE(h_off >= 0 && w_off >= 0 && h_off + crop_h <= height && w_off + crop_w <= width,
+              "video_input: crop %dx%d at (%d,%d) does not fit the %dx%d frame", crop_h, crop_w, h_off, w_off, height, width);
+  const long total = (long)num_frames * crop_h * ((crop_w + 3) / 4);
+  hipLaunchKernelGGL((video_input_kernel), dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, frames, y,
+                     (long)num_frames, height, width, crop_h, crop_w, h_off, w_off, mean[0], mean[1], mean[2], scale,
+                     mirror);
+  return check_launch("eco_video_input_forward");
 }
 
 extern "C" int eco_softmax_forward(const float* x, float* y, int64_t outer, int64_t c, int64_t inner, void* stream) {

@@ -21,7 +21,7 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _i32x3 = C.c_int32 * 3
 
@@ -124,6 +124,8 @@ _SIGNATURES = {
                                             C.c_int64, C.c_void_p]),
     "eco_global_avgpool_fc_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                                 C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    "eco_video_input_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_float, C.c_int32, C.c_void_p]),
     "eco_softmax_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
 }
 
@@ -215,6 +217,12 @@ class EcoLib:
     def global_avgpool_fc_forward(self, x, w, bias, y, b, c, s, n_out, wk, c0=0, accumulate=False, stream=None) -> None:
         self._check(self._dll.eco_global_avgpool_fc_forward(x, w, bias, y, b, c, s, n_out, wk, c0,
                                                             int(accumulate), stream))
+
+    def video_input_forward(self, frames, y, num_frames, height, width, crop_h, crop_w, h_off, w_off, mean, scale=1.0,
+                            mirror=False, stream=None) -> None:
+        m = (C.c_float * 3)(*[float(v) for v in mean])
+        self._check(self._dll.eco_video_input_forward(frames, y, num_frames, height, width, crop_h, crop_w, h_off, w_off,
+                                                      m, float(scale), int(bool(mirror)), stream))
 
     def softmax_forward(self, x, y, outer, c, inner, stream=None) -> None:
         self._check(self._dll.eco_softmax_forward(x, y, outer, c, inner, stream))

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 2
+#define ECO_ABI_VERSION 3
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -186,6 +186,17 @@ int eco_inner_product_forward(const float* x, const float* w, const float* bias,
 int eco_global_avgpool_fc_forward(const float* x, const float* w, const float* bias, float* y,
                                   int64_t b, int64_t c, int64_t s, int64_t n_out, int64_t wk,
                                   int64_t c0, int accumulate, void* stream);
+/* GPU-side input stage = the VideoData TEST-phase output contract
+ * (layers/video_data_layer.cpp:107-119, util/io.cpp:368-421 ReadSegmentRGBToDatum, DataTransformer::Transform
+ * data_transformer.cpp:147-330): decoded frames arrive as uint8 H x W x 3 interleaved (OpenCV BGR order, channel
+ * index c = 0,1,2 kept as is), one after another; each is cropped to crop_h x crop_w at (h_off, w_off)
+ * (TEST: centre crop, h_off=(H-crop)/2), optionally mirrored in w, converted to planar fp32
+ *   y[f][c][h][w] = (float(frames[f][h_off+h][w_off+w][c]) - mean[c]) * scale
+ * which is exactly the [B*N, 3, crop, crop] blob the deploy net takes as `data`.  Shipping uint8 frames
+ * and converting on the GPU moves 4x fewer bytes over PCIe than fp32 frames. */
+int eco_video_input_forward(const uint8_t* frames, float* y, int64_t num_frames, int32_t height, int32_t width,
+                            int32_t crop_h, int32_t crop_w, int32_t h_off, int32_t w_off, const float mean[3],
+                            float scale, int32_t mirror, void* stream);
 /* SoftmaxLayer::Forward_gpu over axis 1 of [outer, c, inner] (layers/softmax_layer.cu:14-71). */
 int eco_softmax_forward(const float* x, float* y, int64_t outer, int64_t c, int64_t inner,
                         void* stream);

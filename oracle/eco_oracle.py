@@ -280,6 +280,25 @@ def softmax(x, axis=1) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------
+# VideoData output contract (TEST phase)
+# --------------------------------------------------------------------------
+def video_transform(frames_hwc_u8, crop_h, crop_w, h_off, w_off, mean, scale=1.0, mirror=False) -> np.ndarray:
+    """``ReadSegmentRGBToDatum`` + ``DataTransformer::Transform`` for uint8 colour frames
+    (util/io.cpp:398-408: planar copy ``datum[c][h][w] = img(h,w)[c]``; data_transformer.cpp:258-316:
+    ``top[c][h][w or W-1-w] = (datum[c][h_off+h][w_off+w] - mean_values[c]) * scale``)."""
+    f = np.asarray(frames_hwc_u8)
+    assert f.dtype == np.uint8 and f.ndim == 4 and f.shape[3] == 3
+    F = f.shape[0]
+    out = np.empty((F, 3, crop_h, crop_w), np.float32)
+    for c in range(3):
+        plane = f[:, h_off:h_off + crop_h, w_off:w_off + crop_w, c].astype(np.float32)
+        if mirror:
+            plane = plane[:, :, ::-1]
+        out[:, c] = (plane - np.float32(mean[c])) * np.float32(scale)
+    return out
+
+
+# --------------------------------------------------------------------------
 # whole-net forward (Net::ForwardFromTo, net.cpp:566-583)
 # --------------------------------------------------------------------------
 def forward(spec, params, inputs, keep=None, fast_pool=True, timings=None):
