@@ -29,7 +29,6 @@ def test_video_input_kernel(backend, H, W, ch, cw, ho, wo, mirror):
     frames = rng.integers(0, 256, size=(F, H, W, 3), dtype=np.uint8)
     mean = (104.0, 117.0, 123.0)
     ref = orc.video_transform(frames, ch, cw, ho, wo, mean, 0.5, mirror)
-    dfr = backend.dev(frames.view(np.uint8).reshape(-1).view(np.uint8)) if backend.kind == "hip" else None
     if backend.kind == "emu":
         buf = np.ascontiguousarray(frames)
         backend._keep.append(buf)
