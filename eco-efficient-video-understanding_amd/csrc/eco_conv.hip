@@ -48,7 +48,10 @@ struct ConvKernelArgs {
   long img_stride_in;   // cin * s_in
   int ntot;             // n * s_out output positions
   int nblk_m, nblk_n;
-  int ksplit;           // >1: the reduction is cut into ksplit slices, partial sums go to ws[slice][cout][ntot]
+  // Split-K region: the last n_split tiles (all of them for a full split) have their reduction cut into
+  // ksplit slices; partial sums go to ws[slice][cout][n - n_split0] and a second launch reduces them.
+  int ksplit, n_main, n_split;   // n_main + n_split = nblk_m * nblk_n
+  int n_split0;                  // first output position covered by the split region
   float* ws;
 };
 
@@ -136,7 +139,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&
 template <int TM, int TN>
 __device__ __forceinline__ void conv_store_partial(const ConvKernelArgs& a, f32x16 (&acc)[TM][TN], int slice, int mw,
                                                    int nw, int half, int l31) {
-  float* base = a.ws + (long)slice * a.cout * a.ntot;
+  const int nsplit_pos = a.ntot - a.n_split0;
+  float* base = a.ws + (long)slice * a.cout * nsplit_pos - a.n_split0;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = nw + j * 32 + l31;
@@ -146,17 +150,18 @@ __device__ __forceinline__ void conv_store_partial(const ConvKernelArgs& a, f32x
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ch = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (ch < a.cout) st(base + (long)ch * a.ntot + n, acc[i][j][r]);
+        if (ch < a.cout) st(base + (long)ch * nsplit_pos + n, acc[i][j][r]);
       }
   }
 }
 
 // Second pass of split-K: sum the slices in a fixed order (deterministic) and apply the epilogue.
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKernelArgs a) {
-  const long total = (long)a.cout * a.ntot;
+  const int nsplit_pos = a.ntot - a.n_split0;
+  const long total = (long)a.cout * nsplit_pos;
   const long slice_stride = total;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int ch = (int)(idx / a.ntot), n = (int)(idx - (long)ch * a.ntot);
+    const int ch = (int)(idx / nsplit_pos), n = a.n_split0 + (int)(idx - (long)ch * nsplit_pos);
     float v = 0.0f;
     for (int sidx = 0; sidx < a.ksplit; ++sidx) v += ld((const float*)a.ws + sidx * slice_stride + idx);
     const int img = n / a.s_out, sp = n - img * a.s_out;
@@ -218,14 +223,25 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, l31 = lane & 31;
 
-  const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const int ntiles = a.nblk_m * a.nblk_n;
-  const int slice = bid / ntiles, tile = bid - slice * ntiles;  // slice-major: neighbours share the K range
+  // Hardware blocks [0, n_main) are whole tiles; the rest are (slice, tile) pairs of the split-K region,
+  // slice-major so neighbours share the K range.  Each range gets its own XCD-contiguous remap, and the
+  // split region comes last in dispatch order so its short blocks fill the tail of the launch.
+  int tile, slice, nslices;
+  if ((int)blockIdx.x < a.n_main) {
+    tile = xcd_remap((int)blockIdx.x, a.n_main);
+    slice = 0;
+    nslices = 1;
+  } else {
+    const int lid = xcd_remap((int)blockIdx.x - a.n_main, a.n_split * a.ksplit);
+    slice = lid / a.n_split;
+    tile = a.n_main + (lid - slice * a.n_split);
+    nslices = a.ksplit;
+  }
   const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
   const int m0 = mblk * BM, n0 = nblk * BN;
   const int nstages_all = a.kpad / KC;
-  const int c_begin = (int)((long)slice * nstages_all / a.ksplit);
-  const int c_end = (int)((long)(slice + 1) * nstages_all / a.ksplit);
+  const int c_begin = (int)((long)slice * nstages_all / nslices);
+  const int c_end = (int)((long)(slice + 1) * nstages_all / nslices);
 
   // ---- gather role of this thread: one output position, EPT of the stage's KC rows ----
   const int pos_l = tid % BN;
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(
       sched_fence();
     }
   }
-  if (a.ksplit > 1)
+  if (nslices > 1)
     conv_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
   else
     conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
@@ -423,7 +439,12 @@ static int validate_geom(const eco_conv_geom* g) {
 using namespace eco;
 
 extern "C" int eco_conv_plan_create(const eco_conv_geom* g, eco_conv_plan* plan) {
+  return eco_conv_plan_create_ex(g, kNumCU, plan);
+}
+
+extern "C" int eco_conv_plan_create_ex(const eco_conv_geom* g, int32_t num_cu, eco_conv_plan* plan) {
   clear_error();
+  ECO_REQUIRE(num_cu >= 1, "conv: num_cu must be positive");
   if (int rc = validate_geom(g)) return rc;
   ECO_REQUIRE(plan != nullptr, "conv: null plan");
   int bm;
@@ -446,7 +467,7 @@ extern "C" int eco_conv_plan_create(const eco_conv_geom* g, eco_conv_plan* plan)
     // weight loads, fragment reads and barriers per MFMA at 2 workgroups/CU; split-K keeps the CUs busy.
     // With thousands of tiles (res3) 128x128 at 4 workgroups/CU is as fast and quantises better.
     const long ntot_ = (long)g->n * g->out[0] * g->out[1] * g->out[2];
-    if (ceil_div(g->cout, 128) * ceil_div(ntot_, 128) <= 1024) plan->bn = 256;
+    if (ceil_div(g->cout, 128) * ceil_div(ntot_, 128) <= 4L * num_cu) plan->bn = 256;
   }
   plan->kc = 16;
   plan->mode = (g->cin % plan->kc == 0) ? ECO_CONV_MODE_CTAP : ECO_CONV_MODE_TABLE;
@@ -457,27 +478,54 @@ extern "C" int eco_conv_plan_create(const eco_conv_geom* g, eco_conv_plan* plan)
   plan->mpad = (int)(ceil_div(plan->mpad, 4) * 4);
   plan->wp_elems = (int64_t)plan->kpad * plan->mpad;
   plan->ktab_elems = plan->kpad;
-  // Split-K: with few output tiles the 256 CUs are unevenly loaded (e.g. 784 tiles = 3.06 per CU ->
-  // the busiest CU does 4) and under-occupied.  Cut the reduction into S slices so that tiles*S
-  // quantises well, as long as every slice keeps >= 8 stages; the partial sums cost S extra
-  // write+read passes over the (small) output, priced at ~4 TB/s against ~100 TFLOP/s of MFMA time.
+  // Split-K.  (a) With fewer tiles than resident workgroup slots the CUs are unevenly loaded (e.g. 392 tiles
+  // = 1.53 per CU -> the busiest CU does 2) and under-occupied: cut the whole reduction into S slices so
+  // that tiles*S quantises well.  (b) With many tiles the last, partial round of workgroups leaves most
+  // CUs idle while a few finish (3136 tiles over 1024 slots: 3 rounds + 64 stragglers = 4.5 % measured):
+  // split only those trailing tiles, S ways, so that they form one more full round of short blocks.
+  // Either way every slice keeps >= 8 stages, the partial sums cost S write+read passes over the split
+  // region's outputs (priced at ~4 TB/s against ~100 TFLOP/s of MFMA time), and a second, deterministic
+  // launch reduces them and applies the epilogue.
   plan->ksplit = 1;
+  plan->split_tiles = 0;
   plan->ws_bytes = 0;
-  if (plan->mode == ECO_CONV_MODE_CTAP) {
+  {
     const long s_out = (long)g->out[0] * g->out[1] * g->out[2];
     const long ntot = (long)g->n * s_out;
-    const long tiles = ceil_div(g->cout, bm) * ceil_div(ntot, plan->bn);
+    const long mblocks = ceil_div(g->cout, bm);
+    const long tiles = mblocks * ceil_div(ntot, plan->bn);
     const int nstages = plan->kpad / plan->kc;
-    const double t_flops = 2.0 * ntot * g->cout * plan->k / 100e12;
-    double best = 1e30;
-    for (int sp = 1; sp <= 16; ++sp) {
-      if (sp > 1 && nstages / sp < 8) break;
-      const double per_cu = (double)tiles * sp / kNumCU;
-      const double eff = per_cu / (double)ceil_div(tiles * sp, kNumCU);
-      const double t = t_flops / eff + (sp > 1 ? 2.0 * sp * ntot * g->cout * 4.0 / 4e12 + 5e-6 : 0.0);
-      if (t < best * 0.97) { best = t; plan->ksplit = sp; }  // prefer fewer slices unless >3 % better
+    const int occ = (bm == 128 && plan->bn == 256) ? 2 : (bm == 96 ? 3 : 4);  // resident workgroups per CU
+    const long slots = (long)num_cu * occ;
+    if (tiles < slots) {
+      const double t_flops = 2.0 * ntot * g->cout * plan->k / 100e12;
+      double best = 1e30;
+      for (int sp = 1; sp <= 16; ++sp) {
+        if (sp > 1 && nstages / sp < 8) break;
+        const double per_cu = (double)tiles * sp / num_cu;
+        const double eff = per_cu / (double)ceil_div(tiles * sp, num_cu);
+        const double t = t_flops / eff + (sp > 1 ? 2.0 * sp * ntot * g->cout * 4.0 / 4e12 + 5e-6 : 0.0);
+        if (t < best * 0.97) { best = t; plan->ksplit = sp; }  // prefer fewer slices unless >3 % better
+      }
+      if (plan->ksplit > 1) plan->split_tiles = (int)tiles;
+    } else {
+      long rem = tiles % slots;
+      if (rem > 0 && 2 * rem < slots) {
+        rem = ceil_div(rem, mblocks) * mblocks;              // whole columns of M-blocks
+        long sp = slots / rem;
+        if (sp > 16) sp = 16;
+        if (sp > nstages / 8) sp = nstages / 8;
+        if (sp >= 2 && rem < tiles) { plan->ksplit = (int)sp; plan->split_tiles = (int)rem; }
+      }
     }
-    if (plan->ksplit > 1) plan->ws_bytes = (int64_t)plan->ksplit * g->cout * ntot * 4;
+    if (plan->ksplit > 1) {
+      const long split_cols = plan->split_tiles / mblocks;   // N-blocks in the split region
+      long split_pos = split_cols * plan->bn;
+      if (split_pos > ntot) split_pos = ntot;
+      const long n_split0 = (ceil_div(ntot, plan->bn) - split_cols) * plan->bn;
+      plan->ws_bytes = (int64_t)plan->ksplit * g->cout * (ntot - n_split0) * 4;
+      (void)split_pos;
+    }
   }
   return ECO_OK;
 }
@@ -520,7 +568,7 @@ extern "C" int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan
 
 template <int TM, int TN, int WM, int WN, int KC>
 static int launch_conv(const ConvKernelArgs& a, int mode, hipStream_t stream) {
-  const int grid = a.nblk_m * a.nblk_n * a.ksplit;
+  const int grid = a.n_main + a.n_split * a.ksplit;
   if (mode == ECO_CONV_MODE_CTAP)
     hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, KC, ECO_CONV_MODE_CTAP>), dim3(grid), dim3(256), 0, stream, a);
   else
@@ -567,10 +615,19 @@ extern "C" int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* pla
               "conv: bad plan mode");
   ECO_REQUIRE((long)g->n * a.img_stride_in < 2147483647l, "conv: input tensor too large for int32 gather offsets");
   const int mode = plan->mode;
+  const int ntiles = a.nblk_m * a.nblk_n;
   ECO_REQUIRE(plan->ksplit >= 1 && (plan->ksplit == 1 || plan->kpad / plan->kc >= plan->ksplit),
               "conv: bad split-K factor %d", plan->ksplit);
+  ECO_REQUIRE((plan->ksplit == 1) == (plan->split_tiles == 0) && plan->split_tiles >= 0 && plan->split_tiles <= ntiles &&
+                  plan->split_tiles % a.nblk_m == 0,
+              "conv: bad split-K region (%d of %d tiles, %d slices)", plan->split_tiles, ntiles, plan->ksplit);
   ECO_REQUIRE(plan->ksplit == 1 || workspace != nullptr, "conv: plan needs a %ld-byte workspace", (long)plan->ws_bytes);
   a.ksplit = plan->ksplit;
+  a.n_split = plan->split_tiles;
+  a.n_main = ntiles - a.n_split;
+  a.n_split0 = (a.n_main / a.nblk_m) * plan->bn;
+  ECO_REQUIRE(plan->ksplit == 1 || (int64_t)plan->ksplit * a.cout * (a.ntot - a.n_split0) * 4 <= plan->ws_bytes,
+              "conv: plan workspace too small");
   a.ws = (float*)workspace;
   int rc = ECO_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -585,7 +642,7 @@ extern "C" int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* pla
     default: return fail(ECO_ERR_INVALID, "conv: unsupported block tile bm=%d", plan->bm);
   }
   if (rc != ECO_OK || a.ksplit == 1) return rc;
-  long rblocks = ceil_div((long)a.cout * a.ntot, 256);
+  long rblocks = ceil_div((long)a.cout * (a.ntot - a.n_split0), 256);
   if (rblocks > 262144) rblocks = 262144;
   hipLaunchKernelGGL((conv_splitk_reduce_kernel), dim3((unsigned)rblocks), dim3(256), 0, s, a);
   return check_launch("eco_conv_forward(split-K reduce)");

@@ -213,30 +213,42 @@ __global__ __launch_bounds__(256) void inner_product_kernel(const float* x, cons
 }
 
 constexpr int kTailMaxC = 2048;
-constexpr int kTailOutPerBlock = 64;
+constexpr int kTailThreads = 1024;        // 16 waves per workgroup
+constexpr int kTailOutPerBlock = 128;
 
-// grid = (ceil(n_out / 64), b).  Each workgroup pools its clip's C channels into LDS
-// (wave per channel, butterfly reduce), then its 4 waves produce 64 logits.
-__global__ __launch_bounds__(256) void global_avgpool_fc_kernel(const float* x, const float* w, const float* bias,
-                                                                float* y, int c, int s, int n_out, int wk, int c0,
-                                                                int accumulate) {
+// grid = (ceil(n_out / 128), b), 1024 threads.  Each workgroup pools its clip's C channels into LDS
+// (one wave per channel, two channels in flight per wave, 64-lane butterfly reduce), then its 16 waves
+// produce 128 logits (one wave per logit: lanes stride over C, butterfly reduce).
+__global__ __launch_bounds__(1024) void global_avgpool_fc_kernel(const float* x, const float* w, const float* bias,
+                                                                 float* y, int c, int s, int n_out, int wk, int c0,
+                                                                 int accumulate) {
   __shared__ float pooled[kTailMaxC];
+  constexpr int kWaves = kTailThreads / kWave;
   const int lane = lane_id();
   const int wave = uniform((int)(threadIdx.x >> 6));
   const int b = (int)blockIdx.y;
   const float* xb = x + (long)b * c * s;
   const float inv = 1.0f / (float)s;
-  for (int ch = wave; ch < c; ch += 4) {
+  for (int ch = wave; ch < c; ch += 2 * kWaves) {
+    const int ch2 = ch + kWaves;
     const float* xp = xb + (long)ch * s;
-    float acc = 0.0f;
-    for (int i = lane; i < s; i += kWave) acc += ld(xp + i);
-    acc = wave_sum(acc);
-    if (lane == 0) pooled[ch] = acc * inv;
+    const float* xq = xb + (long)(ch2 < c ? ch2 : ch) * s;
+    float a0 = 0.0f, a1 = 0.0f;
+    for (int i = lane; i < s; i += kWave) {
+      a0 += ld(xp + i);
+      a1 += ld(xq + i);
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if (lane == 0) {
+      pooled[ch] = a0 * inv;
+      if (ch2 < c) pooled[ch2] = a1 * inv;
+    }
   }
   __syncthreads();
   const int o_begin = (int)blockIdx.x * kTailOutPerBlock;
   const int o_end = min(o_begin + kTailOutPerBlock, n_out);
-  for (int o = o_begin + wave; o < o_end; o += 4) {
+  for (int o = o_begin + wave; o < o_end; o += kWaves) {
     const float* wr = w + (long)o * wk + c0;
     float acc = 0.0f;
     for (int i = lane; i < c; i += kWave) acc += pooled[i] * ld(wr + i);
@@ -436,7 +448,7 @@ extern "C" int eco_global_avgpool_fc_forward(const float* x, const float* w, con
               (long)(c0 + c), (long)wk);
   ECO_REQUIRE(b <= 65535 && s < 2147483647l, "global_avgpool_fc: batch too large for one launch");
   dim3 grid((unsigned)ceil_div(n_out, kTailOutPerBlock), (unsigned)b);
-  hipLaunchKernelGGL((global_avgpool_fc_kernel), grid, dim3(kThreads), 0, (hipStream_t)stream, x, w, bias, y, (int)c,
+  hipLaunchKernelGGL((global_avgpool_fc_kernel), grid, dim3(kTailThreads), 0, (hipStream_t)stream, x, w, bias, y, (int)c,
                      (int)s, (int)n_out, (int)wk, (int)c0, accumulate);
   return check_launch("eco_global_avgpool_fc_forward");
 }

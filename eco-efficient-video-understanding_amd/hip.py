@@ -21,7 +21,7 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _i32x3 = C.c_int32 * 3
 
@@ -44,7 +44,8 @@ class ConvPlan(C.Structure):
     _fields_ = [("bm", C.c_int32), ("bn", C.c_int32), ("kc", C.c_int32), ("k", C.c_int32),
                 ("kpad", C.c_int32), ("mpad", C.c_int32),
                 ("wp_elems", C.c_int64), ("ktab_elems", C.c_int64),
-                ("mode", C.c_int32), ("ksplit", C.c_int32), ("ws_bytes", C.c_int64)]
+                ("mode", C.c_int32), ("ksplit", C.c_int32), ("ws_bytes", C.c_int64),
+                ("split_tiles", C.c_int32), ("reserved", C.c_int32)]
 
 
 class View(C.Structure):
@@ -107,6 +108,7 @@ _SIGNATURES = {
     "eco_set_device": (C.c_int, [C.c_int]),
     "eco_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "eco_conv_plan_create": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvPlan)]),
+    "eco_conv_plan_create_ex": (C.c_int, [C.POINTER(ConvGeom), C.c_int32, C.POINTER(ConvPlan)]),
     "eco_conv_pack_weights": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvPlan), C.c_void_p, C.c_void_p, C.c_void_p]),
     "eco_conv_forward": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvPlan), C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(ConvEpilogue), C.c_void_p, C.c_void_p]),
@@ -177,9 +179,12 @@ class EcoLib:
         return {"name": name.value.decode(), "num_cu": cu.value, "hbm_bytes": mem.value}
 
     # -- convolution ----------------------------------------------------------
-    def conv_plan(self, g: ConvGeom) -> ConvPlan:
+    def conv_plan(self, g: ConvGeom, num_cu: Optional[int] = None) -> ConvPlan:
         p = ConvPlan()
-        self._check(self._dll.eco_conv_plan_create(C.byref(g), C.byref(p)))
+        if num_cu is None:
+            self._check(self._dll.eco_conv_plan_create(C.byref(g), C.byref(p)))
+        else:
+            self._check(self._dll.eco_conv_plan_create_ex(C.byref(g), int(num_cu), C.byref(p)))
         return p
 
     def conv_pack_weights(self, g: ConvGeom, p: ConvPlan, w_ptr: int, wp_ptr: int, ktab_ptr: int) -> None:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 3
+#define ECO_ABI_VERSION 4
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -86,8 +86,10 @@ typedef struct eco_conv_plan {
   int64_t wp_elems;   /* floats in the packed weight buffer  (kpad*mpad) */
   int64_t ktab_elems; /* int32 entries in the gather table   (kpad)      */
   int32_t mode;       /* ECO_CONV_MODE_*: reduction order of the packed weights / kernel family */
-  int32_t ksplit;     /* >1: split-K, the launch needs a workspace of ws_bytes                   */
+  int32_t ksplit;     /* >1: the last split_tiles output tiles have their reduction cut into ksplit slices */
   int64_t ws_bytes;   /* bytes of device scratch eco_conv_forward needs for this plan (0 if none) */
+  int32_t split_tiles; /* 0 (no split-K), all tiles (few-tile layers) or the tail of a many-tile launch */
+  int32_t reserved;
 } eco_conv_plan;
 
 /* Strided view of an N,C,[D,]H,W output (or residual) tensor.  Element
@@ -124,8 +126,11 @@ typedef struct eco_conv_epilogue {
   eco_view act;
 } eco_conv_epilogue;
 
-/* Validates `g` (fills nothing) and chooses the tiling. */
+/* Validates `g` (fills nothing) and chooses the tiling for MI355X (256 CUs). */
 int eco_conv_plan_create(const eco_conv_geom* g, eco_conv_plan* plan);
+/* Same, for a device with `num_cu` compute units (the CPU test-suite uses tiny values to reach the
+ * many-tile code paths with emulator-sized problems). */
+int eco_conv_plan_create_ex(const eco_conv_geom* g, int32_t num_cu, eco_conv_plan* plan);
 /* HOST function.  Re-lays caffe weights w[cout][cin][kd][kh][kw] (host pointer) into the
  * kernel's K-major image wp[kpad][mpad] (zero padded) and builds the gather table
  * ktab[kpad] (host pointers, sizes from the plan).  The caller uploads both. */

@@ -17,7 +17,7 @@ def relerr(got, ref):
     return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
 
 
-def run_conv(be, n, cin, cout, insp, k, s, p, mode="plain", seed=0):
+def run_conv(be, n, cin, cout, insp, k, s, p, mode="plain", seed=0, num_cu=None):
     rng = np.random.default_rng(seed)
     nd = len(insp)
     x = rng.standard_normal((n, cin) + tuple(insp)).astype(np.float32)
@@ -28,7 +28,7 @@ def run_conv(be, n, cin, cout, insp, k, s, p, mode="plain", seed=0):
     S = int(np.prod(outsp))
     lib = be.lib
     g = hip.conv_geom(n, cin, cout, insp, k, s, p, outsp)
-    plan = lib.conv_plan(g)
+    plan = lib.conv_plan(g, num_cu)
     wp = np.zeros(plan.wp_elems, np.float32)
     kt = np.zeros(plan.ktab_elems, np.int32)
     lib.conv_pack_weights(g, plan, w.ctypes.data, wp.ctypes.data, kt.ctypes.data)
@@ -137,11 +137,29 @@ def test_conv_plan_choice(backend):
     p4 = lib.conv_plan(hip.conv_geom(32, 256, 256, (8, 14, 14), (3, 3, 3), (1, 1, 1), (1, 1, 1), (8, 14, 14)))  # res4b: 784 tiles
     p3 = lib.conv_plan(hip.conv_geom(32, 128, 128, (16, 28, 28), (3, 3, 3), (1, 1, 1), (1, 1, 1), (16, 28, 28)))  # res3b: 3136 tiles
     assert p5.ksplit > 1 and p5.ws_bytes == p5.ksplit * 512 * 32 * 196 * 4
-    assert p4.ksplit > 1 and p3.ksplit == 1 and p3.ws_bytes == 0
+    assert p4.ksplit > 1 and p4.split_tiles == 2 * 196 and p5.split_tiles == 4 * 25   # full split: every tile
     assert (p3.bm, p3.bn) == (128, 128) and (p4.bm, p4.bn) == (128, 256) and (p5.bm, p5.bn) == (128, 256)
+    # res3b: 3136 tiles over 4 x 256 slots -> only the 64 stragglers of the 4th round are split, 16 ways
+    assert (p3.split_tiles, p3.ksplit) == (64, 16) and p3.ws_bytes == 16 * 128 * 64 * 128 * 4
     with pytest.raises(hip.EcoError, match="workspace"):
         lib.conv_forward(hip.conv_geom(32, 512, 512, (4, 7, 7), (3, 3, 3), (1, 1, 1), (1, 1, 1), (4, 7, 7)), p5, 8, 8, 8,
                          _dummy_epilogue(), None)
+
+
+# Tail split-K: with a tiny "device" (num_cu) the many-tile path is reachable at emulator sizes.
+# (num_cu, conv cfg, expected split_tiles, expected ksplit)
+TAIL_SPLIT = [
+    (1, (1, 64, 64, (34, 34), (3, 3), (1, 1), (1, 1)), 1, 4),               # 5 tiles of 64x256 on 4 slots
+    (1, (1, 16, 128, (2, 16, 18), (3, 3, 3), (1, 1, 1), (1, 1, 1)), 1, 3),  # 5 tiles of 128x128, last one ragged
+    (2, (1, 16, 130, (2, 20, 20), (3, 3, 3), (1, 1, 1), (1, 1, 1)), 2, 3),  # 2 M-blocks x 4 N-blocks on 6 slots
+]
+
+
+@pytest.mark.parametrize("num_cu,cfg,split_tiles,ksplit", TAIL_SPLIT)
+@pytest.mark.parametrize("mode", ["plain", "fused"])
+def test_conv_tail_split(backend, num_cu, cfg, split_tiles, ksplit, mode):
+    plan = run_conv(backend, *cfg, mode=mode, seed=5, num_cu=num_cu)
+    assert (plan.split_tiles, plan.ksplit) == (split_tiles, ksplit) and plan.ws_bytes > 0
 
 
 def _dummy_epilogue():
