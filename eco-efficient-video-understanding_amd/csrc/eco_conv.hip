@@ -256,14 +256,15 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(
       const int oh = t % a.Ho, od = t / a.Ho;
       const int id0 = od * a.sd - a.pd, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
       in_base = (int)((long)img * a.img_stride_in + ((long)id0 * a.Hi + ih0) * a.Wi + iw0);
-      int tap = 0;
+      // tap-validity mask, built separably (kw + kh + kd steps instead of kd*kh*kw): bit
+      // ((z*kh + y)*kw + x) is set iff input (id0+z, ih0+y, iw0+x) lies inside the image.
+      unsigned long long mw = 0ull, mhw = 0ull;
+      for (int xx = 0; xx < a.kw; ++xx) mw |= (unsigned long long)((unsigned)(iw0 + xx) < (unsigned)a.Wi) << xx;
+      for (int y = 0; y < a.kh; ++y)
+        if ((unsigned)(ih0 + y) < (unsigned)a.Hi) mhw |= mw << (y * a.kw);
+      const int khw = a.kh * a.kw;
       for (int z = 0; z < a.kd; ++z)
-        for (int y = 0; y < a.kh; ++y)
-          for (int xx = 0; xx < a.kw; ++xx, ++tap) {
-            const bool ok = (unsigned)(id0 + z) < (unsigned)a.Di && (unsigned)(ih0 + y) < (unsigned)a.Hi &&
-                            (unsigned)(iw0 + xx) < (unsigned)a.Wi;
-            mask |= (unsigned long long)ok << tap;
-          }
+        if ((unsigned)(id0 + z) < (unsigned)a.Di) mask |= mhw << (z * khw);
     }
   }
 
