@@ -140,6 +140,8 @@ def main() -> None:
         roofline["traffic"] = None
     roofline.update({
         "kernel": dom_name, "launches_per_step": dom["launches"],
+        "timing": "HIP events on the launch stream around each eco_conv_forward call; for split-K plans that "
+                  "includes the conv_splitk_reduce_kernel launch that follows the main kernel",
         "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
         "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
         "kernel_share_of_step": round(dom["ms"] / total_ms, 4),

@@ -352,7 +352,7 @@ class Engine:
         self._keep.append(pg)
         lib = self.lib
         self._add(i, L.name, lambda s, pg=pg, x=x, y=y: lib.pool_forward(pg, x, y, s),
-                  {"kernel": "eco::pool_kernel", "flops": 0,
+                  {"kernel": hip.pool_kernel_name(pg), "flops": 0,
                    "bytes": 4 * (_prod(b) + _prod(L.top_shapes[0]))})
 
     def _emit_concat(self, i: int, L: LayerSpec, skip: Sequence[int]) -> None:

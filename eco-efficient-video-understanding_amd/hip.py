@@ -91,6 +91,23 @@ def conv_kernel_name(plan: ConvPlan) -> str:
     return f"eco::conv_mfma_kernel<{tm}, {tn}, {wm}, {wn}, {plan.kc}, {plan.mode}>"
 
 
+def pool_kernel_name(g: "PoolGeom") -> str:
+    """Device kernel eco_pool_forward picks for this geometry (mirrors the dispatch in csrc/eco_ops.hip;
+    the float4 fast paths additionally need 16-byte aligned pointers, which torch allocations are)."""
+    two_d = g.in_[0] == 1 and g.kernel[0] == 1 and g.stride[0] == 1 and g.pad[0] == 0
+    k, s, p = tuple(g.kernel[1:]), tuple(g.stride[1:]), tuple(g.pad[1:])
+    if all(g.kernel[i] == g.in_[i] and g.pad[i] == 0 and g.out[i] == 1 for i in range(3)) and g.method == POOL_AVE \
+            and g.in_[0] * g.in_[1] * g.in_[2] >= 32:
+        return "eco::global_avg_kernel"
+    if two_d and g.method == POOL_MAX and k == (3, 3) and s == (2, 2) and p == (0, 0) and g.in_[2] % 4 == 0 \
+            and g.out[2] % 4 == 0 and 2 * (g.out[2] - 1) + 2 <= g.in_[2]:
+        return "eco::maxpool2d_k3s2_kernel"
+    if two_d and g.method == POOL_AVE and k == (3, 3) and s == (1, 1) and p == (1, 1) and g.in_[2] % 4 == 0 \
+            and g.in_[1] >= 2 and g.in_[2] >= 4:
+        return "eco::avgpool2d_k3s1p1_kernel"
+    return "eco::pool_kernel"
+
+
 def plain_view(ptr: int, channels: int, spatial: int) -> View:
     """Dense [N, C, S] tensor."""
     return View(ptr, int(channels) * int(spatial), 0, int(spatial), 1)
