@@ -156,22 +156,58 @@ __device__ __forceinline__ void conv_store_partial(const ConvKernelArgs& a, f32x
 }
 
 // Second pass of split-K: sum the slices in a fixed order (deterministic) and apply the epilogue.
+// VEC = 4 handles four consecutive positions per thread with 16-byte accesses (the launcher checks that
+// positions n..n+3 are contiguous in every view: s_out, the region bounds and all strides are multiples
+// of 4 and the pointers are 16-byte aligned); VEC = 1 is the general form.  HBM-bound: S slices read +
+// outputs written once.
+template <int VEC>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKernelArgs a) {
   const int nsplit_pos = a.ntot - a.n_split0;
   const long total = (long)a.cout * nsplit_pos;
   const long slice_stride = total;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+  for (long idx = ((long)blockIdx.x * 256 + threadIdx.x) * VEC; idx < total; idx += (long)gridDim.x * 256 * VEC) {
     const int ch = (int)(idx / nsplit_pos), n = a.n_split0 + (int)(idx - (long)ch * nsplit_pos);
-    float v = 0.0f;
-    for (int sidx = 0; sidx < a.ksplit; ++sidx) v += ld((const float*)a.ws + sidx * slice_stride + idx);
+    float v[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = 0.0f;
+    for (int sidx = 0; sidx < a.ksplit; ++sidx) {
+      const float* p = (const float*)a.ws + sidx * slice_stride + idx;
+      if (VEC == 4) {
+        const float4 q = ld((const float4*)p);
+        v[0] += q.x; v[1 % VEC] += q.y; v[2 % VEC] += q.z; v[3 % VEC] += q.w;
+      } else {
+        v[0] += ld(p);
+      }
+    }
     const int img = n / a.s_out, sp = n - img * a.s_out;
-    if (a.bias) v += ld(a.bias + ch);
-    if (a.residual.ptr) v += ld((const float*)a.residual.ptr + view_base(a.residual, img, sp) + (long)ch * a.residual.stride_c);
-    if (a.raw.ptr) st(a.raw.ptr + view_base(a.raw, img, sp) + (long)ch * a.raw.stride_c, v);
+    const float b = a.bias ? ld(a.bias + ch) : 0.0f;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] += b;
+    if (a.residual.ptr) {
+      const float* r = (const float*)a.residual.ptr + view_base(a.residual, img, sp) + (long)ch * a.residual.stride_c;
+      if (VEC == 4) {
+        const float4 q = ld((const float4*)r);
+        v[0] += q.x; v[1 % VEC] += q.y; v[2 % VEC] += q.z; v[3 % VEC] += q.w;
+      } else {
+        v[0] += ld(r);
+      }
+    }
+    if (a.raw.ptr) {
+      float* o = a.raw.ptr + view_base(a.raw, img, sp) + (long)ch * a.raw.stride_c;
+      if (VEC == 4) st((float4*)o, make_float4(v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]));
+      else st(o, v[0]);
+    }
     if (a.act.ptr) {
-      float y = a.bn_scale ? v * ld(a.bn_scale + ch) + ld(a.bn_shift + ch) : v;
-      if (a.relu) y = fmaxf(y, 0.0f);
-      st(a.act.ptr + view_base(a.act, img, sp) + (long)ch * a.act.stride_c, y);
+      const float sc = a.bn_scale ? ld(a.bn_scale + ch) : 1.0f, sh = a.bn_scale ? ld(a.bn_shift + ch) : 0.0f;
+      float y[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        y[e] = v[e] * sc + sh;
+        if (a.relu) y[e] = fmaxf(y[e], 0.0f);
+      }
+      float* o = a.act.ptr + view_base(a.act, img, sp) + (long)ch * a.act.stride_c;
+      if (VEC == 4) st((float4*)o, make_float4(y[0], y[1 % VEC], y[2 % VEC], y[3 % VEC]));
+      else st(o, y[0]);
     }
   }
 }
@@ -388,9 +424,13 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) {
       if (kk + 1 < KSTEPS) read_frags(buf, kk + 1, (kk + 1) & 1);
+      // all of the next stage's loads go out in the first half of this stage (2*BPS gathers per step),
+      // so even the last one has half a stage of MFMAs to land before store_stage needs it
       if (kk < A_ITERS) load_a(kk);
+      if (kk < KSTEPS / 2) {
 #pragma unroll
-      for (int q = 0; q < BPS; ++q) load_b(kk * BPS + q);
+        for (int q = 0; q < 2 * BPS; ++q) load_b(kk * 2 * BPS + q);
+      }
       mfma_step(kk & 1);
       sched_fence();
     }
@@ -643,8 +683,16 @@ extern "C" int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* pla
     default: return fail(ECO_ERR_INVALID, "conv: unsupported block tile bm=%d", plan->bm);
   }
   if (rc != ECO_OK || a.ksplit == 1) return rc;
-  long rblocks = ceil_div((long)a.cout * (a.ntot - a.n_split0), 256);
+  auto vec_ok = [](const eco_view& v) {
+    return !v.ptr || (((uintptr_t)v.ptr & 15) == 0 && v.stride_b % 4 == 0 && v.stride_t % 4 == 0 && v.stride_c % 4 == 0);
+  };
+  const bool vec4 = a.s_out % 4 == 0 && a.n_split0 % 4 == 0 && (a.ntot - a.n_split0) % 4 == 0 &&
+                    ((uintptr_t)a.ws & 15) == 0 && vec_ok(a.residual) && vec_ok(a.raw) && vec_ok(a.act);
+  long rblocks = ceil_div((long)a.cout * (a.ntot - a.n_split0), 256L * (vec4 ? 4 : 1));
   if (rblocks > 262144) rblocks = 262144;
-  hipLaunchKernelGGL((conv_splitk_reduce_kernel), dim3((unsigned)rblocks), dim3(256), 0, s, a);
+  if (vec4)
+    hipLaunchKernelGGL((conv_splitk_reduce_kernel<4>), dim3((unsigned)rblocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_splitk_reduce_kernel<1>), dim3((unsigned)rblocks), dim3(256), 0, s, a);
   return check_launch("eco_conv_forward(split-K reduce)");
 }
