@@ -289,13 +289,32 @@ class Net:
         self._forward(start_ind, end_ind)
         return {out: self.blobs[out].data for out in outputs}
 
-    def forward_device(self):
+    def forward_device(self, graph: bool = False):
         """Run the whole net on whatever is resident in HBM; returns nothing and does not
-        synchronise (extension used by bench.py / the multi-GPU driver)."""
-        self._engine.forward()
+        synchronise (extension used by bench.py / the multi-GPU driver).  ``graph=True`` replays the
+        launch list as one hipGraph (captured on first use; re-captured after reshape / parameter
+        edits) -- worth it when the step is launch-bound, e.g. single-clip online recognition."""
+        if graph:
+            self._graph_replay()
+        else:
+            self._engine.forward()
         for name, b in self.blobs.items():
             if name in self._engine.tensors:
                 b._head = _HEAD_DEVICE
+
+    def _graph_replay(self) -> None:
+        import torch
+        eng = self._engine
+        key = (id(eng.ops), len(eng.ops))
+        if getattr(self, "_graph_key", None) != key or eng._dirty_params:
+            eng._sync_params()                       # uploads happen outside the capture
+            eng.forward()                            # warm-up on the normal stream
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):                # capture stream becomes torch's current stream
+                eng.forward()
+            self._graph, self._graph_key = g, key
+        self._graph.replay()
 
     def op_labels(self) -> List[str]:
         return self._engine.op_labels()

@@ -90,3 +90,25 @@ def test_eco_lite_n32_shapes():
     spec1 = NetSpec.from_prototxt(models.eco_lite_deploy(num_segments=32, num_clips=1))
     ref = orc.forward(spec1, params, {"data": x[:32]})["fc8"]
     assert relerr(out[:1], ref) < TOL
+
+
+def test_hipgraph_replay_matches_eager():
+    """Net.forward_device(graph=True): the launch list replayed as one hipGraph gives bit-identical logits,
+    also after a parameter edit (re-capture) -- the graph path is plumbing, not a different computation."""
+    import torch
+    proto = models.eco_lite_deploy(num_segments=4, num_clips=1)
+    spec = NetSpec.from_prototxt(proto)
+    params = fillers.synthetic_params(spec)
+    net = Net(proto, params=params)
+    net.blobs["data"].tensor.copy_(torch.from_numpy(fillers.synthetic_frames(4)).cuda())
+    net.forward_device()
+    torch.cuda.synchronize()
+    eager = net.blobs["fc8"].tensor.clone()
+    for _ in range(3):
+        net.forward_device(graph=True)
+    torch.cuda.synchronize()
+    assert torch.equal(net.blobs["fc8"].tensor, eager)
+    net.params["fc8"][1].data[...] += 2.0
+    net.forward_device(graph=True)
+    torch.cuda.synchronize()
+    assert torch.allclose(net.blobs["fc8"].tensor, eager + 2.0, rtol=1e-5, atol=1e-3)
