@@ -64,66 +64,93 @@ __global__ __launch_bounds__(256) void pool_kernel(const PoolArgs a) {
   }
 }
 
-// 2-D MAX 3x3 stride 2, no padding (pool1 / pool2 / the ECO-Full stride-2 pools): one thread per four
-// consecutive outputs of a row.  It reads 8 (+1) consecutive input floats of each of the three rows as
-// two float4 (+1 scalar) and writes one float4 -> every global access is 16 B per lane and contiguous
-// across lanes.  Ceil-mode clipping (pooling_layer.cpp:131-147,199-225): the 9th column and the 3rd
-// row simply do not exist at the right / bottom edge.
+// VEC consecutive floats as one 16- or 8-byte access.
+template <int VEC>
+__device__ __forceinline__ void ld_vec(const float* p, float (&v)[VEC]) {
+  if (VEC == 4) {
+    const float4 q = ld((const float4*)p);
+    v[0] = q.x; v[1 % VEC] = q.y; v[2 % VEC] = q.z; v[3 % VEC] = q.w;
+  } else {
+    const float2 q = ld((const float2*)p);
+    v[0] = q.x; v[1 % VEC] = q.y;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void st_vec(float* p, const float (&v)[VEC]) {
+  if (VEC == 4) st((float4*)p, make_float4(v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]));
+  else st((float2*)p, make_float2(v[0], v[1 % VEC]));
+}
+
+// 2-D MAX 3x3 stride 2, no padding (pool1 / pool2 / the ECO-Full stride-2 pools): one thread per VEC
+// (4 or 2) consecutive outputs of a row.  It reads 2*VEC (+1) consecutive input floats of each of the
+// three rows as two vector loads (+1 scalar) and writes one vector -> global accesses are 16 (8) bytes
+// per lane and contiguous across lanes.  Ceil-mode clipping (pooling_layer.cpp:131-147,199-225): the
+// last column and the 3rd row simply do not exist at the right / bottom edge.
+template <int VEC>
 __global__ __launch_bounds__(256) void maxpool2d_k3s2_kernel(const float* x, float* y, long planes, int Hi, int Wi,
                                                              int Ho, int Wo) {
-  const int wq = Wo / 4;
+  const int wq = Wo / VEC;
   const long total = planes * Ho * wq;
   for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
     const int q = (int)(i % wq);
     const long t = i / wq;
     const int oh = (int)(t % Ho);
     const long pl = t / Ho;
-    const float* xp = x + pl * Hi * Wi + (long)(2 * oh) * Wi + 8 * q;
-    const bool has9 = 8 * q + 8 < Wi;
-    float m[4] = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+    const float* xp = x + pl * Hi * Wi + (long)(2 * oh) * Wi + 2 * VEC * q;
+    const bool has_last = 2 * VEC * q + 2 * VEC < Wi;
+    float m[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) m[e] = -FLT_MAX;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       if (2 * oh + r >= Hi) break;
-      const float4 a = ld((const float4*)(xp + (long)r * Wi));
-      const float4 b = ld((const float4*)(xp + (long)r * Wi + 4));
-      const float c = has9 ? ld(xp + (long)r * Wi + 8) : -FLT_MAX;
-      m[0] = fmaxf(m[0], fmaxf(fmaxf(a.x, a.y), a.z));
-      m[1] = fmaxf(m[1], fmaxf(fmaxf(a.z, a.w), b.x));
-      m[2] = fmaxf(m[2], fmaxf(fmaxf(b.x, b.y), b.z));
-      m[3] = fmaxf(m[3], fmaxf(fmaxf(b.z, b.w), c));
+      float in[2 * VEC + 1], lo[VEC], hi[VEC];
+      ld_vec<VEC>(xp + (long)r * Wi, lo);
+      ld_vec<VEC>(xp + (long)r * Wi + VEC, hi);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { in[e] = lo[e]; in[VEC + e] = hi[e]; }
+      in[2 * VEC] = has_last ? ld(xp + (long)r * Wi + 2 * VEC) : -FLT_MAX;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) m[e] = fmaxf(m[e], fmaxf(fmaxf(in[2 * e], in[2 * e + 1]), in[2 * e + 2]));
     }
-    st((float4*)(y + (pl * Ho + oh) * Wo + 4 * q), make_float4(m[0], m[1], m[2], m[3]));
+    st_vec<VEC>(y + (pl * Ho + oh) * Wo + VEC * q, m);
   }
 }
 
-// 2-D AVE 3x3 stride 1 pad 1 (inception *_pool): four consecutive outputs per thread; per row one
-// float4 plus the two neighbours.  Zero padding, divisor 9 everywhere (the reference's window size
+// 2-D AVE 3x3 stride 1 pad 1 (inception *_pool): VEC consecutive outputs per thread; per row one vector
+// load plus the two neighbours.  Zero padding, divisor 9 everywhere (the reference's window size
 // including padding, pooling_layer.cpp:247-262, equals 9 for every position of this geometry).
+template <int VEC>
 __global__ __launch_bounds__(256) void avgpool2d_k3s1p1_kernel(const float* x, float* y, long planes, int H, int W) {
-  const int wq = W / 4;
+  const int wq = W / VEC;
   const long total = planes * H * wq;
   for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
     const int q = (int)(i % wq);
     const long t = i / wq;
     const int oh = (int)(t % H);
     const long pl = t / H;
-    const float* xp = x + pl * H * W + 4 * q;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float* xp = x + pl * H * W + VEC * q;
+    float sum[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) sum[e] = 0.0f;
 #pragma unroll
     for (int r = -1; r <= 1; ++r) {
       const int h = oh + r;
       if (h < 0 || h >= H) continue;
       const float* row = xp + (long)h * W;
-      const float4 a = ld((const float4*)row);
-      const float l = (q > 0) ? ld(row - 1) : 0.0f;
-      const float rr = (4 * q + 4 < W) ? ld(row + 4) : 0.0f;
-      s0 += l + a.x + a.y;
-      s1 += a.x + a.y + a.z;
-      s2 += a.y + a.z + a.w;
-      s3 += a.z + a.w + rr;
+      float in[VEC + 2], mid[VEC];
+      ld_vec<VEC>(row, mid);
+      in[0] = (q > 0) ? ld(row - 1) : 0.0f;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) in[1 + e] = mid[e];
+      in[VEC + 1] = (VEC * q + VEC < W) ? ld(row + VEC) : 0.0f;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) sum[e] += in[e] + in[e + 1] + in[e + 2];
     }
     const float inv = 1.0f / 9.0f;
-    st((float4*)(y + (pl * H + oh) * W + 4 * q), make_float4(s0 * inv, s1 * inv, s2 * inv, s3 * inv));
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) sum[e] *= inv;
+    st_vec<VEC>(y + (pl * H + oh) * W + VEC * q, sum);
   }
 }
 
@@ -335,18 +362,31 @@ extern "C" int eco_pool_forward(const eco_pool_geom* g, const float* x, float* y
   const bool two_d = g->in[0] == 1 && g->kernel[0] == 1 && g->stride[0] == 1 && g->pad[0] == 0;
   const bool aligned = (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
   if (two_d && aligned && g->method == ECO_POOL_MAX && g->kernel[1] == 3 && g->kernel[2] == 3 && g->stride[1] == 2 &&
-      g->stride[2] == 2 && g->pad[1] == 0 && g->pad[2] == 0 && g->in[2] % 4 == 0 && g->out[2] % 4 == 0 &&
+      g->stride[2] == 2 && g->pad[1] == 0 && g->pad[2] == 0 && g->in[2] % 4 == 0 && g->out[2] % 2 == 0 &&
       2 * (g->out[2] - 1) + 2 <= g->in[2]) {
-    const long total = rows * g->out[1] * (g->out[2] / 4);
-    hipLaunchKernelGGL((maxpool2d_k3s2_kernel), dim3(grid_for(total)), dim3(kThreads), 0, s, x, y, rows, g->in[1],
-                       g->in[2], g->out[1], g->out[2]);
+    // rows are 16-byte aligned (Wi % 4 == 0); 4 outputs per thread when Wo % 4 == 0, else 2 (e.g. 28 -> 14)
+    if (g->out[2] % 4 == 0) {
+      const long total = rows * g->out[1] * (g->out[2] / 4);
+      hipLaunchKernelGGL((maxpool2d_k3s2_kernel<4>), dim3(grid_for(total)), dim3(kThreads), 0, s, x, y, rows, g->in[1],
+                         g->in[2], g->out[1], g->out[2]);
+    } else {
+      const long total = rows * g->out[1] * (g->out[2] / 2);
+      hipLaunchKernelGGL((maxpool2d_k3s2_kernel<2>), dim3(grid_for(total)), dim3(kThreads), 0, s, x, y, rows, g->in[1],
+                         g->in[2], g->out[1], g->out[2]);
+    }
     return check_launch("eco_pool_forward(max 3x3 s2)");
   }
   if (two_d && aligned && g->method == ECO_POOL_AVE && g->kernel[1] == 3 && g->kernel[2] == 3 && g->stride[1] == 1 &&
-      g->stride[2] == 1 && g->pad[1] == 1 && g->pad[2] == 1 && g->in[2] % 4 == 0 && g->in[1] >= 2 && g->in[2] >= 4) {
-    const long total = rows * g->in[1] * (g->in[2] / 4);
-    hipLaunchKernelGGL((avgpool2d_k3s1p1_kernel), dim3(grid_for(total)), dim3(kThreads), 0, s, x, y, rows, g->in[1],
-                       g->in[2]);
+      g->stride[2] == 1 && g->pad[1] == 1 && g->pad[2] == 1 && g->in[2] % 2 == 0 && g->in[1] >= 2 && g->in[2] >= 4) {
+    if (g->in[2] % 4 == 0) {
+      const long total = rows * g->in[1] * (g->in[2] / 4);
+      hipLaunchKernelGGL((avgpool2d_k3s1p1_kernel<4>), dim3(grid_for(total)), dim3(kThreads), 0, s, x, y, rows,
+                         g->in[1], g->in[2]);
+    } else {  // e.g. 14x14: 8-byte accesses
+      const long total = rows * g->in[1] * (g->in[2] / 2);
+      hipLaunchKernelGGL((avgpool2d_k3s1p1_kernel<2>), dim3(grid_for(total)), dim3(kThreads), 0, s, x, y, rows,
+                         g->in[1], g->in[2]);
+    }
     return check_launch("eco_pool_forward(ave 3x3 s1 p1)");
   }
   PoolArgs a;

@@ -100,11 +100,11 @@ def pool_kernel_name(g: "PoolGeom") -> str:
             and g.in_[0] * g.in_[1] * g.in_[2] >= 32:
         return "eco::global_avg_kernel"
     if two_d and g.method == POOL_MAX and k == (3, 3) and s == (2, 2) and p == (0, 0) and g.in_[2] % 4 == 0 \
-            and g.out[2] % 4 == 0 and 2 * (g.out[2] - 1) + 2 <= g.in_[2]:
-        return "eco::maxpool2d_k3s2_kernel"
-    if two_d and g.method == POOL_AVE and k == (3, 3) and s == (1, 1) and p == (1, 1) and g.in_[2] % 4 == 0 \
+            and g.out[2] % 2 == 0 and 2 * (g.out[2] - 1) + 2 <= g.in_[2]:
+        return "eco::maxpool2d_k3s2_kernel<%d>" % (4 if g.out[2] % 4 == 0 else 2)
+    if two_d and g.method == POOL_AVE and k == (3, 3) and s == (1, 1) and p == (1, 1) and g.in_[2] % 2 == 0 \
             and g.in_[1] >= 2 and g.in_[2] >= 4:
-        return "eco::avgpool2d_k3s1p1_kernel"
+        return "eco::avgpool2d_k3s1p1_kernel<%d>" % (4 if g.in_[2] % 4 == 0 else 2)
     return "eco::pool_kernel"
 
 

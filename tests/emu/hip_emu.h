@@ -35,6 +35,10 @@ struct float4 {
   float x, y, z, w;
 };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+struct float2 {
+  float x, y;
+};
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
 typedef void* hipStream_t;
 typedef int hipError_t;

@@ -220,6 +220,9 @@ POOLS = [
     ("AVE", (2, 3), (6, 8), (3, 3), (1, 1), (1, 1)),
     ("AVE", (1, 2), (28, 28), (3, 3), (1, 1), (1, 1)),          # inception_3a_pool geometry
     ("AVE", (1, 2), (5, 12), (3, 3), (1, 1), (1, 1)),
+    ("AVE", (2, 3), (14, 14), (3, 3), (1, 1), (1, 1)),          # ECO-Full inception_4x_pool: float2 path
+    ("AVE", (1, 2), (5, 6), (3, 3), (1, 1), (1, 1)),            # W % 4 == 2
+    ("MAX", (2, 2), (7, 12), (3, 3), (2, 2), (0, 0)),           # Wi % 4 == 0, Wo = 6: 2 outputs per thread
 ]
 
 
