@@ -453,6 +453,235 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(
     conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
 }
 
+// ------------------------------------------------------------------------------------------
+// "Span" kernel (ECO_CONV_MODE_SPAN): stride-1, same-size kd x 3 x 3 convolutions with cin % 16 == 0 --
+// every res3/res4/res5 stride-1 conv, conv2_3x3 and all inception 3x3 convs (87 % of ECO-Lite's flops).
+//
+// For such a conv the im2col row of tap (z, y, x) of channel c is the channel's *own flattened plane
+// sequence shifted by a constant*:  X_c[v + (z-kd/2)*H*W + (y-1)*W + (x-1)]  (v = flattened (img, d, h, w)
+// position), masked where the shifted tap leaves the image.  So instead of gathering 16 x BN elements for
+// each of the 9 (y, x) taps, a workgroup stages once per (16-channel tile, z) group the *span*
+//   Bsp[ci][e] = X_{cc*16+ci}[n0 - (W+1) + (z-kd/2)*H*W + e],   e in [0, BN + 2*(W+1))
+// in LDS and the MFMA B-fragments of the group's 9 stages are read from it at offset y*W + x, with one
+// select per fragment for the zero padding.  Global gather instructions and LDS stores for the B operand
+// drop ~6-8x; the weight operand, the stage / k-pair structure, split-K and the epilogue are those of
+// conv_mfma_kernel (packed-weight order is CTAP's: k' = ((cc*kd + z)*9 + y*3 + x)*16 + ci).
+//
+// The span of the next group is fetched two channels per stage (one coalesced dword load per 256
+// consecutive span elements) under the MFMAs of the current group and stored to the other span buffer at
+// the end of each stage; weights are double-buffered per stage as before.  LDS is dynamic
+// (2*16*BM + 2*16*span_len floats: 40 KB for res3, 52 KB for 28x28 inception convs, 59 KB for conv2_3x3).
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : 2)) void conv_span_kernel(const ConvKernelArgs a) {
+  constexpr int KC = 16, KSTEPS = 8, T2 = 9;
+  constexpr int BM = 32 * TM * WM;
+  constexpr int BN = 32 * TN * WN;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int A_F4 = KC * BM / 4;
+  constexpr int A_ITERS = (A_F4 + 255) / 256;
+  constexpr int NCOL = 2;  // span columns per thread: span_len <= 512
+
+  ECO_DYNAMIC_LDS(lds);
+  const int halo = a.Wi + 1;
+  const int span_len = BN + 2 * halo;
+  float* As = lds;                       // [2][KC][BM]
+  float* Bsp = lds + 2 * KC * BM;        // [2][KC][span_len]
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  int tile, slice, nslices;
+  if ((int)blockIdx.x < a.n_main) {
+    tile = xcd_remap((int)blockIdx.x, a.n_main);
+    slice = 0;
+    nslices = 1;
+  } else {
+    const int lid = xcd_remap((int)blockIdx.x - a.n_main, a.n_split * a.ksplit);
+    slice = lid / a.n_split;
+    tile = a.n_main + (lid - slice * a.n_split);
+    nslices = a.ksplit;
+  }
+  const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
+  const int m0 = mblk * BM, n0 = nblk * BN;
+  const int ngroups_all = a.kpad / (KC * T2);  // (cin/16) * kd; split-K slices are whole groups
+  const int g_begin = (int)((long)slice * ngroups_all / nslices);
+  const int g_end = (int)((long)(slice + 1) * ngroups_all / nslices);
+  const int hw = a.Hi * a.Wi;
+  const int S = a.s_in;  // == s_out
+
+  // ---- zero-padding masks of this lane's TN fragment positions: bit (z*9 + y*3 + x) ----
+  unsigned fmask[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    fmask[j] = 0u;
+    const int n = n0 + (wn * TN + j) * 32 + l31;
+    if (n < a.ntot) {
+      const int sp = n % S;
+      const int w = sp % a.Wi, t = sp / a.Wi;
+      const int h = t % a.Hi, d = t / a.Hi;
+      unsigned mw = 0u, mhw = 0u;
+      for (int xx = 0; xx < 3; ++xx) mw |= (unsigned)((unsigned)(w - 1 + xx) < (unsigned)a.Wi) << xx;
+      for (int y = 0; y < 3; ++y)
+        if ((unsigned)(h - 1 + y) < (unsigned)a.Hi) mhw |= mw << (3 * y);
+      for (int z = 0; z < a.kd; ++z)
+        if ((unsigned)(d - a.pd + z) < (unsigned)a.Di) fmask[j] |= mhw << (9 * z);
+    }
+  }
+
+  // ---- span columns of this thread: element e = tid + q*256 of every channel row ----
+  int col_base[NCOL], col_sp[NCOL];  // offset of (img, channel 0, sp) / sp, for the centre depth tap
+  bool col_in[NCOL];
+#pragma unroll
+  for (int q = 0; q < NCOL; ++q) {
+    const int e = tid + q * 256;
+    col_in[q] = e < span_len;
+    const int v = n0 - halo + e;
+    col_base[q] = 0;
+    col_sp[q] = -(1 << 29);  // never inside [0, S) whatever depth shift is added
+    if (col_in[q] && v >= 0 && v < a.ntot) {
+      const int img = v / S, sp = v - img * S;
+      col_base[q] = (int)((long)img * a.img_stride_in + sp);
+      col_sp[q] = sp;
+    }
+  }
+
+  // uniform description of the group being loaded
+  auto group_xoff = [&](int g, int& shift) -> int {  // the whole input fits int32 offsets (checked by the host)
+    const int cc = g / a.kd, z = g - cc * a.kd;
+    shift = (z - a.pd) * hw;
+    return cc * KC * S + shift;
+  };
+  // The zero fill of out-of-image columns is applied when the value is *stored* to LDS, so that the wait for
+  // the global load lands there and not right behind the load.
+  auto span_ok = [&](int shift, int q) -> bool { return col_in[q] && (unsigned)(col_sp[q] + shift) < (unsigned)S; };
+  auto span_load = [&](int xoff, bool ok, int ci, int q) -> float {
+    return ld(a.x + (ok ? xoff + ci * S + col_base[q] : 0));
+  };
+  // columns past the end of the span go to one dummy float behind the buffers: no divergent branch in the loop
+  const int dummy = 2 * KC * span_len;
+  auto span_store = [&](int sbuf, int ci, int q, bool ok, float v) {
+    Bsp[col_in[q] ? (sbuf * KC + ci) * span_len + tid + q * 256 : dummy] = ok ? v : 0.0f;
+  };
+
+  const float* l_wp = a.wp + m0 + (long)g_begin * T2 * KC * a.mpad;  // packed-weight rows of the stage being loaded
+  float4 areg[A_ITERS];
+  auto load_a = [&](int i) {
+    const int idx = tid + i * 256;
+    if (A_F4 % 256 == 0 || idx < A_F4) {
+      const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+      areg[i] = ld((const float4*)(l_wp + (long)row * a.mpad + c4 * 4));
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int idx = tid + i * 256;
+      if (A_F4 % 256 == 0 || idx < A_F4) *(float4*)&As[(long)buf * KC * BM + (long)idx * 4] = areg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  float af[2][TM], bf[2][TN];
+  bool okj[TN];        // this stage's tap is inside the image at fragment position j
+  int frag_off = 0;    // y*W + x of this stage's tap
+  auto read_frags = [&](int buf, int sbuf, int kk, int slot) {
+    const float* ap = As + ((long)buf * KC + 2 * kk + half) * BM + wm * TM * 32 + l31;
+    const float* bp = Bsp + ((long)sbuf * KC + 2 * kk + half) * span_len + wn * TN * 32 + l31 + frag_off;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[slot][i] = ap[i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[slot][j] = bp[j * 32];
+  };
+  auto mfma_step = [&](int slot) {  // the zero-padding select sits here, a scheduling region after the LDS read
+    float b[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[j] = okj[j] ? bf[slot][j] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(af[slot][i], b[j], acc[i][j]);
+  };
+
+  // ---- prologue: whole span of the first group, weights of its first stage ----
+  {
+    int shift;
+    const int xoff = group_xoff(g_begin, shift);
+    bool ok[NCOL];
+#pragma unroll
+    for (int q = 0; q < NCOL; ++q) ok[q] = span_ok(shift, q);
+#pragma unroll 4
+    for (int ci = 0; ci < KC; ++ci)
+#pragma unroll
+      for (int q = 0; q < NCOL; ++q) span_store(0, ci, q, ok[q], span_load(xoff, ok[q], ci, q));
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) load_a(i);
+    store_a(0);
+  }
+  __syncthreads();
+
+  int stage = 0;  // stages done in this slice (parity selects the weight buffer)
+#pragma unroll 1
+  for (int g = g_begin; g < g_end; ++g) {
+    const int sbuf = (g - g_begin) & 1;
+    const int z = g % a.kd;
+    const bool next_group = g + 1 < g_end;
+    int nshift = 0;
+    const int nxoff = next_group ? group_xoff(g + 1, nshift) : 0;
+    bool nok[NCOL];
+#pragma unroll
+    for (int q = 0; q < NCOL; ++q) nok[q] = next_group && span_ok(nshift, q);
+#pragma unroll 1
+    for (int t2 = 0; t2 < T2; ++t2, ++stage) {
+      // The loop body is branch-free: the last stage re-loads its own weights into the idle buffer, stage 8
+      // of a group re-stages channels 14/15, and without a next group the span loads hit address 0 and land
+      // in the idle span buffer.  Conditional loads would split the body into basic blocks and make the
+      // compiler drain vmcnt at every join.
+      const int buf = stage & 1;
+      const bool last_stage = !next_group && t2 == T2 - 1;
+      const int tap = z * T2 + t2;
+      const int y = t2 / 3, xx = t2 - 3 * y;
+      frag_off = y * a.Wi + xx;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) okj[j] = (fmask[j] >> tap) & 1u;
+      l_wp += last_stage ? 0l : (long)KC * a.mpad;  // weights of the next stage
+      const int ci0 = t2 < KC / 2 ? 2 * t2 : KC - 2;  // channels ci0, ci0+1 of the next group's span
+      float sreg[2][NCOL];
+      read_frags(buf, sbuf, 0, 0);
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        if (kk + 1 < KSTEPS) read_frags(buf, sbuf, kk + 1, (kk + 1) & 1);
+        if (kk < A_ITERS) load_a(kk);
+        if (kk < 2) {
+#pragma unroll
+          for (int q = 0; q < NCOL; ++q) sreg[kk][q] = span_load(nxoff, nok[q], ci0 + kk, q);
+        }
+        mfma_step(kk & 1);
+        sched_fence();
+      }
+      store_a(buf ^ 1);
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int q = 0; q < NCOL; ++q) span_store(sbuf ^ 1, ci0 + c2, q, nok[q], sreg[c2][q]);
+      __syncthreads();
+    }
+  }
+  if (nslices > 1)
+    conv_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+  else
+    conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+}
+
 static int validate_geom(const eco_conv_geom* g) {
   ECO_REQUIRE(g != nullptr, "conv: null geometry");
   ECO_REQUIRE(g->n > 0 && g->cin > 0 && g->cout > 0, "conv: n/cin/cout must be positive (n=%d cin=%d cout=%d)",
@@ -512,6 +741,14 @@ extern "C" int eco_conv_plan_create_ex(const eco_conv_geom* g, int32_t num_cu, e
   }
   plan->kc = 16;
   plan->mode = (g->cin % plan->kc == 0) ? ECO_CONV_MODE_CTAP : ECO_CONV_MODE_TABLE;
+  {
+    // stride-1, same-size (kd) x 3 x 3 convolutions stage input *spans* instead of per-tap gathers
+    bool span = plan->mode == ECO_CONV_MODE_CTAP && g->kernel[1] == 3 && g->kernel[2] == 3 && g->pad[1] == 1 &&
+                g->pad[2] == 1 && (g->kernel[0] == 1 || g->kernel[0] == 3) && g->pad[0] == g->kernel[0] / 2;
+    for (int i = 0; i < 3; ++i) span = span && g->stride[i] == 1 && g->out[i] == g->in[i];
+    span = span && plan->bn + 2 * (g->in[2] + 1) <= 512;  // two span columns per thread
+    if (span) plan->mode = ECO_CONV_MODE_SPAN;
+  }
   plan->k = g->cin * g->kernel[0] * g->kernel[1] * g->kernel[2];
   plan->kpad = (int)(ceil_div(plan->k, plan->kc) * plan->kc);
   plan->mpad = (int)(ceil_div(g->cout, 128) * 128);
@@ -536,13 +773,14 @@ extern "C" int eco_conv_plan_create_ex(const eco_conv_geom* g, int32_t num_cu, e
     const long mblocks = ceil_div(g->cout, bm);
     const long tiles = mblocks * ceil_div(ntot, plan->bn);
     const int nstages = plan->kpad / plan->kc;
+    const int ngroups = plan->mode == ECO_CONV_MODE_SPAN ? nstages / 9 : nstages;  // split-K granularity
     const int occ = (bm == 128 && plan->bn == 256) ? 2 : (bm == 96 ? 3 : 4);  // resident workgroups per CU
     const long slots = (long)num_cu * occ;
     if (tiles < slots) {
       const double t_flops = 2.0 * ntot * g->cout * plan->k / 100e12;
       double best = 1e30;
       for (int sp = 1; sp <= 16; ++sp) {
-        if (sp > 1 && nstages / sp < 8) break;
+        if (sp > 1 && (nstages / sp < 8 || sp > ngroups)) break;
         const double per_cu = (double)tiles * sp / num_cu;
         const double eff = per_cu / (double)ceil_div(tiles * sp, num_cu);
         const double t = t_flops / eff + (sp > 1 ? 2.0 * sp * ntot * g->cout * 4.0 / 4e12 + 5e-6 : 0.0);
@@ -556,6 +794,7 @@ extern "C" int eco_conv_plan_create_ex(const eco_conv_geom* g, int32_t num_cu, e
         long sp = slots / rem;
         if (sp > 16) sp = 16;
         if (sp > nstages / 8) sp = nstages / 8;
+        if (sp > ngroups) sp = ngroups;
         if (sp >= 2 && rem < tiles) { plan->ksplit = (int)sp; plan->split_tiles = (int)rem; }
       }
     }
@@ -579,7 +818,8 @@ extern "C" int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan
   const int taps = g->kernel[0] * g->kernel[1] * g->kernel[2];
   const int K = g->cin * taps;
   ECO_REQUIRE(plan->k == K && plan->kpad >= K && plan->mpad >= g->cout, "conv pack: plan does not match geometry");
-  ECO_REQUIRE(plan->mode == ECO_CONV_MODE_TABLE || (plan->mode == ECO_CONV_MODE_CTAP && g->cin % plan->kc == 0),
+  ECO_REQUIRE(plan->mode == ECO_CONV_MODE_TABLE ||
+                  ((plan->mode == ECO_CONV_MODE_CTAP || plan->mode == ECO_CONV_MODE_SPAN) && g->cin % plan->kc == 0),
               "conv pack: bad plan mode");
   const long s_in = (long)g->in[0] * g->in[1] * g->in[2];
   memset(wp, 0, sizeof(float) * (size_t)plan->wp_elems);
@@ -589,7 +829,7 @@ extern "C" int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan
       continue;
     }
     int c, tap;
-    if (plan->mode == ECO_CONV_MODE_CTAP) {  // k' = (cc*taps + tap)*kc + ci, channel c = cc*kc + ci
+    if (plan->mode != ECO_CONV_MODE_TABLE) {  // CTAP / SPAN: k' = (cc*taps + tap)*kc + ci, channel c = cc*kc + ci
       const int ci = k % plan->kc, rest = k / plan->kc;
       tap = rest % taps;
       c = (rest / taps) * plan->kc + ci;
@@ -610,6 +850,12 @@ extern "C" int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan
 template <int TM, int TN, int WM, int WN, int KC>
 static int launch_conv(const ConvKernelArgs& a, int mode, hipStream_t stream) {
   const int grid = a.n_main + a.n_split * a.ksplit;
+  if (mode == ECO_CONV_MODE_SPAN) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    const size_t lds_bytes = sizeof(float) * (2 * KC * BM + 2 * KC * (size_t)(BN + 2 * (a.Wi + 1)) + 4);
+    hipLaunchKernelGGL((conv_span_kernel<TM, TN, WM, WN>), dim3(grid), dim3(256), lds_bytes, stream, a);
+    return check_launch("eco_conv_forward");
+  }
   if (mode == ECO_CONV_MODE_CTAP)
     hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, KC, ECO_CONV_MODE_CTAP>), dim3(grid), dim3(256), 0, stream, a);
   else
@@ -652,8 +898,17 @@ extern "C" int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* pla
   a.nblk_m = (int)ceil_div(g->cout, plan->bm);
   a.nblk_n = (int)ceil_div(a.ntot, plan->bn);
   ECO_REQUIRE((long)a.nblk_m * plan->bm <= plan->mpad, "conv: plan mpad too small for bm");
-  ECO_REQUIRE(plan->mode == ECO_CONV_MODE_TABLE || (plan->mode == ECO_CONV_MODE_CTAP && g->cin % plan->kc == 0),
+  ECO_REQUIRE(plan->mode == ECO_CONV_MODE_TABLE ||
+                  ((plan->mode == ECO_CONV_MODE_CTAP || plan->mode == ECO_CONV_MODE_SPAN) && g->cin % plan->kc == 0),
               "conv: bad plan mode");
+  if (plan->mode == ECO_CONV_MODE_SPAN) {
+    bool ok = g->kernel[1] == 3 && g->kernel[2] == 3 && g->pad[1] == 1 && g->pad[2] == 1 &&
+              (g->kernel[0] == 1 || g->kernel[0] == 3) && g->pad[0] == g->kernel[0] / 2 &&
+              plan->bn + 2 * (g->in[2] + 1) <= 512 && plan->kpad == plan->k;
+    for (int i = 0; i < 3; ++i) ok = ok && g->stride[i] == 1 && g->out[i] == g->in[i];
+    ECO_REQUIRE(ok, "conv: the span kernel needs a stride-1 same-size (kd)x3x3 geometry");
+    ECO_REQUIRE(plan->ksplit <= plan->kpad / (plan->kc * 9), "conv: more split-K slices than channel-tile groups");
+  }
   ECO_REQUIRE((long)g->n * a.img_stride_in < 2147483647l, "conv: input tensor too large for int32 gather offsets");
   const int mode = plan->mode;
   const int ntiles = a.nblk_m * a.nblk_n;

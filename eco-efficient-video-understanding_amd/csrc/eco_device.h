@@ -92,6 +92,15 @@ __device__ __forceinline__ void st(T* p, T v) {
   *p = v;
 }
 
+// Dynamic LDS of the launch as a float array (16-byte aligned; no static __shared__ may precede it).
+#ifdef ECO_EMU
+#define ECO_DYNAMIC_LDS(name) float* name = (float*)emu::dyn_smem()
+#else
+#define ECO_DYNAMIC_LDS(name)                                        \
+  extern __shared__ __attribute__((aligned(16))) char name##_raw[]; \
+  float* name = (float*)name##_raw
+#endif
+
 // XCD-aware workgroup remap (MI355X: 8 XCDs, hardware places block b on XCD b % 8, each
 // XCD has a private 4 MiB L2).  Returns the logical tile id for hardware block `b` such
 // that each XCD works on a contiguous range of logical tiles; bijective for any nwg.

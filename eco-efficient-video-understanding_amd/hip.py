@@ -88,6 +88,8 @@ _CONV_TILES = {(128, 128): (2, 2, 2, 2), (128, 256): (2, 4, 2, 2), (96, 256): (3
 def conv_kernel_name(plan: ConvPlan) -> str:
     """Name of the device kernel eco_conv_forward launches for this plan, as rocprofv3 prints it."""
     tm, tn, wm, wn = _CONV_TILES[(plan.bm, plan.bn)]
+    if plan.mode == 2:
+        return f"eco::conv_span_kernel<{tm}, {tn}, {wm}, {wn}>"
     return f"eco::conv_mfma_kernel<{tm}, {tn}, {wm}, {wn}, {plan.kc}, {plan.mode}>"
 
 

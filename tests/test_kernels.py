@@ -100,6 +100,9 @@ SMALL_CONVS = [
     (3, 16, 20, (3, 3), (3, 3), (1, 1), (1, 1)),               # bm=32, tile spans images
     (1, 48, 40, (6, 6), (1, 1), (1, 1), (0, 0)),               # 1x1 with 3 channel tiles
     (1, 64, 128, (2, 6, 6), (3, 3, 3), (1, 1, 1), (1, 1, 1)),  # 1 tile, 108 stages -> split-K (plan.ksplit > 1)
+    # span kernel (ECO_CONV_MODE_SPAN) corner cases
+    (1, 16, 32, (2, 127), (3, 3), (1, 1), (1, 1)),             # widest row the span buffer takes (span_len = 512)
+    (2, 16, 32, (3, 5, 5), (1, 3, 3), (1, 1, 1), (0, 1, 1)),   # 3-D input, kd = 1
 ]
 
 
@@ -131,7 +134,10 @@ def test_conv_plan_choice(backend):
         p = lib.conv_plan(hip.conv_geom(1, 8, cout, (8, 8), (3, 3), (1, 1), (1, 1), (8, 8)))
         assert p.bm == bm and p.bn in (128, 256) and p.kpad % p.kc == 0 and p.mpad >= cout and p.mpad % 4 == 0
         assert p.mode == 0  # cin=8: table mode
-    assert lib.conv_plan(hip.conv_geom(1, 64, 64, (8, 8), (3, 3), (1, 1), (1, 1), (8, 8))).mode == 1
+    assert lib.conv_plan(hip.conv_geom(1, 64, 64, (8, 8), (3, 3), (1, 1), (1, 1), (8, 8))).mode == 2   # span: 3x3 s1 same
+    assert lib.conv_plan(hip.conv_geom(1, 64, 64, (8, 8), (3, 3), (2, 2), (1, 1), (4, 4))).mode == 1   # strided: ctap
+    assert lib.conv_plan(hip.conv_geom(1, 64, 64, (8, 8), (1, 1), (1, 1), (0, 0), (8, 8))).mode == 1   # 1x1: ctap
+    assert lib.conv_plan(hip.conv_geom(1, 16, 64, (4, 300), (3, 3), (1, 1), (1, 1), (4, 300))).mode == 1  # rows too wide
     # split-K: chosen when the tile count quantises badly over 256 CUs and the reduction is long
     p5 = lib.conv_plan(hip.conv_geom(32, 512, 512, (4, 7, 7), (3, 3, 3), (1, 1, 1), (1, 1, 1), (4, 7, 7)))   # res5b: 196 tiles
     p4 = lib.conv_plan(hip.conv_geom(32, 256, 256, (8, 14, 14), (3, 3, 3), (1, 1, 1), (1, 1, 1), (8, 14, 14)))  # res4b: 784 tiles

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--filter", default="")
     ap.add_argument("--clips", type=int, default=32)
     ap.add_argument("--segments", type=int, default=16)
+    ap.add_argument("--no-span", action="store_true", help="run span-eligible plans with the CTAP gather kernel (A/B)")
     args = ap.parse_args()
     lib = hip.load()
     spec = NetSpec.from_prototxt(models.eco_lite_deploy(num_segments=args.segments, num_clips=args.clips))
@@ -40,6 +41,8 @@ def main():
         bs, ts = L.bottom_shapes[0], L.top_shapes[0]
         geom = hip.conv_geom(bs[0], g["cin"], g["cout"], bs[2:], g["kernel"], g["stride"], g["pad"], ts[2:])
         plan = lib.conv_plan(geom)
+        if args.no_span and plan.mode == 2:
+            plan.mode = 1  # same packed-weight order
         w = (np.random.default_rng(0).standard_normal((g["cout"], g["cin"]) + tuple(g["kernel"])) * 0.05).astype(np.float32)
         wp = np.zeros(plan.wp_elems, np.float32)
         kt = np.zeros(plan.ktab_elems, np.int32)
@@ -69,15 +72,15 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.iters
         flops = 2.0 * np.prod(ts) * g["cin"] * np.prod(g["kernel"])
-        rows.append((L.name, plan.bm, plan.bn, flops / 1e9, ms, flops / ms / 1e9, key, plan.ksplit))
+        rows.append((L.name, plan.bm, plan.bn, flops / 1e9, ms, flops / ms / 1e9, key, plan.ksplit, plan.mode))
         del x, y
     tot_f = tot_t = 0.0
     print(f"{'layer':34s} bm  bn   GFLOP     ms    TFLOP/s  x  (frac of 157.3)")
-    for name, bm, bn, gf, ms, tf, key, ks in rows:
+    for name, bm, bn, gf, ms, tf, key, ks, mode in rows:
         mult = len(seen[key])
         tot_f += gf * mult
         tot_t += ms * mult
-        print(f"{name:34s} {bm:3d} {bn:3d} {gf:8.1f} {ms:7.3f} {tf:8.1f}  x{mult}  {tf / 157.3:.3f}  ksplit={ks}")
+        print(f"{name:34s} {bm:3d} {bn:3d} {gf:8.1f} {ms:7.3f} {tf:8.1f}  x{mult}  {tf / 157.3:.3f}  ksplit={ks} mode={mode}")
     print(f"TOTAL conv: {tot_f:.1f} GFLOP in {tot_t:.2f} ms = {tot_f / tot_t:.1f} TFLOP/s ({tot_f / tot_t / 157.3:.3f} of peak)")
 
 
