@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(
 // the end of each stage; weights are double-buffered per stage as before.  LDS is dynamic
 // (2*16*BM + 2*16*span_len floats: 40 KB for res3, 52 KB for 28x28 inception convs, 59 KB for conv2_3x3).
 template <int TM, int TN, int WM, int WN>
-__global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : 2)) void conv_span_kernel(const ConvKernelArgs a) {
+__global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : TM * TN <= 6 ? 3 : 2)) void conv_span_kernel(const ConvKernelArgs a) {
   constexpr int KC = 16, KSTEPS = 8, T2 = 9;
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
@@ -484,8 +484,8 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : 2)) void conv_span_kernel(
   ECO_DYNAMIC_LDS(lds);
   const int halo = a.Wi + 1;
   const int span_len = BN + 2 * halo;
-  float* As = lds;                       // [2][KC][BM]
-  float* Bsp = lds + 2 * KC * BM;        // [2][KC][span_len]
+  float* As = lds;                       // [2][KC/2][BM][2]        (k-pair interleaved, see conv_mfma_kernel)
+  float* Bsp = lds + 2 * KC * BM;        // [2][KC/2][span_len][2]
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
@@ -562,17 +562,20 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : 2)) void conv_span_kernel(
   };
   // columns past the end of the span go to one dummy float behind the buffers: no divergent branch in the loop
   const int dummy = 2 * KC * span_len;
-  auto span_store = [&](int sbuf, int ci, int q, bool ok, float v) {
-    Bsp[col_in[q] ? (sbuf * KC + ci) * span_len + tid + q * 256 : dummy] = ok ? v : 0.0f;
+  auto span_store = [&](int sbuf, int p, int q, bool ok, float v0, float v1) {  // channels 2p, 2p+1
+    float2 v;
+    v.x = ok ? v0 : 0.0f;
+    v.y = ok ? v1 : 0.0f;
+    *(float2*)&Bsp[col_in[q] ? 2 * ((sbuf * (KC / 2) + p) * span_len + tid + q * 256) : dummy] = v;
   };
 
-  const float* l_wp = a.wp + m0 + (long)g_begin * T2 * KC * a.mpad;  // packed-weight rows of the stage being loaded
+  const float* l_wp = a.wp + 2 * m0 + (long)g_begin * T2 * KC * a.mpad;  // packed-weight rows of the stage being loaded
   float4 areg[A_ITERS];
   auto load_a = [&](int i) {
     const int idx = tid + i * 256;
     if (A_F4 % 256 == 0 || idx < A_F4) {
-      const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-      areg[i] = ld((const float4*)(l_wp + (long)row * a.mpad + c4 * 4));
+      const int row = idx / (BM / 2), c4 = idx % (BM / 2);
+      areg[i] = ld((const float4*)(l_wp + (long)row * 2 * a.mpad + c4 * 4));
     }
   };
   auto store_a = [&](int buf) {
@@ -591,25 +594,32 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : 2)) void conv_span_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  float af[2][TM], bf[2][TN];
+  float2 af[2][TM], bf[2][TN];
   bool okj[TN];        // this stage's tap is inside the image at fragment position j
   int frag_off = 0;    // y*W + x of this stage's tap
-  auto read_frags = [&](int buf, int sbuf, int kk, int slot) {
-    const float* ap = As + ((long)buf * KC + 2 * kk + half) * BM + wm * TM * 32 + l31;
-    const float* bp = Bsp + ((long)sbuf * KC + 2 * kk + half) * span_len + wn * TN * 32 + l31 + frag_off;
+  int ia[TM], ib[TN];  // float index of this lane's fragment i / j in pair-row `half` of buffer 0 (tap offset 0)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[slot][i] = ap[i * 32];
+  for (int i = 0; i < TM; ++i) { ia[i] = 2 * (half * BM + (wm * TM + i) * 32 + l31); ECO_OPAQUE(ia[i]); }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bf[slot][j] = bp[j * 32];
+  for (int j = 0; j < TN; ++j) { ib[j] = 2 * (half * span_len + (wn * TN + j) * 32 + l31); ECO_OPAQUE(ib[j]); }
+  auto read_frags = [&](int buf, int sbuf, int t, int slot) {
+    const float* ap = As + 2 * (buf * (KC / 2) + 2 * t) * BM;
+    const float* bp = Bsp + 2 * ((sbuf * (KC / 2) + 2 * t) * span_len + frag_off);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[slot][i] = *(const float2*)(ap + ia[i]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[slot][j] = *(const float2*)(bp + ib[j]);
   };
-  auto mfma_step = [&](int slot) {  // the zero-padding select sits here, a scheduling region after the LDS read
+  auto mfma_step = [&](int kk) {  // the zero-padding select sits here, a scheduling region after the LDS read
+    const int slot = (kk >> 1) & 1;
     float b[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b[j] = okj[j] ? bf[slot][j] : 0.0f;
+    for (int j = 0; j < TN; ++j) b[j] = okj[j] ? ((kk & 1) ? bf[slot][j].y : bf[slot][j].x) : 0.0f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(af[slot][i], b[j], acc[i][j]);
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = mfma_32x32x2((kk & 1) ? af[slot][i].y : af[slot][i].x, b[j], acc[i][j]);
   };
 
   // ---- prologue: whole span of the first group, weights of its first stage ----
@@ -619,10 +629,11 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : 2)) void conv_span_kernel(
     bool ok[NCOL];
 #pragma unroll
     for (int q = 0; q < NCOL; ++q) ok[q] = span_ok(shift, q);
-#pragma unroll 4
-    for (int ci = 0; ci < KC; ++ci)
+#pragma unroll 2
+    for (int p = 0; p < KC / 2; ++p)
 #pragma unroll
-      for (int q = 0; q < NCOL; ++q) span_store(0, ci, q, ok[q], span_load(xoff, ok[q], ci, q));
+      for (int q = 0; q < NCOL; ++q)
+        span_store(0, p, q, ok[q], span_load(xoff, ok[q], 2 * p, q), span_load(xoff, ok[q], 2 * p + 1, q));
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) load_a(i);
     store_a(0);
@@ -654,25 +665,23 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : 2)) void conv_span_kernel(
 #pragma unroll
       for (int j = 0; j < TN; ++j) okj[j] = (fmask[j] >> tap) & 1u;
       l_wp += last_stage ? 0l : (long)KC * a.mpad;  // weights of the next stage
-      const int ci0 = t2 < KC / 2 ? 2 * t2 : KC - 2;  // channels ci0, ci0+1 of the next group's span
+      const int p0 = t2 < KC / 2 ? t2 : KC / 2 - 1;  // channel pair (2*p0, 2*p0+1) of the next group's span
       float sreg[2][NCOL];
       read_frags(buf, sbuf, 0, 0);
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
-        if (kk + 1 < KSTEPS) read_frags(buf, sbuf, kk + 1, (kk + 1) & 1);
+        if ((kk & 1) == 0 && kk + 2 < KSTEPS) read_frags(buf, sbuf, kk / 2 + 1, (kk / 2 + 1) & 1);
         if (kk < A_ITERS) load_a(kk);
         if (kk < 2) {
 #pragma unroll
-          for (int q = 0; q < NCOL; ++q) sreg[kk][q] = span_load(nxoff, nok[q], ci0 + kk, q);
+          for (int q = 0; q < NCOL; ++q) sreg[kk][q] = span_load(nxoff, nok[q], 2 * p0 + kk, q);
         }
-        mfma_step(kk & 1);
+        mfma_step(kk);
         sched_fence();
       }
       store_a(buf ^ 1);
 #pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-        for (int q = 0; q < NCOL; ++q) span_store(sbuf ^ 1, ci0 + c2, q, nok[q], sreg[c2][q]);
+      for (int q = 0; q < NCOL; ++q) span_store(sbuf ^ 1, p0, q, nok[q], sreg[0][q], sreg[1][q]);
       __syncthreads();
     }
   }
@@ -840,9 +849,12 @@ extern "C" int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan
     const int kx = tap % g->kernel[2], ky = (tap / g->kernel[2]) % g->kernel[1], kz = tap / (g->kernel[2] * g->kernel[1]);
     const long off = (long)c * s_in + ((long)kz * g->in[1] + ky) * g->in[2] + kx;
     ktab[k] = (int32_t)(((unsigned)tap << kKoffBits) | (unsigned)off);
-    float* row = wp + (long)k * plan->mpad;
+    // gather kernels: K-major rows wp[k][m]; span kernel: k-pair interleaved wp[k/2][m][k%2]
+    const bool paired = plan->mode == ECO_CONV_MODE_SPAN;
+    float* row = paired ? wp + (long)(k >> 1) * 2 * plan->mpad + (k & 1) : wp + (long)k * plan->mpad;
+    const int mstep = paired ? 2 : 1;
     const long wk = (long)c * taps + tap;  // column of w[cout][cin*taps]
-    for (int m = 0; m < g->cout; ++m) row[m] = w[(long)m * K + wk];
+    for (int m = 0; m < g->cout; ++m) row[(long)m * mstep] = w[(long)m * K + wk];
   }
   return ECO_OK;
 }

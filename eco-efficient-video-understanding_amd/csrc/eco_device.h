@@ -101,6 +101,14 @@ __device__ __forceinline__ void st(T* p, T v) {
   float* name = (float*)name##_raw
 #endif
 
+// Hide a per-lane integer from the optimiser.  Used on LDS fragment indices: two 8-byte reads off the same
+// base register get merged into ds_read2_b64, which the LDS serves at half the rate of two ds_read_b64.
+#ifdef ECO_EMU
+#define ECO_OPAQUE(v) ((void)(v))
+#else
+#define ECO_OPAQUE(v) asm volatile("" : "+v"(v))
+#endif
+
 // XCD-aware workgroup remap (MI355X: 8 XCDs, hardware places block b on XCD b % 8, each
 // XCD has a private 4 MiB L2).  Returns the logical tile id for hardware block `b` such
 // that each XCD works on a contiguous range of logical tiles; bijective for any nwg.
