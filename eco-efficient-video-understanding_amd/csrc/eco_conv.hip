@@ -52,6 +52,14 @@ struct ConvKernelArgs {
   // ksplit slices; partial sums go to ws[slice][cout][n - n_split0] and a second launch reduces them.
   int ksplit, n_main, n_split;   // n_main + n_split = nblk_m * nblk_n
   int n_split0;                  // first output position covered by the split region
+  // Order of the flattened output positions n: 0 = (img, d, h, w) as in memory; 1 = depth-major (d, img, h, w)
+  // (span kernel, 3-D convs): a tile then holds one depth plane of several clips, and the tiles of the first /
+  // last plane skip the depth taps that only see zero padding.
+  int dmajor, n_img, bn_tile;
+  // Split-K slices per tile (span kernel): tile columns [col_long0, col_long1) are cut into ns_long slices,
+  // the others (depth-major: tiles of the first / last depth plane, 1/3 of the depth taps dead) into
+  // ns_short <= ns_long.  Gather kernels: every split tile has ksplit slices (ns_short = ns_long = ksplit).
+  int col_long0, col_long1, ns_short, ns_long;
   float* ws;
 };
 
@@ -63,6 +71,38 @@ constexpr int kNumCU = 256;    // MI355X
 __device__ __forceinline__ long view_base(const eco_view& v, int img, int sp) {
   const int b = img / v.t, t = img - b * v.t;
   return (long)b * v.stride_b + (long)t * v.stride_t + sp;
+}
+
+// Output position n -> (image, spatial index) under the launch's position order.
+__device__ __forceinline__ void decode_pos(const ConvKernelArgs& a, int n, int& img, int& sp) {
+  if (a.dmajor) {
+    const int phw = a.Ho * a.Wo, per_d = a.n_img * phw;
+    const int d = n / per_d, r = n - d * per_d;
+    img = r / phw;
+    sp = d * phw + (r - img * phw);
+  } else {
+    img = n / a.s_out;
+    sp = n - img * a.s_out;
+  }
+}
+
+// Depth-major launches: the depth taps [zlo, zhi] that touch at least one real input plane for some position
+// of the tile [n0, n0 + bn) (the tile lies in depth planes dlo..dhi; tap z reads plane d + z - pd).  Other
+// position orders: every tap.
+__device__ __forceinline__ void live_depth_taps(const ConvKernelArgs& a, int n0, int bn, int& zlo, int& zhi) {
+  zlo = 0;
+  zhi = a.kd - 1;
+  if (a.dmajor) {
+    const int per_d = a.n_img * a.Ho * a.Wo;
+    const int nlast = (n0 + bn < a.ntot ? n0 + bn : a.ntot) - 1;
+    const int dlo = n0 / per_d, dhi = nlast / per_d;
+    if (a.pd - dhi > 0) zlo = a.pd - dhi;
+    if (a.Di - 1 + a.pd - dlo < zhi) zhi = a.Di - 1 + a.pd - dlo;
+  }
+}
+// Split-K slices of the tiles of column `col` (see ConvKernelArgs).
+__device__ __forceinline__ int col_slices(const ConvKernelArgs& a, int col) {
+  return (col >= a.col_long0 && col < a.col_long1) ? a.ns_long : a.ns_short;
 }
 
 // Epilogue shared by both kernels: bias, Eltwise-SUM residual, raw store, folded BN, ReLU,
@@ -83,7 +123,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&
     const int n = nw + j * 32 + l31;
     e_ok[j] = n < a.ntot;
     const int nn = e_ok[j] ? n : 0;
-    const int img = nn / a.s_out, sp = nn - img * a.s_out;
+    int img, sp;
+    decode_pos(a, nn, img, sp);
     e_res[j] = has_res ? view_base(a.residual, img, sp) : 0;
     e_raw[j] = has_raw ? view_base(a.raw, img, sp) : 0;
     e_act[j] = has_act ? view_base(a.act, img, sp) : 0;
@@ -170,7 +211,8 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKerne
     float v[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v[e] = 0.0f;
-    for (int sidx = 0; sidx < a.ksplit; ++sidx) {
+    const int nsl = col_slices(a, n / a.bn_tile);  // tiles with dead depth taps were cut into fewer slices
+    for (int sidx = 0; sidx < nsl; ++sidx) {
       const float* p = (const float*)a.ws + sidx * slice_stride + idx;
       if (VEC == 4) {
         const float4 q = ld((const float4*)p);
@@ -179,7 +221,8 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKerne
         v[0] += ld(p);
       }
     }
-    const int img = n / a.s_out, sp = n - img * a.s_out;
+    int img, sp;
+    decode_pos(a, n, img, sp);
     const float b = a.bias ? ld(a.bias + ch) : 0.0f;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v[e] += b;
@@ -477,15 +520,20 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : TM * TN <= 6 ? 3 : 2)) voi
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
   static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int NCOL = 2;  // span columns per thread: span_len <= 512
+  // Weight operand: through a double-buffered LDS tile shared by the four waves (one barrier per stage), or
+  // -- for the 128x256 tile, where each fragment feeds four MFMAs and two waves per SIMD leave registers to
+  // spare -- straight from global memory into a register ring (one barrier per group of 9 stages).  Measured:
+  // direct is +1 % on the 128x256 tile and -1.5..-3 % on the others (2-4x duplicated L1 traffic).
+  constexpr bool ALDS = !(TM == 2 && TN == 4);
   constexpr int A_F4 = KC * BM / 4;
   constexpr int A_ITERS = (A_F4 + 255) / 256;
-  constexpr int NCOL = 2;  // span columns per thread: span_len <= 512
 
   ECO_DYNAMIC_LDS(lds);
   const int halo = a.Wi + 1;
   const int span_len = BN + 2 * halo;
-  float* As = lds;                       // [2][KC/2][BM][2]        (k-pair interleaved, see conv_mfma_kernel)
-  float* Bsp = lds + 2 * KC * BM;        // [2][KC/2][span_len][2]
+  float* Bsp = lds;                      // [2][KC/2][span_len][2]  (k-pair interleaved: row p = channels 2p, 2p+1)
+  float* As = lds + 2 * KC * span_len + 4;  // [2][KC/2][BM][2] behind the span buffers and the dummy slot (ALDS)
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
@@ -499,16 +547,36 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : TM * TN <= 6 ? 3 : 2)) voi
     slice = 0;
     nslices = 1;
   } else {
-    const int lid = xcd_remap((int)blockIdx.x - a.n_main, a.n_split * a.ksplit);
-    slice = lid / a.n_split;
-    tile = a.n_main + (lid - slice * a.n_split);
-    nslices = a.ksplit;
+    // (slice, tile) pairs that exist, slice-major: slices [0, ns_short) of every split tile, then slices
+    // [ns_short, ns_long) of the long columns only -- numbered densely so that the XCD remap deals every
+    // XCD the same number of live workgroups.
+    const int c0 = a.n_main / a.nblk_m;                               // first split column
+    const int cl0 = a.col_long0 > c0 ? a.col_long0 : c0;             // long columns of the split region
+    const int n_long = (a.col_long1 > cl0 ? a.col_long1 - cl0 : 0) * a.nblk_m;
+    const int n_all = a.n_split * a.ns_short;
+    const int lid = xcd_remap((int)blockIdx.x - a.n_main, n_all + n_long * (a.ns_long - a.ns_short));
+    if (lid < n_all) {
+      slice = lid / a.n_split;
+      tile = a.n_main + (lid - slice * a.n_split);
+    } else {
+      const int r = lid - n_all;
+      slice = a.ns_short + r / n_long;
+      tile = cl0 * a.nblk_m + r % n_long;
+    }
+    nslices = col_slices(a, tile / a.nblk_m);
   }
   const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
   const int m0 = mblk * BM, n0 = nblk * BN;
-  const int ngroups_all = a.kpad / (KC * T2);  // (cin/16) * kd; split-K slices are whole groups
-  const int g_begin = (int)((long)slice * ngroups_all / nslices);
-  const int g_end = (int)((long)(slice + 1) * ngroups_all / nslices);
+  // Reduction work list of this tile: "live" groups l = (cc, z) with z in [zlo, zhi], cc-major; a split-K
+  // slice is an equal share of it.
+  int zlo, zhi;
+  live_depth_taps(a, n0, BN, zlo, zhi);
+  const int nz = zhi - zlo + 1;
+  const int nlive = (a.cin / KC) * nz;
+  const bool sliced = (int)blockIdx.x >= a.n_main;
+  const int l_begin = (int)((long)slice * nlive / nslices);
+  const int l_end = (int)((long)(slice + 1) * nlive / nslices);
+  auto live_group = [&](int l) -> int { const int cc = l / nz; return cc * a.kd + zlo + (l - cc * nz); };
   const int hw = a.Hi * a.Wi;
   const int S = a.s_in;  // == s_out
 
@@ -519,7 +587,8 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : TM * TN <= 6 ? 3 : 2)) voi
     fmask[j] = 0u;
     const int n = n0 + (wn * TN + j) * 32 + l31;
     if (n < a.ntot) {
-      const int sp = n % S;
+      int img_, sp;
+      decode_pos(a, n, img_, sp);
       const int w = sp % a.Wi, t = sp / a.Wi;
       const int h = t % a.Hi, d = t / a.Hi;
       unsigned mw = 0u, mhw = 0u;
@@ -542,7 +611,8 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : TM * TN <= 6 ? 3 : 2)) voi
     col_base[q] = 0;
     col_sp[q] = -(1 << 29);  // never inside [0, S) whatever depth shift is added
     if (col_in[q] && v >= 0 && v < a.ntot) {
-      const int img = v / S, sp = v - img * S;
+      int img, sp;
+      decode_pos(a, v, img, sp);
       col_base[q] = (int)((long)img * a.img_stride_in + sp);
       col_sp[q] = sp;
     }
@@ -569,16 +639,30 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : TM * TN <= 6 ? 3 : 2)) voi
     *(float2*)&Bsp[col_in[q] ? 2 * ((sbuf * (KC / 2) + p) * span_len + tid + q * 256) : dummy] = v;
   };
 
-  const float* l_wp = a.wp + 2 * m0 + (long)g_begin * T2 * KC * a.mpad;  // packed-weight rows of the stage being loaded
+  // ---- weights.  Direct form: lane (m = l31, half h) of a wave needs, for the step pair t of a stage, exactly
+  // the two floats wp[pair-row 2t+h][m][0..1] of the packed image, so every fragment is one 8-byte global
+  // load per lane (256 contiguous bytes per half-wave, L1/L2 hits: all N-tiles of an M-block read the same
+  // rows).  The four step pairs of a stage form a register ring: the load for pair t of the *next* stage is
+  // issued right after the MFMAs of pair t, ~6 MFMA steps before it is needed, and the only LDS hazard left
+  // is the span double buffer.  LDS form: the stage's 8 pair-rows x BM x 2 floats are copied by all threads
+  // (16-byte loads, one stage ahead) and read back as fragments like the span.
+  const float* const wp_lane = a.wp + 2 * ((long)half * a.mpad + m0 + wm * TM * 32 + l31);  // pair-row `half`
+  const float* const wp_tile = a.wp + 2 * m0;
+  long l_woff = 0;  // float offset of the stage being loaded in the packed image
+  float2 af[KSTEPS / 2][TM];
   float4 areg[A_ITERS];
-  auto load_a = [&](int i) {
+  auto load_a = [&](int t) {  // direct: fragment pair t
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[t][i] = ld((const float2*)(wp_lane + l_woff + (long)t * 4 * a.mpad + i * 64));
+  };
+  auto load_a_tile = [&](int i) {  // LDS form: 16-byte piece i of the stage image
     const int idx = tid + i * 256;
     if (A_F4 % 256 == 0 || idx < A_F4) {
       const int row = idx / (BM / 2), c4 = idx % (BM / 2);
-      areg[i] = ld((const float4*)(l_wp + (long)row * 2 * a.mpad + c4 * 4));
+      areg[i] = ld((const float4*)(wp_tile + l_woff + (long)row * 2 * a.mpad + c4 * 4));
     }
   };
-  auto store_a = [&](int buf) {
+  auto store_a_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
       const int idx = tid + i * 256;
@@ -594,24 +678,27 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : TM * TN <= 6 ? 3 : 2)) voi
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  float2 af[2][TM], bf[2][TN];
+  float2 bf[2][TN];
   bool okj[TN];        // this stage's tap is inside the image at fragment position j
   int frag_off = 0;    // y*W + x of this stage's tap
+  int abuf = 0;        // LDS form: weight buffer of the current stage
   int ia[TM], ib[TN];  // float index of this lane's fragment i / j in pair-row `half` of buffer 0 (tap offset 0)
 #pragma unroll
   for (int i = 0; i < TM; ++i) { ia[i] = 2 * (half * BM + (wm * TM + i) * 32 + l31); ECO_OPAQUE(ia[i]); }
 #pragma unroll
   for (int j = 0; j < TN; ++j) { ib[j] = 2 * (half * span_len + (wn * TN + j) * 32 + l31); ECO_OPAQUE(ib[j]); }
-  auto read_frags = [&](int buf, int sbuf, int t, int slot) {
-    const float* ap = As + 2 * (buf * (KC / 2) + 2 * t) * BM;
+  auto read_frags = [&](int sbuf, int t, int slot) {
     const float* bp = Bsp + 2 * ((sbuf * (KC / 2) + 2 * t) * span_len + frag_off);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[slot][i] = *(const float2*)(ap + ia[i]);
-#pragma unroll
     for (int j = 0; j < TN; ++j) bf[slot][j] = *(const float2*)(bp + ib[j]);
+    if (ALDS) {
+      const float* ap = As + 2 * (abuf * (KC / 2) + 2 * t) * BM;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[slot][i] = *(const float2*)(ap + ia[i]);
+    }
   };
   auto mfma_step = [&](int kk) {  // the zero-padding select sits here, a scheduling region after the LDS read
-    const int slot = (kk >> 1) & 1;
+    const int t = kk >> 1, slot = t & 1, aslot = ALDS ? slot : t;
     float b[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) b[j] = okj[j] ? ((kk & 1) ? bf[slot][j].y : bf[slot][j].x) : 0.0f;
@@ -619,13 +706,15 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : TM * TN <= 6 ? 3 : 2)) voi
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        acc[i][j] = mfma_32x32x2((kk & 1) ? af[slot][i].y : af[slot][i].x, b[j], acc[i][j]);
+        acc[i][j] = mfma_32x32x2((kk & 1) ? af[aslot][i].y : af[aslot][i].x, b[j], acc[i][j]);
   };
 
-  // ---- prologue: whole span of the first group, weights of its first stage ----
-  {
+  // ---- prologue: whole span of the first live group, weights of its first stage ----
+  int l = l_begin;
+  if (l < l_end) {
+    const int g = live_group(l);
     int shift;
-    const int xoff = group_xoff(g_begin, shift);
+    const int xoff = group_xoff(g, shift);
     bool ok[NCOL];
 #pragma unroll
     for (int q = 0; q < NCOL; ++q) ok[q] = span_ok(shift, q);
@@ -634,58 +723,71 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : TM * TN <= 6 ? 3 : 2)) voi
 #pragma unroll
       for (int q = 0; q < NCOL; ++q)
         span_store(0, p, q, ok[q], span_load(xoff, ok[q], 2 * p, q), span_load(xoff, ok[q], 2 * p + 1, q));
+    l_woff = (long)g * T2 * KC * a.mpad;
+    if (ALDS) {
 #pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) load_a(i);
-    store_a(0);
+      for (int i = 0; i < A_ITERS; ++i) load_a_tile(i);
+      store_a_tile(0);
+    } else {
+#pragma unroll
+      for (int t = 0; t < KSTEPS / 2; ++t) load_a(t);
+    }
   }
   __syncthreads();
 
-  int stage = 0;  // stages done in this slice (parity selects the weight buffer)
+  int sbuf = 0;
 #pragma unroll 1
-  for (int g = g_begin; g < g_end; ++g) {
-    const int sbuf = (g - g_begin) & 1;
+  for (; l < l_end; ++l) {
+    const int g = live_group(l);
     const int z = g % a.kd;
-    const bool next_group = g + 1 < g_end;
+    const bool next_group = l + 1 < l_end;
+    const int gn = next_group ? live_group(l + 1) : g;
     int nshift = 0;
-    const int nxoff = next_group ? group_xoff(g + 1, nshift) : 0;
+    const int nxoff = next_group ? group_xoff(gn, nshift) : 0;
     bool nok[NCOL];
 #pragma unroll
     for (int q = 0; q < NCOL; ++q) nok[q] = next_group && span_ok(nshift, q);
 #pragma unroll 1
-    for (int t2 = 0; t2 < T2; ++t2, ++stage) {
-      // The loop body is branch-free: the last stage re-loads its own weights into the idle buffer, stage 8
-      // of a group re-stages channels 14/15, and without a next group the span loads hit address 0 and land
-      // in the idle span buffer.  Conditional loads would split the body into basic blocks and make the
-      // compiler drain vmcnt at every join.
-      const int buf = stage & 1;
-      const bool last_stage = !next_group && t2 == T2 - 1;
+    for (int t2 = 0; t2 < T2; ++t2) {
+      // The stage body is branch-free and barrier-free: the last stage of the slice re-loads its own weights,
+      // stage 8 of a group re-stages channels 14/15, and without a next group the span loads hit address 0
+      // and land in the idle span buffer.  Conditional loads would split the body into basic blocks and make
+      // the compiler drain vmcnt at every join.
       const int tap = z * T2 + t2;
       const int y = t2 / 3, xx = t2 - 3 * y;
       frag_off = y * a.Wi + xx;
 #pragma unroll
       for (int j = 0; j < TN; ++j) okj[j] = (fmask[j] >> tap) & 1u;
-      l_wp += last_stage ? 0l : (long)KC * a.mpad;  // weights of the next stage
+      // weights of the next stage: the next tap of this group, or tap 0 of the next live group
+      const int nstage = t2 + 1 < T2 ? g * T2 + t2 + 1 : (next_group ? gn * T2 : g * T2 + t2);
+      l_woff = (long)nstage * KC * a.mpad;
       const int p0 = t2 < KC / 2 ? t2 : KC / 2 - 1;  // channel pair (2*p0, 2*p0+1) of the next group's span
       float sreg[2][NCOL];
-      read_frags(buf, sbuf, 0, 0);
+      read_frags(sbuf, 0, 0);
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
-        if ((kk & 1) == 0 && kk + 2 < KSTEPS) read_frags(buf, sbuf, kk / 2 + 1, (kk / 2 + 1) & 1);
-        if (kk < A_ITERS) load_a(kk);
+        if ((kk & 1) == 0 && kk + 2 < KSTEPS) read_frags(sbuf, kk / 2 + 1, (kk / 2 + 1) & 1);
         if (kk < 2) {
 #pragma unroll
           for (int q = 0; q < NCOL; ++q) sreg[kk][q] = span_load(nxoff, nok[q], 2 * p0 + kk, q);
         }
+        if (ALDS && kk < A_ITERS) load_a_tile(kk);
         mfma_step(kk);
+        if (!ALDS && (kk & 1)) load_a(kk >> 1);  // ring slot t is free again: fetch pair t of the next stage
         sched_fence();
       }
-      store_a(buf ^ 1);
 #pragma unroll
       for (int q = 0; q < NCOL; ++q) span_store(sbuf ^ 1, p0, q, nok[q], sreg[0][q], sreg[1][q]);
-      __syncthreads();
+      if (ALDS) {
+        store_a_tile(abuf ^ 1);
+        abuf ^= 1;
+        if (t2 + 1 < T2) __syncthreads();  // weights of the next stage are in place
+      }
     }
+    __syncthreads();  // the next group's span is complete; this group's buffer may be overwritten
+    sbuf ^= 1;
   }
-  if (nslices > 1)
+  if (sliced)
     conv_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
   else
     conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
@@ -716,6 +818,46 @@ static int validate_geom(const eco_conv_geom* g) {
 }  // namespace eco
 
 using namespace eco;
+
+// Live depth taps of tile column `col` (bn positions wide) of a depth-major span launch; kd otherwise.
+static int host_col_nz(const eco_conv_geom* g, int mode, int bn, long col) {
+  const int kd = g->kernel[0];
+  if (!(mode == ECO_CONV_MODE_SPAN && kd == 3)) return kd;
+  const long ntot = (long)g->n * g->out[0] * g->out[1] * g->out[2];
+  const long per_d = (long)g->n * g->out[1] * g->out[2];
+  const long n0 = col * bn, nlast = (n0 + bn < ntot ? n0 + bn : ntot) - 1;
+  const long dlo = n0 / per_d, dhi = nlast / per_d;
+  const long zlo = g->pad[0] - dhi > 0 ? g->pad[0] - dhi : 0;
+  const long zhi = g->in[0] - 1 + g->pad[0] - dlo < kd - 1 ? g->in[0] - 1 + g->pad[0] - dlo : kd - 1;
+  return (int)(zhi - zlo + 1);
+}
+
+// Slices per tile column for split factor sp: columns [c_long0, c_long1) (all live depth taps) get ns_long,
+// the others (tiles inside the first / last depth plane) ns_short = ceil(sp * nz / kd).  Falls back to one
+// class when the columns do not form that pattern.
+static void host_split_layout(const eco_conv_geom* g, int mode, int bn, int sp, int* c_long0, int* c_long1,
+                              int* ns_short, int* ns_long) {
+  const int kd = g->kernel[0];
+  const long ntot = (long)g->n * g->out[0] * g->out[1] * g->out[2];
+  const int ncols = (int)ceil_div(ntot, bn);
+  *c_long0 = 0; *c_long1 = ncols; *ns_short = *ns_long = sp;
+  int nzmin = kd, nzmax = 0;
+  for (int c = 0; c < ncols; ++c) {
+    const int nz = host_col_nz(g, mode, bn, c);
+    if (nz < nzmin) nzmin = nz;
+    if (nz > nzmax) nzmax = nz;
+  }
+  auto slices = [&](int nz) { const int ns = (sp * nz + kd - 1) / kd; return ns < 1 ? 1 : ns; };
+  if (nzmin == nzmax) { *ns_short = *ns_long = slices(nzmax); return; }
+  int a = 0, b = ncols;
+  while (a < ncols && host_col_nz(g, mode, bn, a) != nzmax) ++a;
+  while (b > a && host_col_nz(g, mode, bn, b - 1) != nzmax) --b;
+  for (int c = 0; c < ncols; ++c) {
+    const int nz = host_col_nz(g, mode, bn, c);
+    if ((c >= a && c < b) ? nz != nzmax : nz != nzmin) { *ns_short = *ns_long = slices(nzmax); return; }  // irregular
+  }
+  *c_long0 = a; *c_long1 = b; *ns_short = slices(nzmin); *ns_long = slices(nzmax);
+}
 
 extern "C" int eco_conv_plan_create(const eco_conv_geom* g, eco_conv_plan* plan) {
   return eco_conv_plan_create_ex(g, kNumCU, plan);
@@ -785,14 +927,33 @@ extern "C" int eco_conv_plan_create_ex(const eco_conv_geom* g, int32_t num_cu, e
     const int ngroups = plan->mode == ECO_CONV_MODE_SPAN ? nstages / 9 : nstages;  // split-K granularity
     const int occ = (bm == 128 && plan->bn == 256) ? 2 : (bm == 96 ? 3 : 4);  // resident workgroups per CU
     const long slots = (long)num_cu * occ;
+    // Depth-major span launches (3-D kernels) skip the depth taps that only see padding: a tile whose
+    // positions lie in the first/last depth plane has nz = 2 (or 1) live taps of kd = 3 and gets
+    // ceil(sp*nz/kd) slices, so all workgroups stay ~1/sp of a full reduction long.
+    const long ncols = ceil_div(ntot, plan->bn);
+    auto split_wgs = [&](long col0, int sp, double* work) -> long {  // workgroups / live share of columns >= col0
+      int cl0, cl1, nss, nsl;
+      host_split_layout(g, plan->mode, plan->bn, sp, &cl0, &cl1, &nss, &nsl);
+      long wgs = 0, nz_sum = 0;
+      for (long c = col0; c < ncols; ++c) {
+        nz_sum += host_col_nz(g, plan->mode, plan->bn, c);
+        wgs += (long)((c >= cl0 && c < cl1) ? nsl : nss) * mblocks;
+      }
+      if (work) *work = (double)nz_sum / ((double)g->kernel[0] * (ncols - col0 > 0 ? ncols - col0 : 1));
+      return wgs;
+    };
+    int max_sp = 16;
+    if (max_sp > nstages / 8) max_sp = nstages / 8;
+    if (max_sp > ngroups) max_sp = ngroups;
     if (tiles < slots) {
-      const double t_flops = 2.0 * ntot * g->cout * plan->k / 100e12;
+      double work = 1.0;
+      split_wgs(0, 1, &work);
+      const double t_flops = 2.0 * ntot * g->cout * plan->k * work / 100e12;
       double best = 1e30;
-      for (int sp = 1; sp <= 16; ++sp) {
-        if (sp > 1 && (nstages / sp < 8 || sp > ngroups)) break;
-        const double per_cu = (double)tiles * sp / num_cu;
-        const double eff = per_cu / (double)ceil_div(tiles * sp, num_cu);
-        const double t = t_flops / eff + (sp > 1 ? 2.0 * sp * ntot * g->cout * 4.0 / 4e12 + 5e-6 : 0.0);
+      for (int sp = 1; sp <= max_sp; ++sp) {
+        const long wgs = split_wgs(0, sp, nullptr);
+        const double eff = ((double)wgs / num_cu) / (double)ceil_div(wgs, num_cu);
+        const double t = t_flops / eff + (sp > 1 ? 2.0 * sp * work * ntot * g->cout * 4.0 / 4e12 + 5e-6 : 0.0);
         if (t < best * 0.97) { best = t; plan->ksplit = sp; }  // prefer fewer slices unless >3 % better
       }
       if (plan->ksplit > 1) plan->split_tiles = (int)tiles;
@@ -801,9 +962,7 @@ extern "C" int eco_conv_plan_create_ex(const eco_conv_geom* g, int32_t num_cu, e
       if (rem > 0 && 2 * rem < slots) {
         rem = ceil_div(rem, mblocks) * mblocks;              // whole columns of M-blocks
         long sp = slots / rem;
-        if (sp > 16) sp = 16;
-        if (sp > nstages / 8) sp = nstages / 8;
-        if (sp > ngroups) sp = ngroups;
+        if (sp > max_sp) sp = max_sp;
         if (sp >= 2 && rem < tiles) { plan->ksplit = (int)sp; plan->split_tiles = (int)rem; }
       }
     }
@@ -861,10 +1020,13 @@ extern "C" int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan
 
 template <int TM, int TN, int WM, int WN, int KC>
 static int launch_conv(const ConvKernelArgs& a, int mode, hipStream_t stream) {
-  const int grid = a.n_main + a.n_split * a.ksplit;
+  const int c0 = a.n_main / a.nblk_m, cl0 = a.col_long0 > c0 ? a.col_long0 : c0;
+  const int n_long = (a.col_long1 > cl0 ? a.col_long1 - cl0 : 0) * a.nblk_m;
+  const int grid = a.n_main + a.n_split * a.ns_short + n_long * (a.ns_long - a.ns_short);
   if (mode == ECO_CONV_MODE_SPAN) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    const size_t lds_bytes = sizeof(float) * (2 * KC * BM + 2 * KC * (size_t)(BN + 2 * (a.Wi + 1)) + 4);
+    const bool alds = !(TM == 2 && TN == 4);  // see conv_span_kernel
+    const size_t lds_bytes = sizeof(float) * (2 * KC * (size_t)(BN + 2 * (a.Wi + 1)) + 4 + (alds ? 2 * KC * BM : 0));
     hipLaunchKernelGGL((conv_span_kernel<TM, TN, WM, WN>), dim3(grid), dim3(256), lds_bytes, stream, a);
     return check_launch("eco_conv_forward");
   }
@@ -907,6 +1069,9 @@ extern "C" int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* pla
   a.s_in = a.Di * a.Hi * a.Wi; a.s_out = a.Do * a.Ho * a.Wo;
   a.img_stride_in = (long)a.cin * a.s_in;
   a.ntot = g->n * a.s_out;
+  a.n_img = g->n;
+  a.bn_tile = plan->bn;
+  a.dmajor = (plan->mode == ECO_CONV_MODE_SPAN && g->kernel[0] == 3) ? 1 : 0;
   a.nblk_m = (int)ceil_div(g->cout, plan->bm);
   a.nblk_n = (int)ceil_div(a.ntot, plan->bn);
   ECO_REQUIRE((long)a.nblk_m * plan->bm <= plan->mpad, "conv: plan mpad too small for bm");
@@ -937,6 +1102,7 @@ extern "C" int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* pla
   ECO_REQUIRE(plan->ksplit == 1 || (int64_t)plan->ksplit * a.cout * (a.ntot - a.n_split0) * 4 <= plan->ws_bytes,
               "conv: plan workspace too small");
   a.ws = (float*)workspace;
+  host_split_layout(g, mode, plan->bn, plan->ksplit, &a.col_long0, &a.col_long1, &a.ns_short, &a.ns_long);
   int rc = ECO_OK;
   hipStream_t s = (hipStream_t)stream;
   switch (plan->bm) {
@@ -953,7 +1119,7 @@ extern "C" int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* pla
   auto vec_ok = [](const eco_view& v) {
     return !v.ptr || (((uintptr_t)v.ptr & 15) == 0 && v.stride_b % 4 == 0 && v.stride_t % 4 == 0 && v.stride_c % 4 == 0);
   };
-  const bool vec4 = a.s_out % 4 == 0 && a.n_split0 % 4 == 0 && (a.ntot - a.n_split0) % 4 == 0 &&
+  const bool vec4 = a.s_out % 4 == 0 && (!a.dmajor || (a.Ho * a.Wo) % 4 == 0) && a.n_split0 % 4 == 0 && (a.ntot - a.n_split0) % 4 == 0 &&
                     ((uintptr_t)a.ws & 15) == 0 && vec_ok(a.residual) && vec_ok(a.raw) && vec_ok(a.act);
   long rblocks = ceil_div((long)a.cout * (a.ntot - a.n_split0), 256L * (vec4 ? 4 : 1));
   if (rblocks > 262144) rblocks = 262144;

@@ -103,6 +103,10 @@ SMALL_CONVS = [
     # span kernel (ECO_CONV_MODE_SPAN) corner cases
     (1, 16, 32, (2, 127), (3, 3), (1, 1), (1, 1)),             # widest row the span buffer takes (span_len = 512)
     (2, 16, 32, (3, 5, 5), (1, 3, 3), (1, 1, 1), (0, 1, 1)),   # 3-D input, kd = 1
+    # depth-major position order: tiles inside the first / last depth plane skip the padded depth taps
+    (3, 16, 32, (3, 10, 10), (3, 3, 3), (1, 1, 1), (1, 1, 1)),  # 4 tiles: d=0 | d=0..1 | d=1..2 | d=2
+    (5, 16, 40, (1, 8, 8), (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # one plane: only the centre depth tap is live
+    (3, 64, 128, (2, 7, 7), (3, 3, 3), (1, 1, 1), (1, 1, 1)),   # split-K slices, plane size 49 (scalar reduce)
 ]
 
 
@@ -112,7 +116,8 @@ def test_conv_plain(backend, cfg):
 
 
 @pytest.mark.parametrize("cfg", [SMALL_CONVS[3], SMALL_CONVS[5], SMALL_CONVS[6], SMALL_CONVS[9], SMALL_CONVS[10],
-                                 SMALL_CONVS[11], SMALL_CONVS[12], SMALL_CONVS[14], SMALL_CONVS[16]])
+                                 SMALL_CONVS[11], SMALL_CONVS[12], SMALL_CONVS[14], SMALL_CONVS[16], SMALL_CONVS[19],
+                                 SMALL_CONVS[20], SMALL_CONVS[21]])
 def test_conv_fused_epilogue(backend, cfg):
     run_conv(backend, *cfg, mode="fused", seed=1)
 

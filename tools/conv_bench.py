@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--filter", default="")
     ap.add_argument("--clips", type=int, default=32)
     ap.add_argument("--segments", type=int, default=16)
+    ap.add_argument("--ksplit", type=int, default=0, help="override the split-K factor of fully split plans (experiments)")
     ap.add_argument("--no-span", action="store_true", help="run span-eligible plans with the CTAP gather kernel (A/B)")
     args = ap.parse_args()
     lib = hip.load()
@@ -43,6 +44,9 @@ def main():
         plan = lib.conv_plan(geom)
         if args.no_span and plan.mode == 2:
             plan.mode = 1  # same packed-weight order
+        if args.ksplit and plan.ksplit > 1 and plan.split_tiles == -(-g["cout"] // plan.bm) * -(-(int(np.prod(ts)) // g["cout"]) // plan.bn):
+            plan.ksplit = args.ksplit
+            plan.ws_bytes = args.ksplit * int(np.prod(ts)) * 4
         w = (np.random.default_rng(0).standard_normal((g["cout"], g["cin"]) + tuple(g["kernel"])) * 0.05).astype(np.float32)
         wp = np.zeros(plan.wp_elems, np.float32)
         kt = np.zeros(plan.ktab_elems, np.int32)
