@@ -133,8 +133,10 @@ int eco_conv_plan_create(const eco_conv_geom* g, eco_conv_plan* plan);
  * many-tile code paths with emulator-sized problems). */
 int eco_conv_plan_create_ex(const eco_conv_geom* g, int32_t num_cu, eco_conv_plan* plan);
 /* HOST function.  Re-lays caffe weights w[cout][cin][kd][kh][kw] (host pointer) into the
- * kernel's K-major image wp[kpad][mpad] (zero padded) and builds the gather table
- * ktab[kpad] (host pointers, sizes from the plan).  The caller uploads both. */
+ * kernel's K-major image (zero padded; wp[kpad][mpad] for the gather modes, k-pair
+ * interleaved wp[kpad/2][mpad][2] for ECO_CONV_MODE_SPAN -- the layout belongs to the plan)
+ * and builds the gather table ktab[kpad] (host pointers, sizes from the plan).  The caller
+ * uploads both. */
 int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan* plan,
                           const float* w, float* wp, int32_t* ktab);
 /* ConvolutionLayer::Forward_gpu (layers/conv_layer.cu, cudnn_conv_layer.cu:15-65) as one

@@ -39,7 +39,7 @@ def test_product_library_exports_every_declared_symbol():
     # plan / pack are host functions: they work without a device
     g = hip.conv_geom(1, 16, 128, (4, 7, 7), (3, 3, 3), (1, 1, 1), (1, 1, 1), (4, 7, 7))
     p = lib.conv_plan(g)
-    assert (p.bm, p.bn, p.kc, p.k, p.mode) == (128, 256, 16, 16 * 27, 1)
+    assert (p.bm, p.bn, p.kc, p.k, p.mode) == (128, 256, 16, 16 * 27, 2)
 
 
 def test_emulator_build_is_not_accepted_as_product(monkeypatch):
