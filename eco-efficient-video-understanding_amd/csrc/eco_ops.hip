@@ -332,6 +332,76 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float* x, float* y, 
   }
 }
 
+// AccuracyLayer::Forward (layers/accuracy_layer.cpp:46-92) over [outer, c, inner] scores and outer*inner
+// labels: a sample is a hit iff its label is among the first top_k entries of the scores sorted by
+// std::greater<pair<score, class>> -- i.e. fewer than top_k classes have a larger score, or the same score
+// and a larger class index.  One wave per sample; out[0] = hits / counted (labels equal to ignore_label are
+// skipped when has_ignore).  Single workgroup: the evaluator tail handles a clip batch.
+__global__ __launch_bounds__(256) void accuracy_kernel(const float* x, const float* label, float* out, long outer,
+                                                       long c, long inner, int top_k, int has_ignore, int ignore_label) {
+  __shared__ int s_hits[4], s_cnt[4];
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+  int hits = 0, cnt = 0;
+  const long total = outer * inner;
+  for (long i = wave; i < total; i += 4) {
+    const long o = i / inner, in = i - o * inner;
+    const int lv = (int)ld(label + i);
+    if (has_ignore && lv == ignore_label) continue;
+    const float* xp = x + o * c * inner + in;
+    const float vl = ld(xp + (long)lv * inner);
+    float before = 0.0f;  // classes ranked ahead of the label (exact in fp32: c < 2^24)
+    for (long j = lane; j < c; j += 64) {
+      const float v = ld(xp + j * inner);
+      before += (v > vl || (v == vl && j > lv)) ? 1.0f : 0.0f;
+    }
+    before = wave_sum(before);
+    hits += before < (float)top_k ? 1 : 0;
+    ++cnt;
+  }
+  if (lane == 0) { s_hits[wave] = hits; s_cnt[wave] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int h = s_hits[0] + s_hits[1] + s_hits[2] + s_hits[3], n = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    st(out, (float)h / (float)n);
+  }
+}
+
+// SoftmaxWithLossLayer::Forward (layers/softmax_loss_layer.cpp:52-84): loss = -sum log(max(prob[label],
+// FLT_MIN)) over the counted samples / (normalize ? counted : outer).  One wave per sample (max, sum of
+// exponentials and the label's exponential by butterfly reductions), partial sums combined in wave order.
+__global__ __launch_bounds__(256) void softmax_loss_kernel(const float* x, const float* label, float* out, long outer,
+                                                           long c, long inner, int normalize, int has_ignore,
+                                                           int ignore_label) {
+  __shared__ float s_loss[4];
+  __shared__ int s_cnt[4];
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+  float loss = 0.0f;
+  int cnt = 0;
+  const long total = outer * inner;
+  for (long i = wave; i < total; i += 4) {
+    const long o = i / inner, in = i - o * inner;
+    const int lv = (int)ld(label + i);
+    if (has_ignore && lv == ignore_label) continue;
+    const float* xp = x + o * c * inner + in;
+    float m = -FLT_MAX;
+    for (long j = lane; j < c; j += 64) m = fmaxf(m, ld(xp + j * inner));
+    m = wave_max(m);
+    float sum = 0.0f;
+    for (long j = lane; j < c; j += 64) sum += expf(ld(xp + j * inner) - m);
+    sum = wave_sum(sum);
+    const float prob = expf(ld(xp + (long)lv * inner) - m) / sum;
+    loss -= logf(fmaxf(prob, FLT_MIN));
+    ++cnt;
+  }
+  if (lane == 0) { s_loss[wave] = loss; s_cnt[wave] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float l = ((s_loss[0] + s_loss[1]) + s_loss[2]) + s_loss[3];
+    const int n = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    st(out, l / (normalize ? (float)n : (float)outer));
+  }
+}
+
 }  // namespace eco
 
 using namespace eco;
@@ -515,4 +585,25 @@ extern "C" int eco_softmax_forward(const float* x, float* y, int64_t outer, int6
   hipLaunchKernelGGL((softmax_kernel), dim3(grid_for(outer * inner)), dim3(kThreads), 0, (hipStream_t)stream, x, y,
                      (long)outer, (long)c, (long)inner);
   return check_launch("eco_softmax_forward");
+}
+
+extern "C" int eco_accuracy_forward(const float* x, const float* label, float* out, int64_t outer, int64_t c,
+                                    int64_t inner, int32_t top_k, int32_t has_ignore_label, int32_t ignore_label,
+                                    void* stream) {
+  clear_error();
+  ECO_REQUIRE(x && label && out && outer > 0 && c > 0 && inner > 0, "accuracy: bad argument");
+  ECO_REQUIRE(top_k >= 1 && top_k <= c, "accuracy: top_k must be in [1, %ld] (got %d)", (long)c, top_k);
+  hipLaunchKernelGGL((accuracy_kernel), dim3(1), dim3(kThreads), 0, (hipStream_t)stream, x, label, out, (long)outer,
+                     (long)c, (long)inner, top_k, has_ignore_label, ignore_label);
+  return check_launch("eco_accuracy_forward");
+}
+
+extern "C" int eco_softmax_loss_forward(const float* x, const float* label, float* out, int64_t outer, int64_t c,
+                                        int64_t inner, int32_t normalize, int32_t has_ignore_label,
+                                        int32_t ignore_label, void* stream) {
+  clear_error();
+  ECO_REQUIRE(x && label && out && outer > 0 && c > 0 && inner > 0, "softmax loss: bad argument");
+  hipLaunchKernelGGL((softmax_loss_kernel), dim3(1), dim3(kThreads), 0, (hipStream_t)stream, x, label, out,
+                     (long)outer, (long)c, (long)inner, normalize, has_ignore_label, ignore_label);
+  return check_launch("eco_softmax_loss_forward");
 }

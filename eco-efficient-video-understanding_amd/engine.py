@@ -325,6 +325,19 @@ class Engine:
             outer, c, inner = _prod(bshape[:ax]), bshape[ax], _prod(bshape[ax + 1:])
             self._add(i, L.name, lambda s, x=x, y=y, outer=outer, c=c, inner=inner:
                       lib.softmax_forward(x, y, outer, c, inner, s))
+        elif t in ("Accuracy", "SoftmaxWithLoss"):
+            g = L.geom
+            x, lab, y = self._ptr(L.bottoms[0]), self._ptr(L.bottoms[1]), self._ptr(top)
+            if t == "Accuracy":
+                self._add(i, L.name, lambda s, x=x, lab=lab, y=y, g=g: lib.accuracy_forward(
+                    x, lab, y, g["outer"], g["classes"], g["inner"], g["top_k"], g["ignore_label"], s))
+            else:
+                self._add(i, L.name, lambda s, x=x, lab=lab, y=y, g=g: lib.softmax_loss_forward(
+                    x, lab, y, g["outer"], g["classes"], g["inner"], g["normalize"], g["ignore_label"], s))
+                if len(L.tops) == 2:  # the softmax itself as second top
+                    p = self._ptr(L.tops[1])
+                    self._add(i, L.name, lambda s, x=x, p=p, g=g: lib.softmax_forward(
+                        x, p, g["outer"], g["classes"], g["inner"], s))
         else:  # pragma: no cover
             raise NetSpecError(f"no HIP launcher for layer type {t}")
 

@@ -21,7 +21,7 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _i32x3 = C.c_int32 * 3
 
@@ -148,6 +148,10 @@ _SIGNATURES = {
     "eco_video_input_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_float, C.c_int32, C.c_void_p]),
     "eco_softmax_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "eco_accuracy_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                       C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "eco_softmax_loss_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                           C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -250,6 +254,15 @@ class EcoLib:
 
     def softmax_forward(self, x, y, outer, c, inner, stream=None) -> None:
         self._check(self._dll.eco_softmax_forward(x, y, outer, c, inner, stream))
+
+    def accuracy_forward(self, x, label, out, outer, c, inner, top_k, ignore_label=None, stream=None) -> None:
+        self._check(self._dll.eco_accuracy_forward(x, label, out, outer, c, inner, top_k,
+                                                   ignore_label is not None, ignore_label or 0, stream))
+
+    def softmax_loss_forward(self, x, label, out, outer, c, inner, normalize=True, ignore_label=None,
+                             stream=None) -> None:
+        self._check(self._dll.eco_softmax_loss_forward(x, label, out, outer, c, inner, bool(normalize),
+                                                       ignore_label is not None, ignore_label or 0, stream))
 
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))

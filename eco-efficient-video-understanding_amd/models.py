@@ -239,3 +239,73 @@ def eco_full_deploy(num_segments: int = 16, num_clips: int = 5, num_classes: int
     b.concat("gn02_concat", ["pool_fusion_st2D", "global_pool_reshape"], "global_pool_gn02_reshape", axis=1)
     _fc(b, fc_name, "global_pool_gn02_reshape", num_classes)
     return _header(net_name, num_clips * num_segments, input_size) + "\n".join(b.out) + "\n"
+
+
+def test_phase_net(deploy_text: str, num_segments: int, batch_size: int = 1, fc_name: str = "fc8",
+                   input_size: int = 224, source: str = "val_frm.txt") -> str:
+    """Wrap a deploy graph into the TEST-phase evaluator of the train/val prototxts
+    (models_ECO_Lite/kinetics/ECO_Lite.prototxt:66-179,1883-1923): VideoData source (tops ``data`` +
+    ``label``), ``reshape_data`` [B, 3N, H, W] -> [B*N, 3, H, W], the deploy body, then ``loss``
+    (SoftmaxWithLoss), ``top1`` and ``top5`` (Accuracy), all ``include { phase: TEST }``."""
+    body = deploy_text[deploy_text.index("layer {"):]
+    if 'bottom: "data"' not in body:
+        raise ValueError("deploy graph does not consume a blob named 'data'")
+    body = body.replace('bottom: "data"', 'bottom: "reshape_data"')
+    mean = "\n".join("    mean_value: [104]\n    mean_value: [117]\n    mean_value: [123]" for _ in range(num_segments))
+    head = f"""name: "o3d"
+layer {{
+  name: "data"
+  type: "VideoData"
+  top: "data"
+  top: "label"
+  video_data_param {{
+    source: "{source}"
+    batch_size: {batch_size}
+    new_length: 1
+    num_segments: {num_segments}
+    modality: RGB
+    name_pattern: "img_%04d.jpg"
+  }}
+  transform_param {{
+    crop_size: {input_size}
+    mirror: false
+{mean}
+  }}
+  include: {{ phase: TEST }}
+}}
+layer {{ name: "reshape_data" type: "Reshape" bottom: "data" top: "reshape_data" reshape_param {{ shape {{ dim: -1 dim: 3 dim: {input_size} dim: {input_size} }} }} }}
+"""
+    tail = f"""layer {{
+  name: "loss"
+  type: "SoftmaxWithLoss"
+  bottom: "{fc_name}"
+  bottom: "label"
+  top: "loss"
+  include {{
+    phase: TEST
+  }}
+}}
+layer {{
+  name: "top1"
+  type: "Accuracy"
+  bottom: "{fc_name}"
+  bottom: "label"
+  top: "top1"
+  accuracy_param {{ top_k : 1}}
+  include {{
+    phase: TEST
+  }}
+}}
+layer {{
+  name: "top5"
+  type: "Accuracy"
+  bottom: "{fc_name}"
+  bottom: "label"
+  top: "top5"
+  accuracy_param {{ top_k: 5 }}
+  include {{
+    phase: TEST
+  }}
+}}
+"""
+    return head + body + tail

@@ -431,6 +431,43 @@ def _setup_softmax(L: LayerSpec) -> None:
     L.top_shapes = [tuple(L.bottom_shapes[0])]
 
 
+def _label_axis_geom(L: LayerSpec, axis: int) -> None:
+    bs, ls = L.bottom_shapes[0], L.bottom_shapes[1]
+    ax = _canon_axis(axis, len(bs), L.name)
+    outer, inner = _prod(bs[:ax]), _prod(bs[ax + 1:])
+    if outer * inner != _prod(ls):  # accuracy_layer.cpp:34-38, softmax_loss_layer.cpp:40-44
+        raise NetSpecError(f"{L.name}: Number of labels must match number of predictions "
+                           f"({outer * inner} predictions of shape {tuple(bs)}, {_prod(ls)} labels)")
+    L.geom.update(axis=ax, outer=outer, classes=int(bs[ax]), inner=inner)
+
+
+def _setup_accuracy(L: LayerSpec) -> None:
+    """AccuracyLayer (layers/accuracy_layer.cpp:14-44): bottoms scores + labels, scalar (0-axis) top."""
+    if len(L.bottoms) != 2 or len(L.tops) != 1:
+        raise NetSpecError(f"{L.name}: Accuracy takes 2 bottoms and 1 top")
+    p = L.param.msg("accuracy_param")
+    ign = p.get("ignore_label", None)
+    L.geom = dict(top_k=int(p.get("top_k", 1)), ignore_label=None if ign is None else int(ign))
+    _label_axis_geom(L, int(p.get("axis", 1)))
+    if L.geom["top_k"] > L.geom["classes"]:
+        raise NetSpecError(f"{L.name}: top_k must be less than or equal to the number of classes.")
+    L.top_shapes = [()]
+
+
+def _setup_softmax_loss(L: LayerSpec) -> None:
+    """SoftmaxWithLossLayer (layers/softmax_loss_layer.cpp:12-50, loss_layer.cpp): scalar loss top and,
+    optionally, the softmax as a second top.  (Forward only: the loss weight matters to training alone.)"""
+    if len(L.bottoms) != 2 or len(L.tops) not in (1, 2):
+        raise NetSpecError(f"{L.name}: SoftmaxWithLoss takes 2 bottoms and 1 or 2 tops")
+    lp = L.param.msg("loss_param")
+    ign = lp.get("ignore_label", None)
+    norm = lp.get("normalize", True)
+    L.geom = dict(normalize=bool(norm) if not isinstance(norm, str) else norm.lower() == "true",
+                  ignore_label=None if ign is None else int(ign))
+    _label_axis_geom(L, int(L.param.msg("softmax_param").get("axis", 1)))
+    L.top_shapes = [()] + ([tuple(L.bottom_shapes[0])] if len(L.tops) == 2 else [])
+
+
 _SETUP = {
     "Convolution": _setup_convolution,
     "Pooling": _setup_pooling,
@@ -444,6 +481,8 @@ _SETUP = {
     "Dropout": _setup_dropout,
     "Split": _setup_same,
     "Softmax": _setup_softmax,
+    "Accuracy": _setup_accuracy,
+    "SoftmaxWithLoss": _setup_softmax_loss,
 }
 
 SUPPORTED_LAYER_TYPES = tuple(_SETUP)
@@ -510,6 +549,27 @@ class NetSpec:
         layers = []
         for lp in raw:
             t = str(lp.get("type"))
+            if t == "VideoData":
+                # The data source of the train/val prototxts.  The engine does not read frame folders: the
+                # layer's tops become net inputs with the shapes VideoDataLayer::DataLayerSetUp gives them
+                # (video_data_layer.cpp:107-119: data [batch, 3*new_length*num_segments, crop, crop] for RGB,
+                # label [batch,1,1,1]); eco_amd.video.VideoInput fills `data` on the GPU.
+                tops = [str(b) for b in lp.getall("top")]
+                vp, tp = lp.msg("video_data_param"), lp.msg("transform_param")
+                batch, segs, nl = int(vp.get("batch_size", 1)), int(vp.get("num_segments", 1)), int(vp.get("new_length", 1))
+                crop = int(tp.get("crop_size", 0))
+                if crop <= 0:
+                    crop_h, crop_w = int(vp.get("new_height", 0)), int(vp.get("new_width", 0))
+                    if crop_h <= 0 or crop_w <= 0:
+                        raise NetSpecError(f"{lp.get('name')}: VideoData needs transform_param.crop_size or "
+                                           "video_data_param.new_height/new_width to fix the input shape")
+                else:
+                    crop_h = crop_w = crop
+                ch = (3 if str(vp.get("modality", "RGB")) == "RGB" else 2) * nl * segs
+                for k, tname in enumerate(tops[:2]):
+                    inputs.append(tname)
+                    in_shapes[tname] = (batch, ch, crop_h, crop_w) if k == 0 else (batch, 1, 1, 1)
+                continue
             layers.append(LayerSpec(name=str(lp.get("name")), type=t,
                                     bottoms=[str(b) for b in lp.getall("bottom")],
                                     tops=[str(b) for b in lp.getall("top")], param=lp))

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 4
+#define ECO_ABI_VERSION 5
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -208,6 +208,18 @@ int eco_video_input_forward(const uint8_t* frames, float* y, int64_t num_frames,
 /* SoftmaxLayer::Forward_gpu over axis 1 of [outer, c, inner] (layers/softmax_layer.cu:14-71). */
 int eco_softmax_forward(const float* x, float* y, int64_t outer, int64_t c, int64_t inner,
                         void* stream);
+/* AccuracyLayer::Forward (layers/accuracy_layer.cpp:46-92; TEST-phase `top1` / `top5` of
+ * the train/val prototxts): scores [outer, c, inner], labels [outer*inner] (float-coded class
+ * ids, as the reference's label blob).  *out (device, the layer's 0-axis top) = fraction of the
+ * counted samples whose label is in the top_k of std::greater<pair<score, class>>. */
+int eco_accuracy_forward(const float* x, const float* label, float* out, int64_t outer, int64_t c,
+                         int64_t inner, int32_t top_k, int32_t has_ignore_label, int32_t ignore_label,
+                         void* stream);
+/* SoftmaxWithLossLayer::Forward (layers/softmax_loss_layer.cpp:52-84; TEST-phase `loss`):
+ * *out = -sum log(max(softmax(x)[label], FLT_MIN)) / (normalize ? counted : outer). */
+int eco_softmax_loss_forward(const float* x, const float* label, float* out, int64_t outer, int64_t c,
+                             int64_t inner, int32_t normalize, int32_t has_ignore_label,
+                             int32_t ignore_label, void* stream);
 
 #ifdef __cplusplus
 }

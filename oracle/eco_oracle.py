@@ -279,6 +279,50 @@ def softmax(x, axis=1) -> np.ndarray:
     return (e / e.sum(axis=axis, keepdims=True)).astype(F32)
 
 
+def accuracy(x, label, top_k=1, axis=1, ignore_label=None) -> np.ndarray:
+    """``AccuracyLayer::Forward_cpu`` (layers/accuracy_layer.cpp:46-92): for every (outer, inner) sample
+    build (score, class) pairs, ``partial_sort`` them with ``std::greater`` and test whether the label is
+    among the first ``top_k``; result = hits / counted samples (0-axis blob)."""
+    x = np.asarray(x, F32)
+    outer = int(np.prod(x.shape[:axis]))
+    c = x.shape[axis]
+    inner = int(np.prod(x.shape[axis + 1:]))
+    xs = x.reshape(outer, c, inner)
+    lab = np.asarray(label).reshape(outer, inner)
+    hits = count = 0
+    for i in range(outer):
+        for j in range(inner):
+            lv = int(lab[i, j])
+            if ignore_label is not None and lv == ignore_label:
+                continue
+            pairs = sorted(((float(xs[i, k, j]), k) for k in range(c)), reverse=True)  # greater<pair<Dtype,int>>
+            hits += any(k == lv for _, k in pairs[:top_k])
+            count += 1
+    return np.asarray(np.float32(hits) / np.float32(count), F32)
+
+
+def softmax_loss(x, label, axis=1, normalize=True, ignore_label=None) -> np.ndarray:
+    """``SoftmaxWithLossLayer::Forward_cpu`` (layers/softmax_loss_layer.cpp:52-84): softmax over ``axis``,
+    ``loss -= log(max(prob[label], FLT_MIN))`` over the counted samples, divided by the count
+    (``normalize``, the default) or by ``outer_num_``."""
+    prob = softmax(x, axis)
+    outer = int(np.prod(prob.shape[:axis]))
+    c = prob.shape[axis]
+    inner = int(np.prod(prob.shape[axis + 1:]))
+    ps = prob.reshape(outer, c, inner)
+    lab = np.asarray(label).reshape(outer, inner)
+    loss = np.float32(0)
+    count = 0
+    for i in range(outer):
+        for j in range(inner):
+            lv = int(lab[i, j])
+            if ignore_label is not None and lv == ignore_label:
+                continue
+            loss -= np.log(np.maximum(ps[i, lv, j], np.finfo(np.float32).tiny)).astype(F32)
+            count += 1
+    return np.asarray(loss / np.float32(count if normalize else outer), F32)
+
+
 # --------------------------------------------------------------------------
 # VideoData output contract (TEST phase)
 # --------------------------------------------------------------------------
@@ -352,6 +396,12 @@ def forward(spec, params, inputs, keep=None, fast_pool=True, timings=None):
             top = [inner_product(bt[0], p[0], p[1] if g["bias_term"] else None, g["axis"])]
         elif L.type == "Softmax":
             top = [softmax(bt[0], g["axis"])]
+        elif L.type == "Accuracy":
+            top = [accuracy(bt[0], bt[1], g["top_k"], g["axis"], g["ignore_label"])]
+        elif L.type == "SoftmaxWithLoss":
+            top = [softmax_loss(bt[0], bt[1], g["axis"], g["normalize"], g["ignore_label"])]
+            if len(L.tops) == 2:
+                top.append(softmax(bt[0], g["axis"]))
         else:
             raise NotImplementedError(L.type)
         for name, v, shp in zip(L.tops, top, L.top_shapes):

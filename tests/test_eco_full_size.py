@@ -112,3 +112,14 @@ def test_hipgraph_replay_matches_eager():
     net.forward_device(graph=True)
     torch.cuda.synchronize()
     assert torch.allclose(net.blobs["fc8"].tensor, eager + 2.0, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_caffe_time_style_report():
+    """tools/eco_time.py (`caffe time` for the HIP path) runs and reports every launch of the fused plan."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "eco_time.py"), "--segments", "4", "--clips", "1",
+                          "--iterations", "2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Average Forward pass" in out.stdout and out.stdout.count("forward:") == 37

@@ -331,3 +331,29 @@ def test_inner_product_tail_softmax(backend):
     ys = backend.empty(sm.shape)
     lib.softmax_forward(backend.ptr(backend.dev(sm)), backend.ptr(ys), 2, 7, 3)
     assert relerr(backend.host(ys, sm.shape), orc.softmax(sm, 1)) < TOL
+
+
+@pytest.mark.parametrize("shape,top_k,ignore", [((7, 13), 1, None), ((7, 13), 5, None), ((5, 400), 5, None),
+                                                ((4, 9, 3), 2, None), ((9, 6), 1, 2), ((3, 70, 2, 2), 3, 5)])
+def test_accuracy_and_softmax_loss(backend, shape, top_k, ignore):
+    """AccuracyLayer / SoftmaxWithLossLayer against the oracle; scores are quantised so that ties occur and
+    the std::greater<pair<score, class>> tie rule (larger class index first) decides some samples."""
+    rng = np.random.default_rng(17)
+    x = (rng.integers(-6, 7, shape) * 0.5).astype(np.float32)
+    c = shape[1]
+    outer, inner = shape[0], int(np.prod(shape[2:]))
+    label = rng.integers(0, c, (outer, inner)).astype(np.float32)
+    if ignore is not None:
+        label[0, 0] = ignore
+    dx, dl = backend.dev(x), backend.dev(label)
+    out = backend.empty((2,))
+    backend.lib.accuracy_forward(backend.ptr(dx), backend.ptr(dl), backend.ptr(out), outer, c, inner, top_k, ignore)
+    ref = orc.accuracy(x, label, top_k, 1, ignore)
+    assert backend.host(out, (2,))[0] == np.float32(ref)
+    for normalize in (True, False):
+        backend.lib.softmax_loss_forward(backend.ptr(dx), backend.ptr(dl), backend.ptr(out), outer, c, inner,
+                                         normalize, ignore)
+        refl = orc.softmax_loss(x, label, 1, normalize, ignore)
+        assert abs(backend.host(out, (2,))[0] - refl) < 1e-5 * abs(refl)
+    with pytest.raises(hip.EcoError, match="top_k"):
+        backend.lib.accuracy_forward(backend.ptr(dx), backend.ptr(dl), backend.ptr(out), outer, c, inner, c + 1, None)

@@ -60,6 +60,34 @@ def test_mini_eco_matches_oracle(backend, variant, fuse):
         assert seen == len(net.blobs)
 
 
+@pytest.mark.parametrize("fuse", [False, True])
+def test_test_phase_evaluator_net(backend, fuse):
+    """The TEST phase of the train/val prototxts (ECO_Lite.prototxt:66-179,1883-1923): VideoData tops become
+    the inputs ``data`` [B,3N,H,W] and ``label`` [B,1,1,1]; outputs ``loss`` / ``top1`` / ``top5``."""
+    B, N, C = 6, 4, 10
+    proto = models.test_phase_net(mini("lite", num_segments=N, num_clips=B), N, batch_size=B, input_size=32)
+    spec = NetSpec.from_prototxt(proto)
+    assert spec.inputs == ["data", "label"] and sorted(spec.outputs) == ["loss", "top1", "top5"]
+    assert spec.input_shapes == {"data": (B, 3 * N, 32, 32), "label": (B, 1, 1, 1)}
+    params = fillers.synthetic_params(spec, seed=11)
+    x = fillers.synthetic_frames(B * N, 32, 32, seed=5).reshape(B, 3 * N, 32, 32)
+    # labels: take the oracle's own ranking so that top1 / top5 are neither 0 nor 1
+    logits = orc.forward(spec, params, {"data": x, "label": np.zeros((B, 1, 1, 1), np.float32)}, keep="all",
+                         fast_pool=False)["fc8"]
+    order = np.argsort(-logits, axis=1)
+    label = np.array([order[0, 0], order[1, 0], order[2, 3], order[3, 4], order[4, 6], order[5, 9]],
+                     np.float32).reshape(B, 1, 1, 1)
+    ref = orc.forward(spec, params, {"data": x, "label": label}, keep="all", fast_pool=False)
+    assert abs(float(ref["top1"]) - 2 / 6) < 1e-6 and abs(float(ref["top5"]) - 4 / 6) < 1e-6
+    net = make_net(backend, proto, params, fuse)
+    net.blobs["data"].data[...] = x
+    net.blobs["label"].data[...] = label
+    out = net.forward()
+    assert sorted(out) == ["loss", "top1", "top5"] and out["top1"].shape == ()
+    assert float(out["top1"]) == float(ref["top1"]) and float(out["top5"]) == float(ref["top5"])
+    assert abs(float(out["loss"]) - float(ref["loss"])) < 1e-4 * abs(float(ref["loss"]))
+
+
 def test_fused_plan_structure(backend):
     """The MI355X plan for ECO-Lite: 32 conv launches carry every BN/ReLU/Eltwise/Concat/Permute."""
     proto = mini("lite")

@@ -128,6 +128,19 @@ def test_generated_graph_equals_reference_file(gen, ref):
 
 
 @needs_ref
+def test_test_phase_of_trainval_prototxt_equals_generated_evaluator():
+    """ECO_Lite.prototxt filtered to phase TEST (VideoData source, reshape_data, body, loss, top1, top5) is the
+    graph models.test_phase_net builds around the deploy body."""
+    b = NetSpec.from_prototxt(os.path.join(REFERENCE, "models_ECO_Lite/kinetics/ECO_Lite.prototxt"))  # TEST default
+    a = NetSpec.from_prototxt(models.test_phase_net(models.eco_lite_deploy(num_clips=1), 16, batch_size=1))
+    assert b.inputs == ["data", "label"] and b.input_shapes == {"data": (1, 48, 224, 224), "label": (1, 1, 1, 1)}
+    assert a.inputs == b.inputs and a.input_shapes == b.input_shapes and sorted(b.outputs) == ["loss", "top1", "top5"]
+    assert len(a.layers) == len(b.layers)
+    for x, y in zip(a.layers, b.layers):
+        assert (x.name, x.type, x.bottoms, x.tops, x.geom, x.top_shapes) == (y.name, y.type, y.bottoms, y.tops, y.geom, y.top_shapes)
+
+
+@needs_ref
 @pytest.mark.parametrize("ds,ncls", [("ucf101", 101), ("hmdb51", 51), ("something_something", 174)])
 def test_other_datasets_differ_only_in_head(ds, ncls):
     b = NetSpec.from_prototxt(os.path.join(REFERENCE, "models_ECO_Lite", ds, "deploy.prototxt"))
@@ -176,3 +189,18 @@ def test_parser_against_reference_schema(ref):
         elif b.type == "Dropout":
             assert abs(a.msg("dropout_param").get("dropout_ratio") - b.dropout_param.dropout_ratio) < 1e-7
         assert len(a.getall("include")) == len(b.include)
+
+
+def test_roofline_tool_rederives_survey_totals():
+    """tools/roofline.py: algorithmic FLOPs and fused-model bytes of SURVEY.md section 8(d), from the shapes."""
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("roofline", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "tools", "roofline.py"))
+    rl = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(rl)
+    for gen, kw, gflop, fused_gb in [(models.eco_lite_deploy, dict(num_segments=16, num_clips=32), 2975.13, 18.54),
+                                     (models.eco_full_deploy, dict(num_segments=16, num_clips=32), 4122.43, 31.30),
+                                     (models.eco_lite_deploy, dict(num_segments=32, num_clips=32), 5950.25, 36.94),
+                                     (models.eco_lite_deploy, dict(num_segments=4, num_clips=1), 23.24, 0.294)]:
+        fl, fb, lb = rl.totals(NetSpec.from_prototxt(gen(**kw)))
+        assert abs(fl / 1e9 - gflop) < 0.01 and abs(fb / 1e9 - fused_gb) < 0.006 and lb > fb

@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""`caffe time`-style report for the HIP path (tools/caffe.cpp:276-360 `time()`, forward only): average
+forward time of every launch of the plan over --iterations, with the algorithmic GFLOP / MB of the launch
+and where it sits against the MI355X roofline.  GPU box only.
+
+    python tools/eco_time.py --variant lite --segments 16 --clips 32 --iterations 10 [--no-fuse]
+    python tools/eco_time.py --model path/to/deploy.prototxt [--weights x.caffemodel]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA = 157.3e12
+PEAK_HBM = 8.0e12
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", help="deploy prototxt (default: generated ECO graph)")
+    ap.add_argument("--weights", help=".caffemodel (default: seeded synthetic parameters)")
+    ap.add_argument("--variant", choices=["lite", "full"], default="lite")
+    ap.add_argument("--segments", type=int, default=16)
+    ap.add_argument("--clips", type=int, default=32)
+    ap.add_argument("--iterations", type=int, default=10)
+    ap.add_argument("--no-fuse", action="store_true", help="one launch per prototxt layer, like the reference executor")
+    args = ap.parse_args()
+
+    import eco_amd as caffe
+    from eco_amd import fillers, models
+    from eco_amd.netspec import NetSpec
+
+    caffe.set_device(0)
+    if args.model:
+        proto = args.model
+    else:
+        gen = models.eco_lite_deploy if args.variant == "lite" else models.eco_full_deploy
+        proto = gen(num_segments=args.segments, num_clips=args.clips)
+    spec = NetSpec.from_prototxt(proto)
+    if args.weights:
+        net = caffe.Net(proto, args.weights, caffe.TEST, fuse=not args.no_fuse)
+    else:
+        net = caffe.Net(proto, caffe.TEST, params=fillers.synthetic_params(spec), fuse=not args.no_fuse)
+    for name in spec.inputs:
+        t = net.blobs[name].tensor
+        t.uniform_(-1.0, 1.0)
+    net.forward_device()
+    prof = net._engine.profile(args.iterations)
+    print(f"*** Benchmark begins ***  Testing for {args.iterations} iterations.")
+    tot = 0.0
+    for p in prof:
+        ms = p["ms"]
+        tot += ms
+        fl, by = p.get("flops", 0), p.get("bytes", 0)
+        floor = max(fl / PEAK_FP32_MFMA, by / PEAK_HBM) * 1e3
+        frac = f"{floor / ms:5.2f}" if ms > 0 and floor > 0 else "    -"
+        print(f"{p['label'][:44]:>44s}\tforward: {ms:8.4f} ms.  {fl / 1e9:9.3f} GFLOP {by / 1e6:9.2f} MB  "
+              f"roofline frac {frac}  [{p.get('kernel', '')}]")
+    flops = spec.conv_fc_flops()
+    print(f"Average Forward pass: {tot:.4f} ms.  ({flops / 1e9:.1f} GFLOP -> {flops / tot / 1e9:.1f} TFLOP/s, "
+          f"{flops / tot / 1e9 / (PEAK_FP32_MFMA / 1e12) * 100:.1f} % of fp32 MFMA peak)")
+    print("*** Benchmark ends ***")
+
+
+if __name__ == "__main__":
+    main()
