@@ -1,0 +1,18 @@
+#!/bin/bash
+# Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
+#   kernel-trace stats, HBM traffic (FETCH_SIZE and WRITE_SIZE in separate --pmc passes), SQ counters,
+#   and the un-profiled bench line.  Outputs under gpurun_out/$1; condense with tools/summarize_profiles.py.
+set -u
+OUT=gpurun_out/${1:-prof}
+mkdir -p $OUT
+export TMPDIR=/tmp
+B="python $PWD/bench.py --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $PWD/$OUT/trace -o bench --output-format csv -- $B --steps 10 --warmup 3 > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $PWD/$OUT/pmc_fetch -o bench --output-format csv -- $B --steps 2 --warmup 1 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $PWD/$OUT/pmc_write -o bench --output-format csv -- $B --steps 2 --warmup 1 > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA -d $PWD/$OUT/pmc_sq -o bench --output-format csv -- $B --steps 2 --warmup 1 > $OUT/pmc_sq.log 2>&1
+python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
+find $OUT -name "*.csv" | head -20
+# keep only what the summariser reads (the merge back is capped at 64 MiB)
+find $OUT -name "*agent_info*" -delete
+ls -la $OUT/*/ 2>/dev/null | head -40

@@ -57,7 +57,50 @@ def main():
             f.write("%s,%.1f,%.1f,%.2f\n" % (k.replace(",", ";"), fk, wk, hbm / 1e6))
     with open(os.path.join(out_dir, "hbm_traffic_latest.json"), "w") as f:
         json.dump({"source": f"profiles/{tag}_pmc_hbm_traffic.csv", "kernels": summary}, f, indent=1)
+    sq = os.path.join(src, "pmc_sq", "bench_counter_collection.csv")
+    if os.path.exists(sq):
+        summarize_sq(sq, os.path.join(out_dir, f"{tag}_pmc_sq.csv"))
     print("wrote", os.listdir(out_dir))
+
+
+SQ_COUNTERS = ("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY "
+               "SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA")
+
+
+def summarize_sq(path, out_path):
+    """Per-kernel shader-engine counters of one `rocprofv3 --pmc <SQ_COUNTERS>` pass.  Derived columns:
+    clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time; MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (per-XCD cycles * 1024
+    SIMDs); wait / active = share of SQ_WAVE_CYCLES; avg waves per SIMD = 4 * SQ_WAVE_CYCLES / (cycles * 1024)
+    (the SQ wave-cycle counters tick once per 4 clocks)."""
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    dur = collections.defaultdict(float)
+    seen = set()
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        per[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        did = r.get("Dispatch_Id", "")
+        disp[k].add(did)
+        if (k, did) not in seen and r.get("Start_Timestamp") and r.get("End_Timestamp"):
+            seen.add((k, did))
+            dur[k] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6
+    with open(out_path, "w") as f:
+        f.write(f"# rocprofv3 --pmc {SQ_COUNTERS} -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline\n")
+        f.write("# clock = GRBM_GUI_ACTIVE/8 XCDs / kernel time; MfmaUtil = MFMA_BUSY / (cycles * 1024 SIMDs); "
+                "wait/active = fraction of wave cycles\n")
+        f.write("kernel,dispatches,total_ms,clock_GHz,MfmaUtil,wait_inst_frac,wait_any_frac,active_frac,"
+                "avg_waves_per_SIMD,lds_bank_conflict_cycles,insts_mfma\n")
+        for k, c in sorted(per.items(), key=lambda kv: -dur[kv[0]]):
+            cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+            wave = c.get("SQ_WAVE_CYCLES", 0.0)
+            if cyc <= 0 or wave <= 0:
+                continue
+            ms = dur[k]
+            f.write("%s,%d,%.3f,%.3f,%.3f,%.3f,%.3f,%.3f,%.2f,%.0f,%.0f\n" % (
+                k.replace(",", ";"), len(disp[k]), ms, cyc / (ms * 1e6) if ms else 0.0,
+                c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (cyc * 1024), c.get("SQ_WAIT_INST_ANY", 0.0) / wave,
+                c.get("SQ_WAIT_ANY", 0.0) / wave, c.get("SQ_ACTIVE_INST_ANY", 0.0) / wave, 4.0 * wave / (cyc * 1024),
+                c.get("SQ_LDS_BANK_CONFLICT", 0.0), c.get("SQ_INSTS_MFMA", 0.0)))
 
 
 if __name__ == "__main__":
