@@ -22,6 +22,12 @@ inline int check_launch(const char* what) {
 
 inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
 
+// Element offset of (image, channel 0, spatial index sp) in a strided output view (include/eco_hip.h).
+__device__ __forceinline__ long view_base(const eco_view& v, int img, int sp) {
+  const int b = img / v.t, t = img - b * v.t;
+  return (long)b * v.stride_b + (long)t * v.stride_t + sp;
+}
+
 }  // namespace eco
 
 #define ECO_REQUIRE(cond, ...)                                   \

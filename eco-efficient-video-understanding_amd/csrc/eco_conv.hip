@@ -61,17 +61,30 @@ struct ConvKernelArgs {
   // ns_short <= ns_long.  Gather kernels: every split tile has ksplit slices (ns_short = ns_long = ksplit).
   int col_long0, col_long1, ns_short, ns_long;
   float* ws;
+  // Batched launches (gridDim.y = batch; the 16 transform points of the Winograd path): element strides of
+  // the input, the packed weights, the output views and the split-K workspace between batch entries.
+  long bstride_x, bstride_w, bstride_out, bstride_ws;
+  int batch;
 };
+
+// The launch's arguments for batch entry blockIdx.y.
+__device__ __forceinline__ ConvKernelArgs batch_args(const ConvKernelArgs& a0) {
+  ConvKernelArgs a = a0;
+  const long bz = (long)blockIdx.y;
+  a.x += bz * a0.bstride_x;
+  a.wp += bz * a0.bstride_w;
+  if (a.residual.ptr) a.residual.ptr += bz * a0.bstride_out;
+  if (a.raw.ptr) a.raw.ptr += bz * a0.bstride_out;
+  if (a.act.ptr) a.act.ptr += bz * a0.bstride_out;
+  if (a.ws) a.ws += bz * a0.bstride_ws;
+  return a;
+}
 
 constexpr int kKoffBits = 26;
 constexpr int kKoffMask = (1 << kKoffBits) - 1;
 constexpr int kNeverTap = 63;  // validity-mask bit that is never set (used by K padding)
 constexpr int kNumCU = 256;    // MI355X
 
-__device__ __forceinline__ long view_base(const eco_view& v, int img, int sp) {
-  const int b = img / v.t, t = img - b * v.t;
-  return (long)b * v.stride_b + (long)t * v.stride_t + sp;
-}
 
 // Output position n -> (image, spatial index) under the launch's position order.
 __device__ __forceinline__ void decode_pos(const ConvKernelArgs& a, int n, int& img, int& sp) {
@@ -202,7 +215,8 @@ __device__ __forceinline__ void conv_store_partial(const ConvKernelArgs& a, f32x
 // of 4 and the pointers are 16-byte aligned); VEC = 1 is the general form.  HBM-bound: S slices read +
 // outputs written once.
 template <int VEC>
-__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKernelArgs a) {
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKernelArgs a0) {
+  const ConvKernelArgs a = batch_args(a0);
   const int nsplit_pos = a.ntot - a.n_split0;
   const long total = (long)a.cout * nsplit_pos;
   const long slice_stride = total;
@@ -278,7 +292,8 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKerne
 // Register budget: 64 accumulators per 2x2 wave tile leave ~100 VGPRs for four workgroups per CU;
 // the second launch-bound argument (waves per SIMD) holds the allocator to that.
 template <int TM, int TN, int WM, int WN, int KC, int MODE>
-__global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(const ConvKernelArgs a) {
+__global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(const ConvKernelArgs a0) {
+  const ConvKernelArgs a = batch_args(a0);
   constexpr bool CTAP = MODE == ECO_CONV_MODE_CTAP;
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
@@ -1031,9 +1046,9 @@ static int launch_conv(const ConvKernelArgs& a, int mode, hipStream_t stream) {
     return check_launch("eco_conv_forward");
   }
   if (mode == ECO_CONV_MODE_CTAP)
-    hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, KC, ECO_CONV_MODE_CTAP>), dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, KC, ECO_CONV_MODE_CTAP>), dim3(grid, a.batch), dim3(256), 0, stream, a);
   else
-    hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, KC, ECO_CONV_MODE_TABLE>), dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, KC, ECO_CONV_MODE_TABLE>), dim3(grid, a.batch), dim3(256), 0, stream, a);
   return check_launch("eco_conv_forward");
 }
 
@@ -1043,9 +1058,9 @@ static int check_view(const eco_view& v, const char* what) {
   return ECO_OK;
 }
 
-extern "C" int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* plan, const float* x, const float* wp,
-                                const int32_t* ktab, const eco_conv_epilogue* ep, void* workspace, void* stream) {
-  clear_error();
+static int conv_forward_impl(const eco_conv_geom* g, const eco_conv_plan* plan, const float* x, const float* wp,
+                             const int32_t* ktab, const eco_conv_epilogue* ep, void* workspace, int batch,
+                             long stride_x, long stride_wp, long stride_out, void* stream) {
   if (int rc = validate_geom(g)) return rc;
   ECO_REQUIRE(plan && x && wp && ktab && ep, "conv: null argument");
   ECO_REQUIRE(ep->raw.ptr || ep->act.ptr, "conv: at least one of raw/act outputs is required");
@@ -1102,6 +1117,11 @@ extern "C" int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* pla
   ECO_REQUIRE(plan->ksplit == 1 || (int64_t)plan->ksplit * a.cout * (a.ntot - a.n_split0) * 4 <= plan->ws_bytes,
               "conv: plan workspace too small");
   a.ws = (float*)workspace;
+  a.batch = batch;
+  a.bstride_x = stride_x; a.bstride_w = stride_wp; a.bstride_out = stride_out;
+  a.bstride_ws = plan->ws_bytes / 4;
+  ECO_REQUIRE(batch >= 1 && batch <= 65535, "conv: bad batch %d", batch);
+  ECO_REQUIRE(batch == 1 || mode != ECO_CONV_MODE_SPAN, "conv: the span kernel has no batched form");
   host_split_layout(g, mode, plan->bn, plan->ksplit, &a.col_long0, &a.col_long1, &a.ns_short, &a.ns_long);
   int rc = ECO_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -1124,8 +1144,23 @@ extern "C" int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* pla
   long rblocks = ceil_div((long)a.cout * (a.ntot - a.n_split0), 256L * (vec4 ? 4 : 1));
   if (rblocks > 262144) rblocks = 262144;
   if (vec4)
-    hipLaunchKernelGGL((conv_splitk_reduce_kernel<4>), dim3((unsigned)rblocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_splitk_reduce_kernel<4>), dim3((unsigned)rblocks, a.batch), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((conv_splitk_reduce_kernel<1>), dim3((unsigned)rblocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_splitk_reduce_kernel<1>), dim3((unsigned)rblocks, a.batch), dim3(256), 0, s, a);
   return check_launch("eco_conv_forward(split-K reduce)");
+}
+
+extern "C" int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* plan, const float* x, const float* wp,
+                                const int32_t* ktab, const eco_conv_epilogue* ep, void* workspace, void* stream) {
+  clear_error();
+  return conv_forward_impl(g, plan, x, wp, ktab, ep, workspace, 1, 0, 0, 0, stream);
+}
+
+extern "C" int eco_conv_forward_batched(const eco_conv_geom* g, const eco_conv_plan* plan, const float* x,
+                                        const float* wp, const int32_t* ktab, const eco_conv_epilogue* ep,
+                                        void* workspace, int32_t batch, int64_t stride_x, int64_t stride_wp,
+                                        int64_t stride_out, void* stream) {
+  clear_error();
+  ECO_REQUIRE(plan && plan->mode != ECO_CONV_MODE_SPAN, "conv (batched): span-mode plans have no batched form");
+  return conv_forward_impl(g, plan, x, wp, ktab, ep, workspace, batch, stride_x, stride_wp, stride_out, stream);
 }

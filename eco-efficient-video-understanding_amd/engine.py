@@ -106,11 +106,14 @@ def bn_eps(L: LayerSpec) -> float:
 
 
 class Engine:
-    def __init__(self, spec: NetSpec, lib: hip.EcoLib, alloc, fuse: bool = True) -> None:
+    def __init__(self, spec: NetSpec, lib: hip.EcoLib, alloc, fuse: bool = True, winograd: bool = True,
+                 num_cu: Optional[int] = None) -> None:
         self.spec = spec
         self.lib = lib
         self.alloc = alloc
         self.fuse = fuse
+        self.winograd = winograd   # Winograd F(2x2,3x3) for the stride-1 3x3x3 convs of the 3-D trunk
+        self.num_cu = num_cu       # None = the device's 256 CUs (tests shrink it to reach split-K paths)
         self.params: Dict[str, List[np.ndarray]] = {}
         self._param_dev: Dict[str, dict] = {}    # layer name -> device-side state
         self._dirty_params: set = set()
@@ -168,6 +171,18 @@ class Engine:
                 self.alloc.upload(st["ktab"], kt)
                 if L.geom["bias_term"]:
                     self.alloc.upload(st["bias"], blobs[1])
+                wn = st.get("wino")
+                if wn is not None:  # u[p] = (G g G^T)[p], each point packed for the (kd,1,1) gather kernel
+                    cout, cin, kd = L.geom["cout"], L.geom["cin"], L.geom["kernel"][0]
+                    u = np.empty((16, cout, cin, kd), np.float32)
+                    self.lib.wino_weight_transform(w.ctypes.data, cout, cin, kd, u.ctypes.data)
+                    wps = np.empty((16, wn["plan"].wp_elems), np.float32)
+                    ktw = np.empty(wn["plan"].ktab_elems, np.int32)
+                    for pt in range(16):
+                        self.lib.conv_pack_weights(wn["geom"], wn["plan"], u[pt].ctypes.data, wps[pt].ctypes.data,
+                                                   ktw.ctypes.data)
+                    self.alloc.upload(wn["wp"], wps)
+                    self.alloc.upload(wn["ktab"], ktw)
             elif L.type == "BN":
                 a, b = fold_bn(blobs, bn_eps(L))
                 self.alloc.upload(st["scale"], a)
@@ -193,7 +208,7 @@ class Engine:
                 g = L.geom
                 geom = hip.conv_geom(L.bottom_shapes[0][0], g["cin"], g["cout"], L.bottom_shapes[0][2:], g["kernel"],
                                      g["stride"], g["pad"], L.top_shapes[0][2:])
-                plan = self.lib.conv_plan(geom)
+                plan = self.lib.conv_plan(geom, self.num_cu)
                 old = st.get("plan")
                 if old is None or (old.wp_elems, old.ktab_elems) != (plan.wp_elems, plan.ktab_elems):
                     st["wp"] = self.alloc.empty(plan.wp_elems, np.float32)
@@ -201,6 +216,7 @@ class Engine:
                     if g["bias_term"]:
                         st["bias"] = self.alloc.empty(g["cout"], np.float32)
                 st["geom"], st["plan"] = geom, plan
+                st.pop("wino", None) if not self._wino_eligible(L) else self._plan_wino(L, st)
                 self._dirty_params.add(L.name)  # the gather table depends on the input dims
             elif L.type == "BN" and "scale" not in st:
                 st["scale"] = self.alloc.empty(L.geom["channels"], np.float32)
@@ -211,8 +227,15 @@ class Engine:
                 if L.geom["bias_term"]:
                     st["bias"] = self.alloc.empty(L.geom["num_output"], np.float32)
                 self._dirty_params.add(L.name)
-        # one scratch buffer serves every split-K convolution (launches are serial on one stream)
-        ws_bytes = max([st["plan"].ws_bytes for st in self._param_dev.values() if "plan" in st] + [0])
+        # one scratch buffer serves every split-K convolution (launches are serial on one stream); the same
+        # goes for the Winograd path's transformed input / output volumes
+        ws_bytes = max([st["plan"].ws_bytes for st in self._param_dev.values() if "plan" in st] +
+                       [16 * st["wino"]["plan"].ws_bytes for st in self._param_dev.values() if "wino" in st] + [0])
+        for key in ("v_elems", "m_elems"):
+            need = max([st["wino"][key] for st in self._param_dev.values() if "wino" in st] + [0])
+            if need > getattr(self, "_wino_" + key, 0):
+                setattr(self, "_wino_buf_" + key, self.alloc.empty(need, np.float32))
+                setattr(self, "_wino_" + key, need)
         if ws_bytes > getattr(self, "_ws_bytes", 0):
             self._ws = self.alloc.empty((ws_bytes + 3) // 4, np.float32)
             self._ws_bytes = ws_bytes
@@ -341,6 +364,66 @@ class Engine:
         else:  # pragma: no cover
             raise NetSpecError(f"no HIP launcher for layer type {t}")
 
+    # -- Winograd F(2x2,3x3) path (csrc/eco_wino.hip) ---------------------------------
+    def _wino_eligible(self, L: LayerSpec) -> bool:
+        """Stride-1, pad-1 3x3x3 convolutions of 5-D blobs with enough channels for the 16 transformed
+        (3,1,1) convolutions (K = 3*cin) to run efficiently: the res3/res4/res5 stride-1 convs.  The 2-D 3x3
+        convs (K = cin = 64..96 per transform point) stay on the direct span kernel."""
+        g = L.geom
+        return (self.winograd and len(L.bottom_shapes[0]) == 5 and tuple(g["kernel"]) == (3, 3, 3) and
+                tuple(g["stride"]) == (1, 1, 1) and tuple(g["pad"]) == (1, 1, 1) and g["cin"] % 16 == 0 and
+                g["cin"] >= 64 and tuple(L.top_shapes[0][2:]) == tuple(L.bottom_shapes[0][2:]))
+
+    def _plan_wino(self, L: LayerSpec, st: dict) -> None:
+        g = L.geom
+        n, _, D, H, W = L.bottom_shapes[0]
+        TH, TW = (H + 1) // 2, (W + 1) // 2
+        gw = hip.conv_geom(n, g["cin"], g["cout"], (D, TH, TW), (3, 1, 1), (1, 1, 1), (1, 0, 0), (D, TH, TW))
+        # the 16 points run side by side: each sees 1/16 of the CUs when the plan weighs tiles against slots
+        ncu = self.num_cu if self.num_cu is not None else 256
+        plan = self.lib.conv_plan(gw, max(1, ncu // 16))
+        old = st.get("wino")
+        wn = dict(geom=gw, plan=plan, TH=TH, TW=TW, v_elems=16 * n * g["cin"] * D * TH * TW,
+                  m_elems=16 * n * g["cout"] * D * TH * TW)
+        if old is not None and (old["plan"].wp_elems, old["plan"].ktab_elems) == (plan.wp_elems, plan.ktab_elems):
+            wn["wp"], wn["ktab"] = old["wp"], old["ktab"]
+        else:
+            wn["wp"] = self.alloc.empty(16 * plan.wp_elems, np.float32)
+            wn["ktab"] = self.alloc.empty(plan.ktab_elems, np.int32)
+        st["wino"] = wn
+
+    def _emit_wino_conv(self, i: int, L: LayerSpec, ep: "hip.ConvEpilogue", label: str, nbytes: int) -> None:
+        st = self._param_dev[L.name]
+        wn = st["wino"]
+        gw, plan = wn["geom"], wn["plan"]
+        lib = self.lib
+        n, cin, D, H, W = L.bottom_shapes[0]
+        cout = L.geom["cout"]
+        x = self._ptr(L.bottoms[0])
+        v, m = self.alloc.ptr(self._wino_buf_v_elems), self.alloc.ptr(self._wino_buf_m_elems)
+        wp, kt = self.alloc.ptr(wn["wp"]), self.alloc.ptr(wn["ktab"])
+        ws = self.alloc.ptr(self._ws) if plan.ws_bytes else None
+        tin, tout = wn["v_elems"] // 16, wn["m_elems"] // 16
+        epg = hip.ConvEpilogue()
+        epg.bias = None
+        epg.residual, epg.act = hip.null_view(), hip.null_view()
+        epg.bn_scale = epg.bn_shift = None
+        epg.relu = 0
+        epg.raw = hip.plain_view(m, cout, D * wn["TH"] * wn["TW"])
+        self._keep.append((gw, plan, ep, epg))
+        self._add(i, label + " [winograd input transform]", lambda s, x=x, v=v, pl=n * cin * D, H=H, W=W:
+                  lib.wino_input_forward(x, v, pl, H, W, s),
+                  {"kernel": "eco::wino_input_kernel", "flops": 0, "bytes": 4 * (n * cin * D * H * W + 16 * tin)})
+        self._add(i, label + " [16 transformed (3,1,1) convs]",
+                  lambda s, gw=gw, plan=plan, v=v, wp=wp, kt=kt, epg=epg, ws=ws, tin=tin, tout=tout:
+                  lib.conv_forward_batched(gw, plan, v, wp, kt, epg, ws, 16, tin, plan.wp_elems, tout, s),
+                  {"kernel": hip.conv_kernel_name(plan), "flops": 2 * 16 * tout * cin * 3,
+                   "bytes": 4 * (16 * tin + 16 * cout * cin * 3 + 16 * tout)})
+        self._add(i, label + " [winograd output transform]", lambda s, m=m, n=n, cout=cout, D=D, H=H, W=W, ep=ep:
+                  lib.wino_output_forward(m, n, cout, D, H, W, ep, s),
+                  {"kernel": "eco::wino_output_kernel", "flops": 0,
+                   "bytes": 4 * 16 * tout + nbytes - 4 * (n * cin * D * H * W + 27 * cin * cout)})
+
     def _emit_conv(self, i: int, L: LayerSpec, ep: "hip.ConvEpilogue", label: str) -> None:
         st = self._param_dev[L.name]
         g, plan = st["geom"], st["plan"]
@@ -354,6 +437,9 @@ class Engine:
         # algorithmic bytes (fused model): input + weights + each tensor the epilogue touches, once
         nbytes = 4 * (_prod(L.bottom_shapes[0]) + k * L.geom["cout"]
                       + n_out * (bool(ep.raw.ptr) + bool(ep.act.ptr) + bool(ep.residual.ptr)))
+        if "wino" in st:
+            self._emit_wino_conv(i, L, ep, label, nbytes)
+            return
         meta = {"kernel": hip.conv_kernel_name(plan), "flops": 2 * n_out * k, "bytes": nbytes}
         self._add(i, label, lambda s, g=g, plan=plan, x=x, wp=wp, kt=kt, ep=ep, ws=ws:
                   lib.conv_forward(g, plan, x, wp, kt, ep, ws, s), meta)

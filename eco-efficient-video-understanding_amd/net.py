@@ -139,8 +139,9 @@ class _LayerView:
 
 
 class Net:
-    def __init__(self, model, weights=None, phase=TEST, *, fuse: bool = True, device: Optional[int] = None,
-                 params: Optional[Dict[str, List[np.ndarray]]] = None, seed: int = 0, _backend=None) -> None:
+    def __init__(self, model, weights=None, phase=TEST, *, fuse: bool = True, winograd: bool = True,
+                 device: Optional[int] = None, params: Optional[Dict[str, List[np.ndarray]]] = None, seed: int = 0,
+                 _backend=None, _num_cu: Optional[int] = None) -> None:
         # pycaffe accepts Net(model, phase) and Net(model, weights, phase)
         if isinstance(weights, int) and not isinstance(weights, bool):
             weights, phase = None, weights
@@ -158,7 +159,9 @@ class Net:
             alloc = TorchAllocator(device)
         self._lib = lib
         self._alloc = alloc
-        self._engine = Engine(self._spec, lib, alloc, fuse=fuse)
+        # winograd=False evaluates every convolution directly (the reference's arithmetic order up to the
+        # summation order); the default uses Winograd F(2x2,3x3) for the 3-D trunk's stride-1 3x3x3 convs
+        self._engine = Engine(self._spec, lib, alloc, fuse=fuse, winograd=winograd, num_cu=_num_cu)
         self._pending_input_shapes: Dict[str, tuple] = {}
         self._engine.set_params(params if params is not None else fillers.filler_params(self._spec, seed))
         self._engine.build()

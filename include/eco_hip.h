@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 5
+#define ECO_ABI_VERSION 6
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -148,6 +148,27 @@ int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan* plan,
 int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* plan, const float* x,
                      const float* wp, const int32_t* ktab, const eco_conv_epilogue* ep,
                      void* workspace, void* stream);
+/* `batch` independent convolutions of one geometry / plan in a single launch (gridDim.y = batch):
+ * entry b reads x + b*stride_x, weights wp + b*stride_wp (same gather table), and writes through
+ * the epilogue's views moved by b*stride_out elements; `workspace` holds batch * plan.ws_bytes.
+ * Used for the 16 transform points of the Winograd path.  Gather-kernel plans only. */
+int eco_conv_forward_batched(const eco_conv_geom* g, const eco_conv_plan* plan, const float* x,
+                             const float* wp, const int32_t* ktab, const eco_conv_epilogue* ep,
+                             void* workspace, int32_t batch, int64_t stride_x, int64_t stride_wp,
+                             int64_t stride_out, void* stream);
+
+/* ---- Winograd F(2x2,3x3) path for stride-1, pad-1 (kd)x3x3 convolutions (csrc/eco_wino.hip) ----
+ * Same result as eco_conv_forward up to fp32 rounding (cudnn_conv_layer.cu:15-65 leaves the algorithm
+ * to cuDNN, which picks Winograd for such shapes too).  Tiles: TH = ceil(H/2), TW = ceil(W/2).
+ *   u = eco_wino_weight_transform(w)            HOST: u[16][cout][cin][kd] = G g G^T per (co, ci, z)
+ *   eco_wino_input_forward(x -> v)              v[16][planes][TH][TW], planes = n*cin*d
+ *   eco_conv_forward_batched(v -> m, batch=16)  geometry n, cin->cout, in (d,TH,TW), kernel (kd,1,1),
+ *                                               pad (kd/2,0,0); weights = pack(u[p]) per point; raw-only epilogue
+ *   eco_wino_output_forward(m -> y)             y tile = A^T m A, then the fused epilogue `ep` */
+int eco_wino_weight_transform(const float* w, int32_t cout, int32_t cin, int32_t kd, float* u);
+int eco_wino_input_forward(const float* x, float* v, int64_t planes, int32_t h, int32_t w, void* stream);
+int eco_wino_output_forward(const float* m, int32_t n, int32_t cout, int32_t d, int32_t h, int32_t w,
+                            const eco_conv_epilogue* ep, void* stream);
 
 /* ---- stand-alone operators (one per reference layer type) -------------------------- */
 

@@ -357,3 +357,123 @@ def test_accuracy_and_softmax_loss(backend, shape, top_k, ignore):
         assert abs(backend.host(out, (2,))[0] - refl) < 1e-5 * abs(refl)
     with pytest.raises(hip.EcoError, match="top_k"):
         backend.lib.accuracy_forward(backend.ptr(dx), backend.ptr(dl), backend.ptr(out), outer, c, inner, c + 1, None)
+
+
+# ---- Winograd F(2x2,3x3) path: transforms + 16 batched (kd,1,1) convolutions == the direct convolution ----
+def wino_conv(be, x, w, b, mode="plain", seed=0, num_cu=None):
+    """Run the three-launch Winograd evaluation through the C ABI; returns (raw, act-or-None, expected act fn)."""
+    lib = be.lib
+    n, cin = x.shape[:2]
+    cout, kd = w.shape[0], w.shape[2]
+    D, H, W = x.shape[2:]
+    TH, TW = (H + 1) // 2, (W + 1) // 2
+    u = np.zeros((16, cout, cin, kd), np.float32)
+    lib.wino_weight_transform(w.ctypes.data, cout, cin, kd, u.ctypes.data)
+    g = hip.conv_geom(n, cin, cout, (D, TH, TW), (kd, 1, 1), (1, 1, 1), (kd // 2, 0, 0), (D, TH, TW))
+    plan = lib.conv_plan(g, num_cu)
+    assert plan.mode in (0, 1)
+    wps = np.zeros((16, plan.wp_elems), np.float32)
+    kt = np.zeros(plan.ktab_elems, np.int32)
+    for p in range(16):
+        up = np.ascontiguousarray(u[p].reshape(cout, cin, kd, 1, 1))
+        lib.conv_pack_weights(g, plan, up.ctypes.data, wps[p].ctypes.data, kt.ctypes.data)
+    tiles_in, tiles_out = n * cin * D * TH * TW, n * cout * D * TH * TW
+    dx, dwp, dkt = be.dev(x), be.dev(wps), be.dev(kt)
+    v, m = be.empty((16 * tiles_in,)), be.empty((16 * tiles_out,))
+    ws = be.ptr(be.empty((16 * plan.ws_bytes // 4,))) if plan.ws_bytes else None
+    lib.wino_input_forward(be.ptr(dx), be.ptr(v), n * cin * D, H, W)
+    epg = hip.ConvEpilogue()
+    epg.bias = None
+    epg.residual, epg.act = hip.null_view(), hip.null_view()
+    epg.bn_scale = epg.bn_shift = None
+    epg.relu = 0
+    epg.raw = hip.plain_view(be.ptr(m), cout, D * TH * TW)
+    lib.conv_forward_batched(g, plan, be.ptr(v), be.ptr(dwp), be.ptr(dkt), epg, ws, 16, tiles_in, plan.wp_elems,
+                             tiles_out)
+    S = D * H * W
+    ep = hip.ConvEpilogue()
+    db = be.dev(b)
+    ep.bias = be.ptr(db)
+    ep.residual, ep.raw, ep.act = hip.null_view(), hip.null_view(), hip.null_view()
+    ep.bn_scale = ep.bn_shift = None
+    ep.relu = 0
+    shape = (n, cout, D, H, W)
+    raw = be.empty(shape)
+    ep.raw = hip.plain_view(be.ptr(raw), cout, S)
+    extra = None
+    if mode == "fused":
+        rng = np.random.default_rng(seed)
+        res = rng.standard_normal(shape).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        sh = rng.standard_normal(cout).astype(np.float32)
+        dres, dsc, dsh, act = be.dev(res), be.dev(sc), be.dev(sh), be.empty(shape)
+        ep.residual = hip.plain_view(be.ptr(dres), cout, S)
+        ep.act = hip.plain_view(be.ptr(act), cout, S)
+        ep.bn_scale, ep.bn_shift, ep.relu = be.ptr(dsc), be.ptr(dsh), 1
+        extra = (res, sc, sh, act)
+    lib.wino_output_forward(be.ptr(m), n, cout, D, H, W, ep)
+    return be.host(raw, shape), extra, (v, u, plan)
+
+
+@pytest.mark.parametrize("cfg", [(2, 16, 32, (3, 8, 8), 3), (1, 16, 130, (2, 7, 7), 3), (3, 32, 20, (1, 6, 10), 1),
+                                 (1, 6, 8, (2, 5, 4), 3)])
+@pytest.mark.parametrize("mode", ["plain", "fused"])
+def test_winograd_path_matches_direct_conv(backend, cfg, mode):
+    n, cin, cout, insp, kd = cfg
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((n, cin) + insp).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, kd, 3, 3)) / np.sqrt(cin * kd * 9)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = orc.convolution(x, w, b, (kd, 3, 3), (1, 1, 1), (kd // 2, 1, 1))
+    raw, extra, (v, u, plan) = wino_conv(backend, x, w, b, mode, seed=4)
+    # transforms against their definitions
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float32)
+    BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float32)
+    uref = np.einsum("ia,kczab,jb->ijkcz", G, w, G).reshape(16, cout, cin, kd)
+    assert relerr(u, uref) < 1e-6
+    H, W = insp[1:]
+    TH, TW = (H + 1) // 2, (W + 1) // 2
+    xp = np.zeros((n, cin, insp[0], 2 * TH + 2, 2 * TW + 2), np.float32)
+    xp[..., 1:H + 1, 1:W + 1] = x
+    tiles = np.stack([np.stack([xp[..., i:i + 2 * TH:2, j:j + 2 * TW:2] for j in range(4)], 0) for i in range(4)], 0)
+    vref = np.einsum("ia,ab...,jb->ij...", BT, tiles, BT).reshape(16, -1)
+    assert relerr(backend.host(v, vref.shape), vref) < 1e-6
+    if mode == "plain":
+        assert relerr(raw, ref) < 2e-5
+    else:
+        res, sc, sh, act = extra
+        exp_raw = ref + res
+        bshape = (1, cout, 1, 1, 1)
+        assert relerr(raw, exp_raw) < 2e-5
+        assert relerr(backend.host(act, ref.shape), np.maximum(exp_raw * sc.reshape(bshape) + sh.reshape(bshape), 0)) < 2e-5
+
+
+def test_batched_conv_equals_separate_launches(backend):
+    """eco_conv_forward_batched: entry b uses x + b*stride_x, wp + b*stride_wp and the views moved by b*stride_out."""
+    rng = np.random.default_rng(3)
+    nb, n, cin, cout, insp = 3, 2, 16, 40, (4, 5, 5)
+    g = hip.conv_geom(n, cin, cout, insp, (3, 1, 1), (1, 1, 1), (1, 0, 0), insp)
+    lib = backend.lib
+    plan = lib.conv_plan(g, 1)   # tiny device: 1 tile, long reduction -> split-K with a per-entry workspace
+    xs = rng.standard_normal((nb, n, cin) + insp).astype(np.float32)
+    wsn = (rng.standard_normal((nb, cout, cin, 3, 1, 1)) * 0.2).astype(np.float32)
+    wps = np.zeros((nb, plan.wp_elems), np.float32)
+    kt = np.zeros(plan.ktab_elems, np.int32)
+    for b in range(nb):
+        lib.conv_pack_weights(g, plan, wsn[b].ctypes.data, wps[b].ctypes.data, kt.ctypes.data)
+    dx, dwp, dkt = backend.dev(xs), backend.dev(wps), backend.dev(kt)
+    S = int(np.prod(insp))
+    y = backend.empty((nb, n, cout) + insp)
+    ep = hip.ConvEpilogue()
+    ep.bias = None
+    ep.residual, ep.act = hip.null_view(), hip.null_view()
+    ep.bn_scale = ep.bn_shift = None
+    ep.relu = 0
+    ep.raw = hip.plain_view(backend.ptr(y), cout, S)
+    ws = backend.ptr(backend.empty((nb * plan.ws_bytes // 4,))) if plan.ws_bytes else None
+    lib.conv_forward_batched(g, plan, backend.ptr(dx), backend.ptr(dwp), backend.ptr(dkt), ep, ws, nb,
+                             n * cin * S, plan.wp_elems, n * cout * S)
+    got = backend.host(y, (nb, n, cout) + insp)
+    for b in range(nb):
+        ref = orc.convolution(xs[b], wsn[b], None, (3, 1, 1), (1, 1, 1), (1, 0, 0))
+        assert relerr(got[b], ref) < TOL

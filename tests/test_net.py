@@ -18,10 +18,10 @@ def mini(variant, num_segments=4, num_clips=2, **kw):
     return gen(num_segments=num_segments, num_clips=num_clips, num_classes=10, input_size=32, width_div=8, **kw)
 
 
-def make_net(backend, proto, params, fuse):
+def make_net(backend, proto, params, fuse, **kw):
     if backend.kind == "emu":
-        return Net(proto, params=params, fuse=fuse, _backend=(backend.lib, backend.alloc))
-    return Net(proto, params=params, fuse=fuse)
+        return Net(proto, params=params, fuse=fuse, _backend=(backend.lib, backend.alloc), **kw)
+    return Net(proto, params=params, fuse=fuse, **kw)
 
 
 def relerr(got, ref):
@@ -55,7 +55,7 @@ def test_mini_eco_matches_oracle(backend, variant, fuse):
         assert seen < len(net.blobs)
         n_conv = sum(L.type == "Convolution" for L in spec.layers)
         # every BN/ReLU/Eltwise and the Lite Concat/Permute copies are gone
-        assert len(net.op_labels()) < n_conv + 25
+        assert len([l for l in net.op_labels() if "winograd input" not in l and "transformed" not in l]) < n_conv + 25
     else:
         assert seen == len(net.blobs)
 
@@ -94,7 +94,13 @@ def test_fused_plan_structure(backend):
     spec = NetSpec.from_prototxt(proto)
     net = make_net(backend, proto, fillers.synthetic_params(spec), True)
     labels = net.op_labels()
-    assert len(labels) == 37  # 32 convs + 4 pools + fused tail
+    # 32 convs + 4 pools + fused tail; the three res5 stride-1 convs (64 channels in this reduced net) take the
+    # Winograd route: input transform + 16 batched (3,1,1) convs + output transform with the fused epilogue
+    assert len(labels) == 37 + 2 * 3
+    wino = [l for l in labels if "winograd" in l or "transformed" in l]
+    assert len(wino) == 9 and "res5b_2+res5b+res5b_bn+res5b_relu [winograd output transform]" in wino
+    direct = make_net(backend, proto, fillers.synthetic_params(spec), True, winograd=False)
+    assert len(direct.op_labels()) == 37 and "res5b_2+res5b+res5b_bn+res5b_relu" in direct.op_labels()
     assert "res3b_2+res3b+res3b_bn+res3b_relu" in labels
     assert "res4a_down+res4a+res4a_bn+res4a_relu" in labels       # eltwise rides on the later operand
     assert "inception_3c_double_3x3_1+inception_3c_double_3x3_1_bn+inception_3c_relu_double_3x3_1_inp" in labels
