@@ -1,16 +1,17 @@
-// eco_wino.hip -- Winograd F(2x2, 3x3) front and back ends for stride-1, pad-1 (kd)x3x3 convolutions.
+// eco_wino.hip -- Winograd F(MxM, 3x3) front and back ends (M = 2 or 4) for stride-1, pad-1 (kd)x3x3 convolutions.
 //
 // The spatial 3x3 part of the kernel is evaluated with the minimal-filtering algorithm of Lavin & Gray
-// ("Fast Algorithms for Convolutional Neural Networks", 2015): a 2x2 output tile needs 16 multiplies per
-// (input channel, depth tap) instead of 36, so the MFMA work of a 3x3x3 convolution drops 2.25x; the depth
-// taps stay direct.  Three launches replace one conv:
-//   1. wino_input_kernel :  V[p][b][c][d][th][tw] = (B^T x_tile B)[p],  p = 4*i + j, 4x4 input tiles at stride 2
-//   2. 16 independent (3,1,1) convolutions M_p = U_p (*) V_p over (c, depth tap) -- the ordinary conv kernel,
+// ("Fast Algorithms for Convolutional Neural Networks", 2015): an MxM output tile needs (M+2)^2 multiplies per
+// (input channel, depth tap) instead of 9*M^2, so the MFMA work of a 3x3x3 convolution drops 2.25x (M = 2) or
+// 4x (M = 4); the depth taps stay direct.  With T = M + 2, three launches replace one conv:
+//   1. wino_input_kernel :  V[p][b][c][d][th][tw] = (B^T x_tile B)[p],  p = T*i + j, TxT input tiles at stride M
+//   2. T*T independent (3,1,1) convolutions M_p = U_p (*) V_p over (c, depth tap) -- the ordinary conv kernel,
 //      one grid slice per transform point (eco_conv_forward_batched), weights U_p = (G g G^T)[p]
 //   3. wino_output_kernel:  y_tile = A^T m A, then the usual fused epilogue (bias, residual, raw store, folded
 //      BN, ReLU, strided views)
-// 1 and 3 are HBM-bound streaming kernels (V and M are 4x the activation size each).  Results differ from the
-// direct evaluation by fp32 rounding only (~1e-6 relative; the path's tolerance is 1e-3).
+// 1 and 3 are HBM-bound streaming kernels (V and M are T^2/M^2 = 4x / 2.25x the activation size each).  Results
+// differ from the direct evaluation by fp32 rounding only: ~1e-6 relative for M = 2, ~1e-5 for M = 4 (larger
+// transform constants); the path's tolerance is 1e-3.
 #include <stdint.h>
 #include <string.h>
 
@@ -20,9 +21,37 @@ namespace eco {
 
 constexpr int kWinoThreads = 256;
 
-// One thread per (b, c, d, th, tw): 4x4 input tile at rows 2*th-1.., cols 2*tw-1.. (zero outside the image).
+// Transform matrices (Lavin & Gray 2015, section 4).  M = outputs per tile and dimension, T = M + 2 inputs.
+template <int M>
+struct WinoMat;
+template <>
+struct WinoMat<2> {
+  static constexpr int T = 4;
+  static constexpr float BT[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
+  static constexpr float G[4][3] = {{1, 0, 0}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0, 0, 1}};
+  static constexpr float AT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+};
+template <>
+struct WinoMat<4> {
+  static constexpr int T = 6;
+  static constexpr float BT[6][6] = {{4, 0, -5, 0, 1, 0},  {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                                     {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+  static constexpr float G[6][3] = {{0.25f, 0, 0},
+                                    {-1.0f / 6, -1.0f / 6, -1.0f / 6},
+                                    {-1.0f / 6, 1.0f / 6, -1.0f / 6},
+                                    {1.0f / 24, 1.0f / 12, 1.0f / 6},
+                                    {1.0f / 24, -1.0f / 12, 1.0f / 6},
+                                    {0, 0, 1}};
+  static constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+};
+
+// One thread per (b, c, d, th, tw): T x T input tile at rows M*th-1.., cols M*tw-1.. (zero outside the image),
+// v = B^T d B scattered to the T*T transform planes.  The matrices are compile-time constants: zero terms
+// vanish and +-1 terms become adds when the loops are unrolled.
+template <int M>
 __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* x, float* v, long planes /* b*c*d */,
                                                                   int H, int W, int TH, int TW) {
+  constexpr int T = WinoMat<M>::T;
   const long tiles = planes * TH * TW;
   for (long idx = (long)blockIdx.x * kWinoThreads + threadIdx.x; idx < tiles; idx += (long)gridDim.x * kWinoThreads) {
     const int tw = (int)(idx % TW);
@@ -30,33 +59,38 @@ __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* x
     const int th = (int)(r % TH);
     const long plane = r / TH;
     const float* xp = x + plane * H * W;
-    float d[4][4];
+    float d[T][T];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int h = 2 * th - 1 + i;
+    for (int i = 0; i < T; ++i) {
+      const int h = M * th - 1 + i;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int w = 2 * tw - 1 + j;
+      for (int j = 0; j < T; ++j) {
+        const int w = M * tw - 1 + j;
         const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
         d[i][j] = ok ? ld(xp + (ok ? (long)h * W + w : 0l)) : 0.0f;
       }
     }
-    // t = B^T d  (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]), then v = t B
-    float t[4][4];
+    float t[T][T];  // t = B^T d
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      t[0][j] = d[0][j] - d[2][j];
-      t[1][j] = d[1][j] + d[2][j];
-      t[2][j] = d[2][j] - d[1][j];
-      t[3][j] = d[1][j] - d[3][j];
-    }
+    for (int i = 0; i < T; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      st(v + (long)(4 * i + 0) * tiles + idx, t[i][0] - t[i][2]);
-      st(v + (long)(4 * i + 1) * tiles + idx, t[i][1] + t[i][2]);
-      st(v + (long)(4 * i + 2) * tiles + idx, t[i][2] - t[i][1]);
-      st(v + (long)(4 * i + 3) * tiles + idx, t[i][1] - t[i][3]);
-    }
+      for (int j = 0; j < T; ++j) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < T; ++k)
+          if (WinoMat<M>::BT[i][k] != 0.0f) acc += WinoMat<M>::BT[i][k] * d[k][j];
+        t[i][j] = acc;
+      }
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+      for (int j = 0; j < T; ++j) {  // v = t B
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < T; ++k)
+          if (WinoMat<M>::BT[j][k] != 0.0f) acc += t[i][k] * WinoMat<M>::BT[j][k];
+        st(v + (long)(T * i + j) * tiles + idx, acc);
+      }
   }
 }
 
@@ -70,11 +104,12 @@ struct WinoOutArgs {
   int n, cout, D, H, W, TH, TW;
 };
 
-// One thread per (b, k, d, th, tw): y = A^T m A (A^T = [1 1 1 0; 0 1 -1 -1]) and the conv epilogue on the
-// 2x2 outputs that fall inside the image.
+// One thread per (b, k, d, th, tw): y = A^T m A and the conv epilogue on the M x M outputs that fall inside
+// the image.
+template <int M>
 __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const WinoOutArgs a) {
+  constexpr int T = WinoMat<M>::T;
   const long tiles = (long)a.n * a.cout * a.D * a.TH * a.TW;
-  const int s_out = a.D * a.H * a.W;
   for (long idx = (long)blockIdx.x * kWinoThreads + threadIdx.x; idx < tiles; idx += (long)gridDim.x * kWinoThreads) {
     const int tw = (int)(idx % a.TW);
     long r = idx / a.TW;
@@ -84,36 +119,38 @@ __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const WinoOut
     r /= a.D;
     const int ch = (int)(r % a.cout);
     const int img = (int)(r / a.cout);
-    float m[4][4];
+    float m[T][T];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < T; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) m[i][j] = ld(a.m + (long)(4 * i + j) * tiles + idx);
-    float s[2][4];
+      for (int j = 0; j < T; ++j) m[i][j] = ld(a.m + (long)(T * i + j) * tiles + idx);
+    float s[M][T];  // s = A^T m
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s[0][j] = m[0][j] + m[1][j] + m[2][j];
-      s[1][j] = m[1][j] - m[2][j] - m[3][j];
-    }
-    float y[2][2];
+    for (int p = 0; p < M; ++p)
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      y[p][0] = s[p][0] + s[p][1] + s[p][2];
-      y[p][1] = s[p][1] - s[p][2] - s[p][3];
-    }
+      for (int j = 0; j < T; ++j) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < T; ++k)
+          if (WinoMat<M>::AT[p][k] != 0.0f) acc += WinoMat<M>::AT[p][k] * m[k][j];
+        s[p][j] = acc;
+      }
     const float b = a.bias ? ld(a.bias + ch) : 0.0f;
     const float sc = a.bn_scale ? ld(a.bn_scale + ch) : 1.0f, sh = a.bn_scale ? ld(a.bn_shift + ch) : 0.0f;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int h = 2 * th + p;
+    for (int p = 0; p < M; ++p) {
+      const int h = M * th + p;
       if (h >= a.H) continue;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int w = 2 * tw + q;
+      for (int q = 0; q < M; ++q) {
+        const int w = M * tw + q;
         if (w >= a.W) continue;
+        float y = 0.0f;  // y = s A
+#pragma unroll
+        for (int k = 0; k < T; ++k)
+          if (WinoMat<M>::AT[q][k] != 0.0f) y += s[p][k] * WinoMat<M>::AT[q][k];
         const int sp = (d * a.H + h) * a.W + w;
-        (void)s_out;
-        float val = y[p][q] + b;
+        float val = y + b;
         if (a.residual.ptr)
           val += ld((const float*)a.residual.ptr + view_base(a.residual, img, sp) + (long)ch * a.residual.stride_c);
         if (a.raw.ptr) st(a.raw.ptr + view_base(a.raw, img, sp) + (long)ch * a.raw.stride_c, val);
@@ -133,47 +170,64 @@ static unsigned wino_grid(long total) {
   return (unsigned)(b < 1 ? 1 : b);
 }
 
+template <int M>
+static void weight_transform(const float* w, long plane, float* u) {
+  constexpr int T = WinoMat<M>::T;
+  // u[p][co][ci][z] = (G g G^T)[i][j], p = T*i + j, g = w[co][ci][z][0..2][0..2]
+  for (long e = 0; e < plane; ++e) {
+    const float* g = w + e * 9;
+    float t[T][3];
+    for (int i = 0; i < T; ++i)
+      for (int j = 0; j < 3; ++j) {
+        float acc = 0.0f;
+        for (int k = 0; k < 3; ++k) acc += WinoMat<M>::G[i][k] * g[k * 3 + j];
+        t[i][j] = acc;
+      }
+    for (int i = 0; i < T; ++i)
+      for (int j = 0; j < T; ++j) {
+        float acc = 0.0f;
+        for (int k = 0; k < 3; ++k) acc += t[i][k] * WinoMat<M>::G[j][k];
+        u[(long)(T * i + j) * plane + e] = acc;
+      }
+  }
+}
+
 }  // namespace eco
 
 using namespace eco;
 
-extern "C" int eco_wino_weight_transform(const float* w, int32_t cout, int32_t cin, int32_t kd, float* u) {
+extern "C" int eco_wino_weight_transform(const float* w, int32_t cout, int32_t cin, int32_t kd, int32_t tile_m,
+                                         float* u) {
   clear_error();
   ECO_REQUIRE(w && u && cout > 0 && cin > 0 && kd > 0, "winograd weights: bad argument");
-  // u[p][co][ci][z] = (G g G^T)[i][j], p = 4*i + j, g = w[co][ci][z][0..2][0..2], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+  ECO_REQUIRE(tile_m == 2 || tile_m == 4, "winograd: output tile must be 2 (F(2x2,3x3)) or 4 (F(4x4,3x3)), got %d", tile_m);
   const long plane = (long)cout * cin * kd;
-  for (long e = 0; e < plane; ++e) {
-    const float* g = w + e * 9;
-    float t[4][3];
-    for (int j = 0; j < 3; ++j) {
-      t[0][j] = g[0 * 3 + j];
-      t[1][j] = 0.5f * (g[0 * 3 + j] + g[1 * 3 + j] + g[2 * 3 + j]);
-      t[2][j] = 0.5f * (g[0 * 3 + j] - g[1 * 3 + j] + g[2 * 3 + j]);
-      t[3][j] = g[2 * 3 + j];
-    }
-    for (int i = 0; i < 4; ++i) {
-      u[(long)(4 * i + 0) * plane + e] = t[i][0];
-      u[(long)(4 * i + 1) * plane + e] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
-      u[(long)(4 * i + 2) * plane + e] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
-      u[(long)(4 * i + 3) * plane + e] = t[i][2];
-    }
-  }
+  if (tile_m == 2) weight_transform<2>(w, plane, u);
+  else weight_transform<4>(w, plane, u);
   return ECO_OK;
 }
 
-extern "C" int eco_wino_input_forward(const float* x, float* v, int64_t planes, int32_t h, int32_t w, void* stream) {
+extern "C" int eco_wino_input_forward(const float* x, float* v, int64_t planes, int32_t h, int32_t w, int32_t tile_m,
+                                      void* stream) {
   clear_error();
   ECO_REQUIRE(x && v && planes > 0 && h > 0 && w > 0, "winograd input transform: bad argument");
-  const int TH = (h + 1) / 2, TW = (w + 1) / 2;
-  hipLaunchKernelGGL((wino_input_kernel), dim3(wino_grid(planes * TH * TW)), dim3(kWinoThreads), 0, (hipStream_t)stream,
-                     x, v, (long)planes, h, w, TH, TW);
+  ECO_REQUIRE(tile_m == 2 || tile_m == 4, "winograd: output tile must be 2 or 4, got %d", tile_m);
+  const int TH = (h + tile_m - 1) / tile_m, TW = (w + tile_m - 1) / tile_m;
+  const dim3 grid(wino_grid(planes * TH * TW));
+  if (tile_m == 2)
+    hipLaunchKernelGGL((wino_input_kernel<2>), grid, dim3(kWinoThreads), 0, (hipStream_t)stream, x, v, (long)planes, h, w,
+                       TH, TW);
+  else
+    hipLaunchKernelGGL((wino_input_kernel<4>), grid, dim3(kWinoThreads), 0, (hipStream_t)stream, x, v, (long)planes, h, w,
+                       TH, TW);
   return check_launch("eco_wino_input_forward");
 }
 
 extern "C" int eco_wino_output_forward(const float* m, int32_t n, int32_t cout, int32_t d, int32_t h, int32_t w,
-                                       const eco_conv_epilogue* ep, void* stream) {
+                                       int32_t tile_m, const eco_conv_epilogue* ep, void* stream) {
   clear_error();
   ECO_REQUIRE(m && ep && n > 0 && cout > 0 && d > 0 && h > 0 && w > 0, "winograd output transform: bad argument");
+  ECO_REQUIRE(tile_m == 2 || tile_m == 4, "winograd: output tile must be 2 or 4, got %d", tile_m);
   ECO_REQUIRE(ep->raw.ptr || ep->act.ptr, "winograd output transform: at least one of raw/act outputs is required");
   ECO_REQUIRE(!ep->bn_scale == !ep->bn_shift, "winograd output transform: bn_scale and bn_shift must be given together");
   const eco_view* views[3] = {&ep->residual, &ep->raw, &ep->act};
@@ -182,8 +236,12 @@ extern "C" int eco_wino_output_forward(const float* m, int32_t n, int32_t cout, 
   WinoOutArgs a;
   a.m = m; a.bias = ep->bias; a.bn_scale = ep->bn_scale; a.bn_shift = ep->bn_shift;
   a.residual = ep->residual; a.raw = ep->raw; a.act = ep->act; a.relu = ep->relu;
-  a.n = n; a.cout = cout; a.D = d; a.H = h; a.W = w; a.TH = (h + 1) / 2; a.TW = (w + 1) / 2;
+  a.n = n; a.cout = cout; a.D = d; a.H = h; a.W = w;
+  a.TH = (h + tile_m - 1) / tile_m; a.TW = (w + tile_m - 1) / tile_m;
   const long tiles = (long)n * cout * d * a.TH * a.TW;
-  hipLaunchKernelGGL((wino_output_kernel), dim3(wino_grid(tiles)), dim3(kWinoThreads), 0, (hipStream_t)stream, a);
+  if (tile_m == 2)
+    hipLaunchKernelGGL((wino_output_kernel<2>), dim3(wino_grid(tiles)), dim3(kWinoThreads), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((wino_output_kernel<4>), dim3(wino_grid(tiles)), dim3(kWinoThreads), 0, (hipStream_t)stream, a);
   return check_launch("eco_wino_output_forward");
 }

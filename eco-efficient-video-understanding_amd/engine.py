@@ -106,13 +106,17 @@ def bn_eps(L: LayerSpec) -> float:
 
 
 class Engine:
-    def __init__(self, spec: NetSpec, lib: hip.EcoLib, alloc, fuse: bool = True, winograd: bool = True,
+    def __init__(self, spec: NetSpec, lib: hip.EcoLib, alloc, fuse: bool = True, winograd=True,
                  num_cu: Optional[int] = None) -> None:
         self.spec = spec
         self.lib = lib
         self.alloc = alloc
         self.fuse = fuse
-        self.winograd = winograd   # Winograd F(2x2,3x3) for the stride-1 3x3x3 convs of the 3-D trunk
+        # Winograd F(MxM,3x3) for the stride-1 3x3x3 convs of the 3-D trunk: False = direct evaluation, 2 / 4 =
+        # output tile M, True = pick M per layer (4 where the planes are large enough to tile by 4)
+        if winograd not in (False, True, 2, 4):
+            raise ValueError("winograd must be False, True, 2 or 4")
+        self.winograd = winograd
         self.num_cu = num_cu       # None = the device's 256 CUs (tests shrink it to reach split-K paths)
         self.params: Dict[str, List[np.ndarray]] = {}
         self._param_dev: Dict[str, dict] = {}    # layer name -> device-side state
@@ -174,11 +178,12 @@ class Engine:
                 wn = st.get("wino")
                 if wn is not None:  # u[p] = (G g G^T)[p], each point packed for the (kd,1,1) gather kernel
                     cout, cin, kd = L.geom["cout"], L.geom["cin"], L.geom["kernel"][0]
-                    u = np.empty((16, cout, cin, kd), np.float32)
-                    self.lib.wino_weight_transform(w.ctypes.data, cout, cin, kd, u.ctypes.data)
-                    wps = np.empty((16, wn["plan"].wp_elems), np.float32)
+                    P = wn["points"]
+                    u = np.empty((P, cout, cin, kd), np.float32)
+                    self.lib.wino_weight_transform(w.ctypes.data, cout, cin, kd, wn["M"], u.ctypes.data)
+                    wps = np.empty((P, wn["plan"].wp_elems), np.float32)
                     ktw = np.empty(wn["plan"].ktab_elems, np.int32)
-                    for pt in range(16):
+                    for pt in range(P):
                         self.lib.conv_pack_weights(wn["geom"], wn["plan"], u[pt].ctypes.data, wps[pt].ctypes.data,
                                                    ktw.ctypes.data)
                     self.alloc.upload(wn["wp"], wps)
@@ -230,7 +235,8 @@ class Engine:
         # one scratch buffer serves every split-K convolution (launches are serial on one stream); the same
         # goes for the Winograd path's transformed input / output volumes
         ws_bytes = max([st["plan"].ws_bytes for st in self._param_dev.values() if "plan" in st] +
-                       [16 * st["wino"]["plan"].ws_bytes for st in self._param_dev.values() if "wino" in st] + [0])
+                       [st["wino"]["points"] * st["wino"]["plan"].ws_bytes for st in self._param_dev.values()
+                        if "wino" in st] + [0])
         for key in ("v_elems", "m_elems"):
             need = max([st["wino"][key] for st in self._param_dev.values() if "wino" in st] + [0])
             if need > getattr(self, "_wino_" + key, 0):
@@ -377,25 +383,30 @@ class Engine:
     def _plan_wino(self, L: LayerSpec, st: dict) -> None:
         g = L.geom
         n, _, D, H, W = L.bottom_shapes[0]
-        TH, TW = (H + 1) // 2, (W + 1) // 2
+        # output tile: F(4x4,3x3) does 4x fewer multiplies than direct (F(2x2): 2.25x) and its transformed
+        # volumes are 2.25x the activations (F(2x2): 4x); planes that do not tile by 4 pay ceil() padding
+        M = self.winograd if self.winograd in (2, 4) else 4
+        T = M + 2
+        TH, TW = -(-H // M), -(-W // M)
         gw = hip.conv_geom(n, g["cin"], g["cout"], (D, TH, TW), (3, 1, 1), (1, 1, 1), (1, 0, 0), (D, TH, TW))
-        # the 16 points run side by side: each sees 1/16 of the CUs when the plan weighs tiles against slots
+        # the T*T points run side by side: each sees 1/(T*T) of the CUs when the plan weighs tiles against slots
         ncu = self.num_cu if self.num_cu is not None else 256
-        plan = self.lib.conv_plan(gw, max(1, ncu // 16))
+        plan = self.lib.conv_plan(gw, max(1, ncu // (T * T)))
         old = st.get("wino")
-        wn = dict(geom=gw, plan=plan, TH=TH, TW=TW, v_elems=16 * n * g["cin"] * D * TH * TW,
-                  m_elems=16 * n * g["cout"] * D * TH * TW)
-        if old is not None and (old["plan"].wp_elems, old["plan"].ktab_elems) == (plan.wp_elems, plan.ktab_elems):
+        wn = dict(geom=gw, plan=plan, M=M, points=T * T, TH=TH, TW=TW, v_elems=T * T * n * g["cin"] * D * TH * TW,
+                  m_elems=T * T * n * g["cout"] * D * TH * TW)
+        if old is not None and (old["points"], old["plan"].wp_elems, old["plan"].ktab_elems) == \
+                (T * T, plan.wp_elems, plan.ktab_elems):
             wn["wp"], wn["ktab"] = old["wp"], old["ktab"]
         else:
-            wn["wp"] = self.alloc.empty(16 * plan.wp_elems, np.float32)
+            wn["wp"] = self.alloc.empty(T * T * plan.wp_elems, np.float32)
             wn["ktab"] = self.alloc.empty(plan.ktab_elems, np.int32)
         st["wino"] = wn
 
     def _emit_wino_conv(self, i: int, L: LayerSpec, ep: "hip.ConvEpilogue", label: str, nbytes: int) -> None:
         st = self._param_dev[L.name]
         wn = st["wino"]
-        gw, plan = wn["geom"], wn["plan"]
+        gw, plan, M, P = wn["geom"], wn["plan"], wn["M"], wn["points"]
         lib = self.lib
         n, cin, D, H, W = L.bottom_shapes[0]
         cout = L.geom["cout"]
@@ -403,7 +414,7 @@ class Engine:
         v, m = self.alloc.ptr(self._wino_buf_v_elems), self.alloc.ptr(self._wino_buf_m_elems)
         wp, kt = self.alloc.ptr(wn["wp"]), self.alloc.ptr(wn["ktab"])
         ws = self.alloc.ptr(self._ws) if plan.ws_bytes else None
-        tin, tout = wn["v_elems"] // 16, wn["m_elems"] // 16
+        tin, tout = wn["v_elems"] // P, wn["m_elems"] // P
         epg = hip.ConvEpilogue()
         epg.bias = None
         epg.residual, epg.act = hip.null_view(), hip.null_view()
@@ -411,18 +422,19 @@ class Engine:
         epg.relu = 0
         epg.raw = hip.plain_view(m, cout, D * wn["TH"] * wn["TW"])
         self._keep.append((gw, plan, ep, epg))
-        self._add(i, label + " [winograd input transform]", lambda s, x=x, v=v, pl=n * cin * D, H=H, W=W:
-                  lib.wino_input_forward(x, v, pl, H, W, s),
-                  {"kernel": "eco::wino_input_kernel", "flops": 0, "bytes": 4 * (n * cin * D * H * W + 16 * tin)})
-        self._add(i, label + " [16 transformed (3,1,1) convs]",
-                  lambda s, gw=gw, plan=plan, v=v, wp=wp, kt=kt, epg=epg, ws=ws, tin=tin, tout=tout:
-                  lib.conv_forward_batched(gw, plan, v, wp, kt, epg, ws, 16, tin, plan.wp_elems, tout, s),
-                  {"kernel": hip.conv_kernel_name(plan), "flops": 2 * 16 * tout * cin * 3,
-                   "bytes": 4 * (16 * tin + 16 * cout * cin * 3 + 16 * tout)})
-        self._add(i, label + " [winograd output transform]", lambda s, m=m, n=n, cout=cout, D=D, H=H, W=W, ep=ep:
-                  lib.wino_output_forward(m, n, cout, D, H, W, ep, s),
-                  {"kernel": "eco::wino_output_kernel", "flops": 0,
-                   "bytes": 4 * 16 * tout + nbytes - 4 * (n * cin * D * H * W + 27 * cin * cout)})
+        tag = f"F({M}x{M},3x3)"
+        self._add(i, f"{label} [winograd {tag} input transform]", lambda s, x=x, v=v, pl=n * cin * D, H=H, W=W, M=M:
+                  lib.wino_input_forward(x, v, pl, H, W, M, s),
+                  {"kernel": f"eco::wino_input_kernel<{M}>", "flops": 0, "bytes": 4 * (n * cin * D * H * W + P * tin)})
+        self._add(i, f"{label} [{P} transformed (3,1,1) convs]",
+                  lambda s, gw=gw, plan=plan, v=v, wp=wp, kt=kt, epg=epg, ws=ws, tin=tin, tout=tout, P=P:
+                  lib.conv_forward_batched(gw, plan, v, wp, kt, epg, ws, P, tin, plan.wp_elems, tout, s),
+                  {"kernel": hip.conv_kernel_name(plan), "flops": 2 * P * tout * cin * 3,
+                   "bytes": 4 * (P * tin + P * cout * cin * 3 + P * tout)})
+        self._add(i, f"{label} [winograd {tag} output transform]",
+                  lambda s, m=m, n=n, cout=cout, D=D, H=H, W=W, M=M, ep=ep: lib.wino_output_forward(m, n, cout, D, H, W, M, ep, s),
+                  {"kernel": f"eco::wino_output_kernel<{M}>", "flops": 0,
+                   "bytes": 4 * P * tout + nbytes - 4 * (n * cin * D * H * W + 27 * cin * cout)})
 
     def _emit_conv(self, i: int, L: LayerSpec, ep: "hip.ConvEpilogue", label: str) -> None:
         st = self._param_dev[L.name]

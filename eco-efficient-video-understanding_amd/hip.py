@@ -21,7 +21,7 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _i32x3 = C.c_int32 * 3
 
@@ -134,9 +134,9 @@ _SIGNATURES = {
     "eco_conv_forward_batched": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvPlan), C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.POINTER(ConvEpilogue), C.c_void_p, C.c_int32, C.c_int64, C.c_int64,
                                            C.c_int64, C.c_void_p]),
-    "eco_wino_weight_transform": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
-    "eco_wino_input_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
-    "eco_wino_output_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+    "eco_wino_weight_transform": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "eco_wino_input_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "eco_wino_output_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.POINTER(ConvEpilogue), C.c_void_p]),
     "eco_pool_forward": (C.c_int, [C.POINTER(PoolGeom), C.c_void_p, C.c_void_p, C.c_void_p]),
     "eco_bn_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
@@ -231,15 +231,15 @@ class EcoLib:
                                                        batch, stride_x, stride_wp, stride_out, stream))
 
     # -- Winograd F(2x2,3x3) front / back end ----------------------------------
-    def wino_weight_transform(self, w_host: int, cout: int, cin: int, kd: int, u_host: int) -> None:
-        self._check(self._dll.eco_wino_weight_transform(w_host, cout, cin, kd, u_host))
+    def wino_weight_transform(self, w_host: int, cout: int, cin: int, kd: int, tile_m: int, u_host: int) -> None:
+        self._check(self._dll.eco_wino_weight_transform(w_host, cout, cin, kd, tile_m, u_host))
 
-    def wino_input_forward(self, x: int, v: int, planes: int, h: int, w: int, stream=None) -> None:
-        self._check(self._dll.eco_wino_input_forward(x, v, planes, h, w, stream))
+    def wino_input_forward(self, x: int, v: int, planes: int, h: int, w: int, tile_m: int, stream=None) -> None:
+        self._check(self._dll.eco_wino_input_forward(x, v, planes, h, w, tile_m, stream))
 
-    def wino_output_forward(self, m: int, n: int, cout: int, d: int, h: int, w: int, ep: ConvEpilogue,
+    def wino_output_forward(self, m: int, n: int, cout: int, d: int, h: int, w: int, tile_m: int, ep: ConvEpilogue,
                             stream=None) -> None:
-        self._check(self._dll.eco_wino_output_forward(m, n, cout, d, h, w, C.byref(ep), stream))
+        self._check(self._dll.eco_wino_output_forward(m, n, cout, d, h, w, tile_m, C.byref(ep), stream))
 
     # -- stand-alone operators -----------------------------------------------
     def pool_forward(self, g: PoolGeom, x: int, y: int, stream=None) -> None:

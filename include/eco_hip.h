@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 6
+#define ECO_ABI_VERSION 7
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -157,18 +157,20 @@ int eco_conv_forward_batched(const eco_conv_geom* g, const eco_conv_plan* plan, 
                              void* workspace, int32_t batch, int64_t stride_x, int64_t stride_wp,
                              int64_t stride_out, void* stream);
 
-/* ---- Winograd F(2x2,3x3) path for stride-1, pad-1 (kd)x3x3 convolutions (csrc/eco_wino.hip) ----
- * Same result as eco_conv_forward up to fp32 rounding (cudnn_conv_layer.cu:15-65 leaves the algorithm
- * to cuDNN, which picks Winograd for such shapes too).  Tiles: TH = ceil(H/2), TW = ceil(W/2).
- *   u = eco_wino_weight_transform(w)            HOST: u[16][cout][cin][kd] = G g G^T per (co, ci, z)
- *   eco_wino_input_forward(x -> v)              v[16][planes][TH][TW], planes = n*cin*d
- *   eco_conv_forward_batched(v -> m, batch=16)  geometry n, cin->cout, in (d,TH,TW), kernel (kd,1,1),
- *                                               pad (kd/2,0,0); weights = pack(u[p]) per point; raw-only epilogue
- *   eco_wino_output_forward(m -> y)             y tile = A^T m A, then the fused epilogue `ep` */
-int eco_wino_weight_transform(const float* w, int32_t cout, int32_t cin, int32_t kd, float* u);
-int eco_wino_input_forward(const float* x, float* v, int64_t planes, int32_t h, int32_t w, void* stream);
+/* ---- Winograd F(MxM,3x3) path, M = tile_m in {2, 4}, for stride-1, pad-1 (kd)x3x3 convolutions
+ * (csrc/eco_wino.hip).  Same result as eco_conv_forward up to fp32 rounding (cudnn_conv_layer.cu:15-65
+ * leaves the algorithm to cuDNN, which picks Winograd for such shapes too).  T = M + 2 transform points per
+ * dimension; tiles TH = ceil(H/M), TW = ceil(W/M).
+ *   u = eco_wino_weight_transform(w)             HOST: u[T*T][cout][cin][kd] = G g G^T per (co, ci, z)
+ *   eco_wino_input_forward(x -> v)               v[T*T][planes][TH][TW], planes = n*cin*d
+ *   eco_conv_forward_batched(v -> m, batch=T*T)  geometry n, cin->cout, in (d,TH,TW), kernel (kd,1,1),
+ *                                                pad (kd/2,0,0); weights = pack(u[p]) per point; raw-only epilogue
+ *   eco_wino_output_forward(m -> y)              y tile = A^T m A, then the fused epilogue `ep` */
+int eco_wino_weight_transform(const float* w, int32_t cout, int32_t cin, int32_t kd, int32_t tile_m, float* u);
+int eco_wino_input_forward(const float* x, float* v, int64_t planes, int32_t h, int32_t w, int32_t tile_m,
+                           void* stream);
 int eco_wino_output_forward(const float* m, int32_t n, int32_t cout, int32_t d, int32_t h, int32_t w,
-                            const eco_conv_epilogue* ep, void* stream);
+                            int32_t tile_m, const eco_conv_epilogue* ep, void* stream);
 
 /* ---- stand-alone operators (one per reference layer type) -------------------------- */
 

@@ -360,35 +360,36 @@ def test_accuracy_and_softmax_loss(backend, shape, top_k, ignore):
 
 
 # ---- Winograd F(2x2,3x3) path: transforms + 16 batched (kd,1,1) convolutions == the direct convolution ----
-def wino_conv(be, x, w, b, mode="plain", seed=0, num_cu=None):
+def wino_conv(be, x, w, b, M, mode="plain", seed=0, num_cu=None):
     """Run the three-launch Winograd evaluation through the C ABI; returns (raw, act-or-None, expected act fn)."""
     lib = be.lib
     n, cin = x.shape[:2]
     cout, kd = w.shape[0], w.shape[2]
     D, H, W = x.shape[2:]
-    TH, TW = (H + 1) // 2, (W + 1) // 2
-    u = np.zeros((16, cout, cin, kd), np.float32)
-    lib.wino_weight_transform(w.ctypes.data, cout, cin, kd, u.ctypes.data)
+    P = (M + 2) ** 2
+    TH, TW = -(-H // M), -(-W // M)
+    u = np.zeros((P, cout, cin, kd), np.float32)
+    lib.wino_weight_transform(w.ctypes.data, cout, cin, kd, M, u.ctypes.data)
     g = hip.conv_geom(n, cin, cout, (D, TH, TW), (kd, 1, 1), (1, 1, 1), (kd // 2, 0, 0), (D, TH, TW))
     plan = lib.conv_plan(g, num_cu)
     assert plan.mode in (0, 1)
-    wps = np.zeros((16, plan.wp_elems), np.float32)
+    wps = np.zeros((P, plan.wp_elems), np.float32)
     kt = np.zeros(plan.ktab_elems, np.int32)
-    for p in range(16):
+    for p in range(P):
         up = np.ascontiguousarray(u[p].reshape(cout, cin, kd, 1, 1))
         lib.conv_pack_weights(g, plan, up.ctypes.data, wps[p].ctypes.data, kt.ctypes.data)
     tiles_in, tiles_out = n * cin * D * TH * TW, n * cout * D * TH * TW
     dx, dwp, dkt = be.dev(x), be.dev(wps), be.dev(kt)
-    v, m = be.empty((16 * tiles_in,)), be.empty((16 * tiles_out,))
-    ws = be.ptr(be.empty((16 * plan.ws_bytes // 4,))) if plan.ws_bytes else None
-    lib.wino_input_forward(be.ptr(dx), be.ptr(v), n * cin * D, H, W)
+    v, m = be.empty((P * tiles_in,)), be.empty((P * tiles_out,))
+    ws = be.ptr(be.empty((P * plan.ws_bytes // 4,))) if plan.ws_bytes else None
+    lib.wino_input_forward(be.ptr(dx), be.ptr(v), n * cin * D, H, W, M)
     epg = hip.ConvEpilogue()
     epg.bias = None
     epg.residual, epg.act = hip.null_view(), hip.null_view()
     epg.bn_scale = epg.bn_shift = None
     epg.relu = 0
     epg.raw = hip.plain_view(be.ptr(m), cout, D * TH * TW)
-    lib.conv_forward_batched(g, plan, be.ptr(v), be.ptr(dwp), be.ptr(dkt), epg, ws, 16, tiles_in, plan.wp_elems,
+    lib.conv_forward_batched(g, plan, be.ptr(v), be.ptr(dwp), be.ptr(dkt), epg, ws, P, tiles_in, plan.wp_elems,
                              tiles_out)
     S = D * H * W
     ep = hip.ConvEpilogue()
@@ -411,41 +412,50 @@ def wino_conv(be, x, w, b, mode="plain", seed=0, num_cu=None):
         ep.act = hip.plain_view(be.ptr(act), cout, S)
         ep.bn_scale, ep.bn_shift, ep.relu = be.ptr(dsc), be.ptr(dsh), 1
         extra = (res, sc, sh, act)
-    lib.wino_output_forward(be.ptr(m), n, cout, D, H, W, ep)
+    lib.wino_output_forward(be.ptr(m), n, cout, D, H, W, M, ep)
     return be.host(raw, shape), extra, (v, u, plan)
 
 
 @pytest.mark.parametrize("cfg", [(2, 16, 32, (3, 8, 8), 3), (1, 16, 130, (2, 7, 7), 3), (3, 32, 20, (1, 6, 10), 1),
                                  (1, 6, 8, (2, 5, 4), 3)])
 @pytest.mark.parametrize("mode", ["plain", "fused"])
-def test_winograd_path_matches_direct_conv(backend, cfg, mode):
+@pytest.mark.parametrize("M", [2, 4])
+def test_winograd_path_matches_direct_conv(backend, cfg, mode, M):
     n, cin, cout, insp, kd = cfg
     rng = np.random.default_rng(23)
     x = rng.standard_normal((n, cin) + insp).astype(np.float32)
     w = (rng.standard_normal((cout, cin, kd, 3, 3)) / np.sqrt(cin * kd * 9)).astype(np.float32)
     b = rng.standard_normal(cout).astype(np.float32)
     ref = orc.convolution(x, w, b, (kd, 3, 3), (1, 1, 1), (kd // 2, 1, 1))
-    raw, extra, (v, u, plan) = wino_conv(backend, x, w, b, mode, seed=4)
-    # transforms against their definitions
-    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float32)
-    BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float32)
-    uref = np.einsum("ia,kczab,jb->ijkcz", G, w, G).reshape(16, cout, cin, kd)
-    assert relerr(u, uref) < 1e-6
+    raw, extra, (v, u, plan) = wino_conv(backend, x, w, b, M, mode, seed=4)
+    # transforms against their definitions (Lavin & Gray 2015, F(2x2,3x3) and F(4x4,3x3))
+    if M == 2:
+        G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+        BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
+    else:
+        G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                      [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], np.float64)
+        BT = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0],
+                       [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], np.float64)
+    T = M + 2
+    uref = np.einsum("ia,kczab,jb->ijkcz", G, w.astype(np.float64), G).reshape(T * T, cout, cin, kd)
+    assert relerr(u, uref) < 2e-6
     H, W = insp[1:]
-    TH, TW = (H + 1) // 2, (W + 1) // 2
-    xp = np.zeros((n, cin, insp[0], 2 * TH + 2, 2 * TW + 2), np.float32)
+    TH, TW = -(-H // M), -(-W // M)
+    xp = np.zeros((n, cin, insp[0], M * TH + 2, M * TW + 2), np.float64)
     xp[..., 1:H + 1, 1:W + 1] = x
-    tiles = np.stack([np.stack([xp[..., i:i + 2 * TH:2, j:j + 2 * TW:2] for j in range(4)], 0) for i in range(4)], 0)
-    vref = np.einsum("ia,ab...,jb->ij...", BT, tiles, BT).reshape(16, -1)
-    assert relerr(backend.host(v, vref.shape), vref) < 1e-6
+    tiles = np.stack([np.stack([xp[..., i:i + M * TH:M, j:j + M * TW:M] for j in range(T)], 0) for i in range(T)], 0)
+    vref = np.einsum("ia,ab...,jb->ij...", BT, tiles, BT).reshape(T * T, -1)
+    assert relerr(backend.host(v, vref.shape), vref) < 2e-6
+    tol = 2e-5 if M == 2 else 2e-4   # F(4x4): transform constants up to 8 amplify the fp32 rounding
     if mode == "plain":
-        assert relerr(raw, ref) < 2e-5
+        assert relerr(raw, ref) < tol
     else:
         res, sc, sh, act = extra
         exp_raw = ref + res
         bshape = (1, cout, 1, 1, 1)
-        assert relerr(raw, exp_raw) < 2e-5
-        assert relerr(backend.host(act, ref.shape), np.maximum(exp_raw * sc.reshape(bshape) + sh.reshape(bshape), 0)) < 2e-5
+        assert relerr(raw, exp_raw) < tol
+        assert relerr(backend.host(act, ref.shape), np.maximum(exp_raw * sc.reshape(bshape) + sh.reshape(bshape), 0)) < tol
 
 
 def test_batched_conv_equals_separate_launches(backend):

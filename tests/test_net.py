@@ -98,7 +98,7 @@ def test_fused_plan_structure(backend):
     # Winograd route: input transform + 16 batched (3,1,1) convs + output transform with the fused epilogue
     assert len(labels) == 37 + 2 * 3
     wino = [l for l in labels if "winograd" in l or "transformed" in l]
-    assert len(wino) == 9 and "res5b_2+res5b+res5b_bn+res5b_relu [winograd output transform]" in wino
+    assert len(wino) == 9 and "res5b_2+res5b+res5b_bn+res5b_relu [winograd F(4x4,3x3) output transform]" in wino
     direct = make_net(backend, proto, fillers.synthetic_params(spec), True, winograd=False)
     assert len(direct.op_labels()) == 37 and "res5b_2+res5b+res5b_bn+res5b_relu" in direct.op_labels()
     assert "res3b_2+res3b+res3b_bn+res3b_relu" in labels
