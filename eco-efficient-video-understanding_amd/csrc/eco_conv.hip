@@ -875,12 +875,17 @@ static void host_split_layout(const eco_conv_geom* g, int mode, int bn, int sp, 
 }
 
 extern "C" int eco_conv_plan_create(const eco_conv_geom* g, eco_conv_plan* plan) {
-  return eco_conv_plan_create_ex(g, kNumCU, plan);
+  return eco_conv_plan_create_batched(g, kNumCU, 1, plan);
 }
 
 extern "C" int eco_conv_plan_create_ex(const eco_conv_geom* g, int32_t num_cu, eco_conv_plan* plan) {
+  return eco_conv_plan_create_batched(g, num_cu, 1, plan);
+}
+
+extern "C" int eco_conv_plan_create_batched(const eco_conv_geom* g, int32_t num_cu, int32_t batch, eco_conv_plan* plan) {
   clear_error();
   ECO_REQUIRE(num_cu >= 1, "conv: num_cu must be positive");
+  ECO_REQUIRE(batch >= 1, "conv: batch must be positive");
   if (int rc = validate_geom(g)) return rc;
   ECO_REQUIRE(plan != nullptr, "conv: null plan");
   int bm;
@@ -903,7 +908,7 @@ extern "C" int eco_conv_plan_create_ex(const eco_conv_geom* g, int32_t num_cu, e
     // weight loads, fragment reads and barriers per MFMA at 2 workgroups/CU; split-K keeps the CUs busy.
     // With thousands of tiles (res3) 128x128 at 4 workgroups/CU is as fast and quantises better.
     const long ntot_ = (long)g->n * g->out[0] * g->out[1] * g->out[2];
-    if (ceil_div(g->cout, 128) * ceil_div(ntot_, 128) <= 4L * num_cu) plan->bn = 256;
+    if (ceil_div(g->cout, 128) * ceil_div(ntot_, 128) * batch <= 4L * num_cu) plan->bn = 256;
   }
   plan->kc = 16;
   plan->mode = (g->cin % plan->kc == 0) ? ECO_CONV_MODE_CTAP : ECO_CONV_MODE_TABLE;
@@ -960,23 +965,25 @@ extern "C" int eco_conv_plan_create_ex(const eco_conv_geom* g, int32_t num_cu, e
     int max_sp = 16;
     if (max_sp > nstages / 8) max_sp = nstages / 8;
     if (max_sp > ngroups) max_sp = ngroups;
-    if (tiles < slots) {
+    // A batched launch (gridDim.y = batch entries of this plan, e.g. the Winograd transform points) fills the
+    // device with tiles*batch workgroups; every entry gets the same split.
+    if (tiles * batch < slots) {
       double work = 1.0;
       split_wgs(0, 1, &work);
-      const double t_flops = 2.0 * ntot * g->cout * plan->k * work / 100e12;
+      const double t_flops = 2.0 * ntot * g->cout * plan->k * work * batch / 100e12;
       double best = 1e30;
       for (int sp = 1; sp <= max_sp; ++sp) {
-        const long wgs = split_wgs(0, sp, nullptr);
+        const long wgs = split_wgs(0, sp, nullptr) * batch;
         const double eff = ((double)wgs / num_cu) / (double)ceil_div(wgs, num_cu);
-        const double t = t_flops / eff + (sp > 1 ? 2.0 * sp * work * ntot * g->cout * 4.0 / 4e12 + 5e-6 : 0.0);
+        const double t = t_flops / eff + (sp > 1 ? 2.0 * sp * work * ntot * g->cout * 4.0 * batch / 4e12 + 5e-6 : 0.0);
         if (t < best * 0.97) { best = t; plan->ksplit = sp; }  // prefer fewer slices unless >3 % better
       }
       if (plan->ksplit > 1) plan->split_tiles = (int)tiles;
     } else {
-      long rem = tiles % slots;
-      if (rem > 0 && 2 * rem < slots) {
-        rem = ceil_div(rem, mblocks) * mblocks;              // whole columns of M-blocks
-        long sp = slots / rem;
+      const long rem_all = (tiles * batch) % slots;           // stragglers of the last round, all entries
+      if (rem_all > 0 && 2 * rem_all < slots) {
+        long rem = ceil_div(ceil_div(rem_all, batch), mblocks) * mblocks;  // per entry, whole columns of M-blocks
+        long sp = slots / (rem * batch);
         if (sp > max_sp) sp = max_sp;
         if (sp >= 2 && rem < tiles) { plan->ksplit = (int)sp; plan->split_tiles = (int)rem; }
       }

@@ -105,10 +105,21 @@ struct WinoOutArgs {
 };
 
 // One thread per (b, k, d, th, tw): y = A^T m A and the conv epilogue on the M x M outputs that fall inside
-// the image.
-template <int M>
+// the image.  VEC consecutive outputs of a row are moved with one 4*VEC-byte access (the launcher checks that
+// W, the view strides and the pointers allow it), so a wave writes whole 256/512-byte row segments.
+template <int VEC>
+struct WinoVec;
+template <>
+struct WinoVec<1> { typedef float type; };
+template <>
+struct WinoVec<2> { typedef float2 type; };
+template <>
+struct WinoVec<4> { typedef float4 type; };
+
+template <int M, int VEC>
 __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const WinoOutArgs a) {
   constexpr int T = WinoMat<M>::T;
+  typedef typename WinoVec<VEC>::type vec_t;
   const long tiles = (long)a.n * a.cout * a.D * a.TH * a.TW;
   for (long idx = (long)blockIdx.x * kWinoThreads + threadIdx.x; idx < tiles; idx += (long)gridDim.x * kWinoThreads) {
     const int tw = (int)(idx % a.TW);
@@ -137,27 +148,47 @@ __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const WinoOut
       }
     const float b = a.bias ? ld(a.bias + ch) : 0.0f;
     const float sc = a.bn_scale ? ld(a.bn_scale + ch) : 1.0f, sh = a.bn_scale ? ld(a.bn_shift + ch) : 0.0f;
+    const long o_res = a.residual.ptr ? view_base(a.residual, img, 0) + (long)ch * a.residual.stride_c : 0;
+    const long o_raw = a.raw.ptr ? view_base(a.raw, img, 0) + (long)ch * a.raw.stride_c : 0;
+    const long o_act = a.act.ptr ? view_base(a.act, img, 0) + (long)ch * a.act.stride_c : 0;
 #pragma unroll
     for (int p = 0; p < M; ++p) {
       const int h = M * th + p;
       if (h >= a.H) continue;
 #pragma unroll
-      for (int q = 0; q < M; ++q) {
-        const int w = M * tw + q;
-        if (w >= a.W) continue;
-        float y = 0.0f;  // y = s A
+      for (int q0 = 0; q0 < M; q0 += VEC) {
+        const int w0 = M * tw + q0;
+        if (w0 >= a.W) continue;  // W % VEC == 0: the VEC outputs are inside or outside together
+        float val[VEC];
 #pragma unroll
-        for (int k = 0; k < T; ++k)
-          if (WinoMat<M>::AT[q][k] != 0.0f) y += s[p][k] * WinoMat<M>::AT[q][k];
-        const int sp = (d * a.H + h) * a.W + w;
-        float val = y + b;
-        if (a.residual.ptr)
-          val += ld((const float*)a.residual.ptr + view_base(a.residual, img, sp) + (long)ch * a.residual.stride_c);
-        if (a.raw.ptr) st(a.raw.ptr + view_base(a.raw, img, sp) + (long)ch * a.raw.stride_c, val);
+        for (int e = 0; e < VEC; ++e) {
+          float y = 0.0f;  // y = s A
+#pragma unroll
+          for (int k = 0; k < T; ++k)
+            if (WinoMat<M>::AT[q0 + e][k] != 0.0f) y += s[p][k] * WinoMat<M>::AT[q0 + e][k];
+          val[e] = y + b;
+        }
+        const int sp = (d * a.H + h) * a.W + w0;
+        if (a.residual.ptr) {
+          const vec_t rv = ld((const vec_t*)((const float*)a.residual.ptr + o_res + sp));
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) val[e] += ((const float*)&rv)[e];
+        }
+        if (a.raw.ptr) {
+          vec_t ov;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) ((float*)&ov)[e] = val[e];
+          st((vec_t*)(a.raw.ptr + o_raw + sp), ov);
+        }
         if (a.act.ptr) {
-          float o = val * sc + sh;
-          if (a.relu) o = fmaxf(o, 0.0f);
-          st(a.act.ptr + view_base(a.act, img, sp) + (long)ch * a.act.stride_c, o);
+          vec_t ov;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            float o = val[e] * sc + sh;
+            if (a.relu) o = fmaxf(o, 0.0f);
+            ((float*)&ov)[e] = o;
+          }
+          st((vec_t*)(a.act.ptr + o_act + sp), ov);
         }
       }
     }
@@ -239,9 +270,23 @@ extern "C" int eco_wino_output_forward(const float* m, int32_t n, int32_t cout, 
   a.n = n; a.cout = cout; a.D = d; a.H = h; a.W = w;
   a.TH = (h + tile_m - 1) / tile_m; a.TW = (w + tile_m - 1) / tile_m;
   const long tiles = (long)n * cout * d * a.TH * a.TW;
-  if (tile_m == 2)
-    hipLaunchKernelGGL((wino_output_kernel<2>), dim3(wino_grid(tiles)), dim3(kWinoThreads), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL((wino_output_kernel<4>), dim3(wino_grid(tiles)), dim3(kWinoThreads), 0, (hipStream_t)stream, a);
+  // widest access every view allows: W, the strides and the base pointers must be multiples of it
+  int vec = tile_m;
+  auto limit = [&](const eco_view& v) {
+    if (!v.ptr) return;
+    while (vec > 1 && (((uintptr_t)v.ptr % (4 * vec)) || v.stride_b % vec || v.stride_t % vec || v.stride_c % vec)) vec /= 2;
+  };
+  while (vec > 1 && w % vec) vec /= 2;
+  limit(a.residual); limit(a.raw); limit(a.act);
+  const dim3 grid(wino_grid(tiles)), block(kWinoThreads);
+  hipStream_t st_ = (hipStream_t)stream;
+  if (tile_m == 2) {
+    if (vec == 2) hipLaunchKernelGGL((wino_output_kernel<2, 2>), grid, block, 0, st_, a);
+    else hipLaunchKernelGGL((wino_output_kernel<2, 1>), grid, block, 0, st_, a);
+  } else {
+    if (vec == 4) hipLaunchKernelGGL((wino_output_kernel<4, 4>), grid, block, 0, st_, a);
+    else if (vec == 2) hipLaunchKernelGGL((wino_output_kernel<4, 2>), grid, block, 0, st_, a);
+    else hipLaunchKernelGGL((wino_output_kernel<4, 1>), grid, block, 0, st_, a);
+  }
   return check_launch("eco_wino_output_forward");
 }

@@ -389,9 +389,7 @@ class Engine:
         T = M + 2
         TH, TW = -(-H // M), -(-W // M)
         gw = hip.conv_geom(n, g["cin"], g["cout"], (D, TH, TW), (3, 1, 1), (1, 1, 1), (1, 0, 0), (D, TH, TW))
-        # the T*T points run side by side: each sees 1/(T*T) of the CUs when the plan weighs tiles against slots
-        ncu = self.num_cu if self.num_cu is not None else 256
-        plan = self.lib.conv_plan(gw, max(1, ncu // (T * T)))
+        plan = self.lib.conv_plan(gw, self.num_cu, batch=T * T)   # the T*T points share one launch
         old = st.get("wino")
         wn = dict(geom=gw, plan=plan, M=M, points=T * T, TH=TH, TW=TW, v_elems=T * T * n * g["cin"] * D * TH * TW,
                   m_elems=T * T * n * g["cout"] * D * TH * TW)

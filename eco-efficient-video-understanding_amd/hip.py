@@ -21,7 +21,7 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _i32x3 = C.c_int32 * 3
 
@@ -128,6 +128,7 @@ _SIGNATURES = {
     "eco_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "eco_conv_plan_create": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvPlan)]),
     "eco_conv_plan_create_ex": (C.c_int, [C.POINTER(ConvGeom), C.c_int32, C.POINTER(ConvPlan)]),
+    "eco_conv_plan_create_batched": (C.c_int, [C.POINTER(ConvGeom), C.c_int32, C.c_int32, C.POINTER(ConvPlan)]),
     "eco_conv_pack_weights": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvPlan), C.c_void_p, C.c_void_p, C.c_void_p]),
     "eco_conv_forward": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvPlan), C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(ConvEpilogue), C.c_void_p, C.c_void_p]),
@@ -209,12 +210,15 @@ class EcoLib:
         return {"name": name.value.decode(), "num_cu": cu.value, "hbm_bytes": mem.value}
 
     # -- convolution ----------------------------------------------------------
-    def conv_plan(self, g: ConvGeom, num_cu: Optional[int] = None) -> ConvPlan:
+    def conv_plan(self, g: ConvGeom, num_cu: Optional[int] = None, batch: int = 1) -> ConvPlan:
         p = ConvPlan()
-        if num_cu is None:
+        if num_cu is None and batch == 1:
             self._check(self._dll.eco_conv_plan_create(C.byref(g), C.byref(p)))
-        else:
+        elif batch == 1:
             self._check(self._dll.eco_conv_plan_create_ex(C.byref(g), int(num_cu), C.byref(p)))
+        else:
+            self._check(self._dll.eco_conv_plan_create_batched(C.byref(g), 256 if num_cu is None else int(num_cu),
+                                                               int(batch), C.byref(p)))
         return p
 
     def conv_pack_weights(self, g: ConvGeom, p: ConvPlan, w_ptr: int, wp_ptr: int, ktab_ptr: int) -> None:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 7
+#define ECO_ABI_VERSION 8
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -132,6 +132,9 @@ int eco_conv_plan_create(const eco_conv_geom* g, eco_conv_plan* plan);
 /* Same, for a device with `num_cu` compute units (the CPU test-suite uses tiny values to reach the
  * many-tile code paths with emulator-sized problems). */
 int eco_conv_plan_create_ex(const eco_conv_geom* g, int32_t num_cu, eco_conv_plan* plan);
+/* Plan for eco_conv_forward_batched: `batch` entries of this geometry share one launch, so the tile
+ * count that is weighed against the device is tiles * batch. */
+int eco_conv_plan_create_batched(const eco_conv_geom* g, int32_t num_cu, int32_t batch, eco_conv_plan* plan);
 /* HOST function.  Re-lays caffe weights w[cout][cin][kd][kh][kw] (host pointer) into the
  * kernel's K-major image (zero padded; wp[kpad][mpad] for the gather modes, k-pair
  * interleaved wp[kpad/2][mpad][2] for ECO_CONV_MODE_SPAN -- the layout belongs to the plan)
