@@ -145,9 +145,13 @@ def main() -> None:
         "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
         "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
         "kernel_share_of_step": round(dom["ms"] / total_ms, 4),
+        # gflop = algorithmic flops of the direct convolutions (what the reference computes); executed_gflop =
+        # MFMA flops the launches actually issue (Winograd F(4x4,3x3) on the 3-D trunk needs 4x fewer)
         "whole_step": {"gflop": round(total_flops / 1e9, 2),
                        "tflops": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
-                       "frac_of_fp32_mfma_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
+                       "frac_of_fp32_mfma_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                       "executed_gflop": round(sum(p["flops"] for p in prof) / 1e9, 2),
+                       "executed_tflops": round(sum(p["flops"] for p in prof) / (ms_per_step * 1e-3) / 1e12, 2)},
         "per_kernel_ms": {k: round(v["ms"], 3) for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])},
     })
 
