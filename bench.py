@@ -36,6 +36,7 @@ def main() -> None:
     ap.add_argument("--segments", type=int, default=16)
     ap.add_argument("--variant", choices=["lite", "full"], default="lite")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-winograd", action="store_true", help="evaluate every convolution directly (A/B runs)")
     ap.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU sample (0 = auto, 10-30 s)")
     ap.add_argument("--profile-iters", type=int, default=3)
     args = ap.parse_args()
@@ -70,7 +71,7 @@ def main() -> None:
     proto = gen(num_segments=N, num_clips=B)
     spec = NetSpec.from_prototxt(proto)
     params = fillers.synthetic_params(spec)            # same weights on every rank (same seed)
-    net = caffe.Net(proto, caffe.TEST, params=params)
+    net = caffe.Net(proto, caffe.TEST, params=params, winograd=not args.no_winograd)
     # rank r owns clips [r*B, (r+1)*B) of the global batch: a different seed per rank
     frames = fillers.synthetic_frames(B * N, seed=1234 + rank)
     net.blobs["data"].tensor.copy_(torch.from_numpy(frames).to(dev))

@@ -33,8 +33,10 @@ def test_eco_n4_b1_vs_oracle(variant):
     params = fillers.synthetic_params(spec)
     x = fillers.synthetic_frames(4)
     ref = orc.forward(spec, params, {"data": x}, keep="all")
-    for fuse in (True, False):
-        net = Net(proto, params=params, fuse=fuse)
+    # default plan (a single N=4 clip runs every conv directly), the layer-by-layer plan, and the Winograd
+    # route forced onto the 3-D trunk in both tile sizes
+    for fuse, wino in ((True, True), (False, True), (True, 4), (True, 2)):
+        net = Net(proto, params=params, fuse=fuse, winograd=wino)
         net.blobs["data"].data[...] = x
         out = net.forward()["fc8"]
         assert np.isfinite(out).all()
@@ -122,5 +124,5 @@ def test_caffe_time_style_report():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "eco_time.py"), "--segments", "4", "--clips", "1",
                           "--iterations", "2"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    # 37 launches of the direct plan + 2 extra per Winograd convolution (9 stride-1 3x3x3 convs in ECO-Lite)
-    assert "Average Forward pass" in out.stdout and out.stdout.count("forward:") == 37 + 2 * 9
+    # 37 launches: a single N=4 clip is below the Winograd size rule, every convolution runs directly
+    assert "Average Forward pass" in out.stdout and out.stdout.count("forward:") == 37

@@ -36,7 +36,9 @@ def test_mini_eco_matches_oracle(backend, variant, fuse):
     params = fillers.synthetic_params(spec, seed=7)
     x = fillers.synthetic_frames(8, 32, 32, seed=3)
     ref = orc.forward(spec, params, {"data": x}, keep="all", fast_pool=False)
-    net = make_net(backend, proto, params, fuse)
+    # winograd=4 forces the F(4x4,3x3) route on the res5 convs (64 channels here); the default size rule would
+    # evaluate a two-clip 32x32 net directly
+    net = make_net(backend, proto, params, fuse, winograd=4)
     net.blobs["data"].data[...] = x
     out = net.forward()
     assert list(out) == ["fc8"] and out["fc8"].shape == (2, 10)
@@ -92,15 +94,16 @@ def test_fused_plan_structure(backend):
     """The MI355X plan for ECO-Lite: 32 conv launches carry every BN/ReLU/Eltwise/Concat/Permute."""
     proto = mini("lite")
     spec = NetSpec.from_prototxt(proto)
-    net = make_net(backend, proto, fillers.synthetic_params(spec), True)
+    net = make_net(backend, proto, fillers.synthetic_params(spec), True, winograd=4)
     labels = net.op_labels()
     # 32 convs + 4 pools + fused tail; the three res5 stride-1 convs (64 channels in this reduced net) take the
     # Winograd route: input transform + 16 batched (3,1,1) convs + output transform with the fused epilogue
     assert len(labels) == 37 + 2 * 3
     wino = [l for l in labels if "winograd" in l or "transformed" in l]
     assert len(wino) == 9 and "res5b_2+res5b+res5b_bn+res5b_relu [winograd F(4x4,3x3) output transform]" in wino
-    direct = make_net(backend, proto, fillers.synthetic_params(spec), True, winograd=False)
-    assert len(direct.op_labels()) == 37 and "res5b_2+res5b+res5b_bn+res5b_relu" in direct.op_labels()
+    for wg in (False, True):   # True = size rule: two clips of a 32x32 net are too small for the Winograd route
+        direct = make_net(backend, proto, fillers.synthetic_params(spec), True, winograd=wg)
+        assert len(direct.op_labels()) == 37 and "res5b_2+res5b+res5b_bn+res5b_relu" in direct.op_labels()
     assert "res3b_2+res3b+res3b_bn+res3b_relu" in labels
     assert "res4a_down+res4a+res4a_bn+res4a_relu" in labels       # eltwise rides on the later operand
     assert "inception_3c_double_3x3_1+inception_3c_double_3x3_1_bn+inception_3c_relu_double_3x3_1_inp" in labels
