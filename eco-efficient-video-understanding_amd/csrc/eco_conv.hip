@@ -100,8 +100,8 @@ __device__ __forceinline__ void decode_pos(const ConvKernelArgs& a, int n, int& 
 }
 
 // Depth-major launches: the depth taps [zlo, zhi] that touch at least one real input plane for some position
-// of the tile [n0, n0 + bn) (the tile lies in depth planes dlo..dhi; tap z reads plane d + z - pd).  Other
-// position orders: every tap.
+// of the tile [n0, n0 + bn) (the tile lies in output depth planes dlo..dhi; tap z reads input plane
+// d*sd + z - pd).  Other position orders: every tap.
 __device__ __forceinline__ void live_depth_taps(const ConvKernelArgs& a, int n0, int bn, int& zlo, int& zhi) {
   zlo = 0;
   zhi = a.kd - 1;
@@ -109,8 +109,8 @@ __device__ __forceinline__ void live_depth_taps(const ConvKernelArgs& a, int n0,
     const int per_d = a.n_img * a.Ho * a.Wo;
     const int nlast = (n0 + bn < a.ntot ? n0 + bn : a.ntot) - 1;
     const int dlo = n0 / per_d, dhi = nlast / per_d;
-    if (a.pd - dhi > 0) zlo = a.pd - dhi;
-    if (a.Di - 1 + a.pd - dlo < zhi) zhi = a.Di - 1 + a.pd - dlo;
+    if (a.pd - dhi * a.sd > 0) zlo = a.pd - dhi * a.sd;
+    if (a.Di - 1 + a.pd - dlo * a.sd < zhi) zhi = a.Di - 1 + a.pd - dlo * a.sd;
   }
 }
 // Split-K slices of the tiles of column `col` (see ConvKernelArgs).
@@ -326,14 +326,35 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(
     slice = 0;
     nslices = 1;
   } else {
-    const int lid = xcd_remap((int)blockIdx.x - a.n_main, a.n_split * a.ksplit);
-    slice = lid / a.n_split;
-    tile = a.n_main + (lid - slice * a.n_split);
-    nslices = a.ksplit;
+    // (slice, tile) pairs that exist, slice-major: slices [0, ns_short) of every split tile, then slices
+    // [ns_short, ns_long) of the long columns only (depth-major launches: tiles of the first / last depth
+    // plane have fewer live taps and fewer slices) -- numbered densely so that the XCD remap deals every
+    // XCD the same number of live workgroups.  Other launches: ns_short = ns_long = ksplit.
+    const int c0 = a.n_main / a.nblk_m;
+    const int cl0 = a.col_long0 > c0 ? a.col_long0 : c0;
+    const int n_long = (a.col_long1 > cl0 ? a.col_long1 - cl0 : 0) * a.nblk_m;
+    const int n_all = a.n_split * a.ns_short;
+    const int lid = xcd_remap((int)blockIdx.x - a.n_main, n_all + n_long * (a.ns_long - a.ns_short));
+    if (lid < n_all) {
+      slice = lid / a.n_split;
+      tile = a.n_main + (lid - slice * a.n_split);
+    } else {
+      const int r = lid - n_all;
+      slice = a.ns_short + r / n_long;
+      tile = cl0 * a.nblk_m + r % n_long;
+    }
+    nslices = col_slices(a, tile / a.nblk_m);
   }
+  const bool sliced = (int)blockIdx.x >= a.n_main;
   const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
   const int m0 = mblk * BM, n0 = nblk * BN;
-  const int nstages_all = a.kpad / KC;
+  // Reduction work list: stages (channel tile cc, tap) with the tap's depth index in the live range of this
+  // tile (depth-major launches skip the depth taps that see only padding; otherwise every tap), cc-major.
+  const int taps = a.kd * a.kh * a.kw, khw = a.kh * a.kw;
+  int zlo, zhi;
+  live_depth_taps(a, n0, BN, zlo, zhi);
+  const int tap_lo = zlo * khw, taps_live = (zhi - zlo + 1) * khw;
+  const int nstages_all = CTAP ? (a.cin / KC) * taps_live : a.kpad / KC;
   const int c_begin = (int)((long)slice * nstages_all / nslices);
   const int c_end = (int)((long)(slice + 1) * nstages_all / nslices);
 
@@ -345,7 +366,8 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(
   {
     const int n = n0 + pos_l;
     if (n < a.ntot) {
-      const int img = n / a.s_out, sp = n - img * a.s_out;
+      int img, sp;
+      decode_pos(a, n, img, sp);
       const int ow = sp % a.Wo, t = sp / a.Wo;
       const int oh = t % a.Ho, od = t / a.Ho;
       const int id0 = od * a.sd - a.pd, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
@@ -356,18 +378,17 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(
       for (int xx = 0; xx < a.kw; ++xx) mw |= (unsigned long long)((unsigned)(iw0 + xx) < (unsigned)a.Wi) << xx;
       for (int y = 0; y < a.kh; ++y)
         if ((unsigned)(ih0 + y) < (unsigned)a.Hi) mhw |= mw << (y * a.kw);
-      const int khw = a.kh * a.kw;
       for (int z = 0; z < a.kd; ++z)
         if ((unsigned)(id0 + z) < (unsigned)a.Di) mask |= mhw << (z * khw);
     }
   }
 
   // ---- the stage being loaded ----
-  const float* l_wp = a.wp + m0 + (long)c_begin * KC * a.mpad;  // uniform: packed-weight rows of the stage
-  // CTAP: uniform (cc, tap) walk + this thread's predicate / offset
-  const int taps = a.kd * a.kh * a.kw;
-  int l_cc = c_begin / taps, l_tap = c_begin % taps;
-  int l_kx = l_tap % a.kw, l_ky = (l_tap / a.kw) % a.kh, l_kz = l_tap / (a.kw * a.kh);
+  // CTAP: uniform (cc, tap) walk over the live taps + this thread's predicate / offset
+  int l_cc = CTAP ? c_begin / taps_live : 0, l_tap = CTAP ? tap_lo + c_begin % taps_live : 0;
+  int l_kx = l_tap % a.kw, l_ky = (l_tap / a.kw) % a.kh, l_kz = l_tap / khw;
+  // uniform: packed-weight rows of the stage being loaded
+  const float* l_wp = a.wp + m0 + (CTAP ? (long)l_cc * taps + l_tap : (long)c_begin) * KC * a.mpad;
   const float* l_xb = a.x;           // uniform: x + cc*KC*s_in + tap offset
   int l_voff = 0;                    // per thread: base(n) if the tap is inside the image, else the
   unsigned l_ok = 0;                 // offset back to the start of the channel plane (always in bounds)
@@ -396,7 +417,12 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(
         l_kx = 0;
         if (++l_ky == a.kh) {
           l_ky = 0;
-          if (++l_kz == a.kd) { l_kz = 0; l_tap = 0; ++l_cc; }
+          if (++l_kz > zhi) {  // next channel tile: back to the first live tap, skipping the dead ones' rows
+            l_kz = zlo;
+            l_tap = tap_lo;
+            ++l_cc;
+            l_wp += (long)(taps - taps_live) * KC * a.mpad;
+          }
         }
       }
     } else {
@@ -505,7 +531,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(
       sched_fence();
     }
   }
-  if (nslices > 1)
+  if (sliced)
     conv_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
   else
     conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
@@ -835,15 +861,21 @@ static int validate_geom(const eco_conv_geom* g) {
 using namespace eco;
 
 // Live depth taps of tile column `col` (bn positions wide) of a depth-major span launch; kd otherwise.
+// Depth-major position order (and dead depth-tap skipping): 3-deep kernels of the span and constant-tap kernels.
+static bool host_dmajor(const eco_conv_geom* g, int mode) {
+  return (mode == ECO_CONV_MODE_SPAN || mode == ECO_CONV_MODE_CTAP) && g->kernel[0] == 3;
+}
+
 static int host_col_nz(const eco_conv_geom* g, int mode, int bn, long col) {
   const int kd = g->kernel[0];
-  if (!(mode == ECO_CONV_MODE_SPAN && kd == 3)) return kd;
+  if (!host_dmajor(g, mode)) return kd;
   const long ntot = (long)g->n * g->out[0] * g->out[1] * g->out[2];
   const long per_d = (long)g->n * g->out[1] * g->out[2];
   const long n0 = col * bn, nlast = (n0 + bn < ntot ? n0 + bn : ntot) - 1;
   const long dlo = n0 / per_d, dhi = nlast / per_d;
-  const long zlo = g->pad[0] - dhi > 0 ? g->pad[0] - dhi : 0;
-  const long zhi = g->in[0] - 1 + g->pad[0] - dlo < kd - 1 ? g->in[0] - 1 + g->pad[0] - dlo : kd - 1;
+  const long sd = g->stride[0];
+  const long zlo = g->pad[0] - dhi * sd > 0 ? g->pad[0] - dhi * sd : 0;
+  const long zhi = g->in[0] - 1 + g->pad[0] - dlo * sd < kd - 1 ? g->in[0] - 1 + g->pad[0] - dlo * sd : kd - 1;
   return (int)(zhi - zlo + 1);
 }
 
@@ -1093,7 +1125,7 @@ static int conv_forward_impl(const eco_conv_geom* g, const eco_conv_plan* plan, 
   a.ntot = g->n * a.s_out;
   a.n_img = g->n;
   a.bn_tile = plan->bn;
-  a.dmajor = (plan->mode == ECO_CONV_MODE_SPAN && g->kernel[0] == 3) ? 1 : 0;
+  a.dmajor = host_dmajor(g, plan->mode) ? 1 : 0;
   a.nblk_m = (int)ceil_div(g->cout, plan->bm);
   a.nblk_n = (int)ceil_div(a.ntot, plan->bn);
   ECO_REQUIRE((long)a.nblk_m * plan->bm <= plan->mpad, "conv: plan mpad too small for bm");

@@ -17,7 +17,7 @@ def relerr(got, ref):
     return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
 
 
-def run_conv(be, n, cin, cout, insp, k, s, p, mode="plain", seed=0, num_cu=None):
+def run_conv(be, n, cin, cout, insp, k, s, p, mode="plain", seed=0, num_cu=None, tweak=None):
     rng = np.random.default_rng(seed)
     nd = len(insp)
     x = rng.standard_normal((n, cin) + tuple(insp)).astype(np.float32)
@@ -29,6 +29,8 @@ def run_conv(be, n, cin, cout, insp, k, s, p, mode="plain", seed=0, num_cu=None)
     lib = be.lib
     g = hip.conv_geom(n, cin, cout, insp, k, s, p, outsp)
     plan = lib.conv_plan(g, num_cu)
+    if tweak:
+        tweak(plan)
     wp = np.zeros(plan.wp_elems, np.float32)
     kt = np.zeros(plan.ktab_elems, np.int32)
     lib.conv_pack_weights(g, plan, w.ctypes.data, wp.ctypes.data, kt.ctypes.data)
@@ -107,6 +109,10 @@ SMALL_CONVS = [
     (3, 16, 32, (3, 10, 10), (3, 3, 3), (1, 1, 1), (1, 1, 1)),  # 4 tiles: d=0 | d=0..1 | d=1..2 | d=2
     (5, 16, 40, (1, 8, 8), (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # one plane: only the centre depth tap is live
     (3, 64, 128, (2, 7, 7), (3, 3, 3), (1, 1, 1), (1, 1, 1)),   # split-K slices, plane size 49 (scalar reduce)
+    # the same for the gather kernel: strided 3x3x3 and the (3,1,1) convs of the Winograd route
+    (6, 16, 128, (6, 9, 9), (3, 3, 3), (2, 2, 2), (1, 1, 1)),   # out 3x5x5: tile 0 = plane 0 only -> depth tap 0 dead
+    (8, 16, 128, (4, 4, 4), (3, 1, 1), (1, 1, 1), (1, 0, 0)),   # tiles = depth planes: first skips z=0, last skips z=2
+    (8, 32, 128, (2, 4, 4), (3, 1, 1), (1, 1, 1), (1, 0, 0)),   # two planes, two live taps each
 ]
 
 
@@ -117,7 +123,7 @@ def test_conv_plain(backend, cfg):
 
 @pytest.mark.parametrize("cfg", [SMALL_CONVS[3], SMALL_CONVS[5], SMALL_CONVS[6], SMALL_CONVS[9], SMALL_CONVS[10],
                                  SMALL_CONVS[11], SMALL_CONVS[12], SMALL_CONVS[14], SMALL_CONVS[16], SMALL_CONVS[19],
-                                 SMALL_CONVS[20], SMALL_CONVS[21]])
+                                 SMALL_CONVS[20], SMALL_CONVS[21], SMALL_CONVS[22], SMALL_CONVS[23], SMALL_CONVS[24]])
 def test_conv_fused_epilogue(backend, cfg):
     run_conv(backend, *cfg, mode="fused", seed=1)
 
@@ -171,6 +177,21 @@ TAIL_SPLIT = [
 def test_conv_tail_split(backend, num_cu, cfg, split_tiles, ksplit, mode):
     plan = run_conv(backend, *cfg, mode=mode, seed=5, num_cu=num_cu)
     assert (plan.split_tiles, plan.ksplit) == (split_tiles, ksplit) and plan.ws_bytes > 0
+
+
+@pytest.mark.parametrize("mode", ["plain", "fused"])
+def test_conv_gather_split_with_dead_depth_taps(backend, mode):
+    """Gather kernel, depth-major order, every tile split: first / last plane tiles have 2 live depth taps of 3 and
+    get ceil(ksplit*2/3) slices, numbered densely; the reduce kernel sums each position's own slice count."""
+    cfg = (8, 128, 128, (4, 4, 4), (3, 1, 1), (1, 1, 1), (1, 0, 0))
+    ntot = 8 * 64
+
+    def force_split(plan):   # 128-wide tiles = one depth plane each, 3-way split of every tile
+        plan.bn, plan.ksplit = 128, 3
+        plan.split_tiles = -(-128 // plan.bm) * -(-ntot // plan.bn)
+        plan.ws_bytes = 3 * 128 * ntot * 4
+    plan = run_conv(backend, *cfg, mode=mode, seed=9, tweak=force_split)
+    assert plan.mode == 1 and (plan.bm, plan.bn, plan.split_tiles) == (128, 128, 4)
 
 
 def _dummy_epilogue():
