@@ -45,13 +45,24 @@ struct WinoMat<4> {
   static constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
 };
 
+template <int VEC>
+struct WinoVec;
+template <>
+struct WinoVec<1> { typedef float type; };
+template <>
+struct WinoVec<2> { typedef float2 type; };
+template <>
+struct WinoVec<4> { typedef float4 type; };
+
 // One thread per (b, c, d, th, tw): T x T input tile at rows M*th-1.., cols M*tw-1.. (zero outside the image),
 // v = B^T d B scattered to the T*T transform planes.  The matrices are compile-time constants: zero terms
-// vanish and +-1 terms become adds when the loops are unrolled.
-template <int M>
+// vanish and +-1 terms become adds when the loops are unrolled.  The M middle columns of a tile row start at a
+// multiple of M, so they are fetched with 4*VEC-byte loads when W % VEC == 0 (launcher's choice).
+template <int M, int VEC>
 __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* x, float* v, long planes /* b*c*d */,
                                                                   int H, int W, int TH, int TW) {
   constexpr int T = WinoMat<M>::T;
+  typedef typename WinoVec<VEC>::type vec_t;
   const long tiles = planes * TH * TW;
   for (long idx = (long)blockIdx.x * kWinoThreads + threadIdx.x; idx < tiles; idx += (long)gridDim.x * kWinoThreads) {
     const int tw = (int)(idx % TW);
@@ -63,11 +74,19 @@ __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* x
 #pragma unroll
     for (int i = 0; i < T; ++i) {
       const int h = M * th - 1 + i;
+      const bool hok = (unsigned)h < (unsigned)H;
+      const float* rp = xp + (hok ? (long)h * W : 0l);
+      const int wl = M * tw - 1, wr = M * tw + M;  // the two edge columns
+      const bool lok = hok && wl >= 0, rok = hok && wr < W;
+      d[i][0] = lok ? ld(rp + (lok ? wl : 0)) : 0.0f;
+      d[i][T - 1] = rok ? ld(rp + (rok ? wr : 0)) : 0.0f;
 #pragma unroll
-      for (int j = 0; j < T; ++j) {
-        const int w = M * tw - 1 + j;
-        const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
-        d[i][j] = ok ? ld(xp + (ok ? (long)h * W + w : 0l)) : 0.0f;
+      for (int j0 = 0; j0 < M; j0 += VEC) {
+        const int w0 = M * tw + j0;
+        const bool ok = hok && w0 < W;  // W % VEC == 0: the VEC columns are inside or outside together
+        vec_t q = ld((const vec_t*)(rp + (ok ? w0 : 0)));
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) d[i][1 + j0 + e] = ok ? ((const float*)&q)[e] : 0.0f;
       }
     }
     float t[T][T];  // t = B^T d
@@ -107,15 +126,6 @@ struct WinoOutArgs {
 // One thread per (b, k, d, th, tw): y = A^T m A and the conv epilogue on the M x M outputs that fall inside
 // the image.  VEC consecutive outputs of a row are moved with one 4*VEC-byte access (the launcher checks that
 // W, the view strides and the pointers allow it), so a wave writes whole 256/512-byte row segments.
-template <int VEC>
-struct WinoVec;
-template <>
-struct WinoVec<1> { typedef float type; };
-template <>
-struct WinoVec<2> { typedef float2 type; };
-template <>
-struct WinoVec<4> { typedef float4 type; };
-
 template <int M, int VEC>
 __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const WinoOutArgs a) {
   constexpr int T = WinoMat<M>::T;
@@ -244,13 +254,19 @@ extern "C" int eco_wino_input_forward(const float* x, float* v, int64_t planes, 
   ECO_REQUIRE(x && v && planes > 0 && h > 0 && w > 0, "winograd input transform: bad argument");
   ECO_REQUIRE(tile_m == 2 || tile_m == 4, "winograd: output tile must be 2 or 4, got %d", tile_m);
   const int TH = (h + tile_m - 1) / tile_m, TW = (w + tile_m - 1) / tile_m;
-  const dim3 grid(wino_grid(planes * TH * TW));
-  if (tile_m == 2)
-    hipLaunchKernelGGL((wino_input_kernel<2>), grid, dim3(kWinoThreads), 0, (hipStream_t)stream, x, v, (long)planes, h, w,
-                       TH, TW);
-  else
-    hipLaunchKernelGGL((wino_input_kernel<4>), grid, dim3(kWinoThreads), 0, (hipStream_t)stream, x, v, (long)planes, h, w,
-                       TH, TW);
+  const dim3 grid(wino_grid(planes * TH * TW)), block(kWinoThreads);
+  hipStream_t st_ = (hipStream_t)stream;
+  int vec = tile_m;
+  while (vec > 1 && (w % vec || ((uintptr_t)x % (4 * vec)))) vec /= 2;
+  const long pl = (long)planes;
+  if (tile_m == 2) {
+    if (vec == 2) hipLaunchKernelGGL((wino_input_kernel<2, 2>), grid, block, 0, st_, x, v, pl, h, w, TH, TW);
+    else hipLaunchKernelGGL((wino_input_kernel<2, 1>), grid, block, 0, st_, x, v, pl, h, w, TH, TW);
+  } else {
+    if (vec == 4) hipLaunchKernelGGL((wino_input_kernel<4, 4>), grid, block, 0, st_, x, v, pl, h, w, TH, TW);
+    else if (vec == 2) hipLaunchKernelGGL((wino_input_kernel<4, 2>), grid, block, 0, st_, x, v, pl, h, w, TH, TW);
+    else hipLaunchKernelGGL((wino_input_kernel<4, 1>), grid, block, 0, st_, x, v, pl, h, w, TH, TW);
+  }
   return check_launch("eco_wino_input_forward");
 }
 
