@@ -101,14 +101,6 @@ __device__ __forceinline__ void st(T* p, T v) {
   float* name = (float*)name##_raw
 #endif
 
-// Wave priority for instruction arbitration on the SIMD (s_setprio): raised around MFMA clusters so that the
-// matrix pipe is fed ahead of other waves' loads / address arithmetic.
-#ifdef ECO_EMU
-#define ECO_SETPRIO(p) ((void)0)
-#else
-#define ECO_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
-#endif
-
 // Hide a per-lane integer from the optimiser.  Used on LDS fragment indices: two 8-byte reads off the same
 // base register get merged into ds_read2_b64, which the LDS serves at half the rate of two ds_read_b64.
 #ifdef ECO_EMU

@@ -56,7 +56,7 @@ def main() -> None:
         fl, by = p.get("flops", 0), p.get("bytes", 0)
         floor = max(fl / PEAK_FP32_MFMA, by / PEAK_HBM) * 1e3
         frac = f"{floor / ms:5.2f}" if ms > 0 and floor > 0 else "    -"
-        print(f"{p['label'][:44]:>44s}\tforward: {ms:8.4f} ms.  {fl / 1e9:9.3f} GFLOP {by / 1e6:9.2f} MB  "
+        print(f"{p['label']:>44s}\tforward: {ms:8.4f} ms.  {fl / 1e9:9.3f} GFLOP {by / 1e6:9.2f} MB  "
               f"roofline frac {frac}  [{p.get('kernel', '')}]")
     flops = spec.conv_fc_flops()
     print(f"Average Forward pass: {tot:.4f} ms.  ({flops / 1e9:.1f} GFLOP -> {flops / tot / 1e9:.1f} TFLOP/s, "
