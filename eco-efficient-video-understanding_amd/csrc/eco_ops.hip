@@ -117,27 +117,29 @@ __global__ __launch_bounds__(256) void maxpool2d_k3s2_kernel(const float* x, flo
   }
 }
 
-// 2-D AVE 3x3 stride 1 pad 1 (inception *_pool): VEC consecutive outputs per thread; per row one vector
-// load plus the two neighbours.  Zero padding, divisor 9 everywhere (the reference's window size
-// including padding, pooling_layer.cpp:247-262, equals 9 for every position of this geometry).
+// 2-D AVE 3x3 stride 1 pad 1 (inception *_pool): VEC consecutive outputs of kAvgRows consecutive rows per thread.
+// Every input row is fetched once per thread (one vector load plus the two neighbours) and its horizontal
+// 3-sums feed up to three output rows, so the rows are read 1.5x instead of 3x.  Zero padding, divisor 9
+// everywhere (the reference's window size including padding, pooling_layer.cpp:247-262, equals 9 for every
+// position of this geometry); rows are accumulated top to bottom as before.
+constexpr int kAvgRows = 4;
 template <int VEC>
 __global__ __launch_bounds__(256) void avgpool2d_k3s1p1_kernel(const float* x, float* y, long planes, int H, int W) {
   const int wq = W / VEC;
-  const long total = planes * H * wq;
+  const int hq = (H + kAvgRows - 1) / kAvgRows;
+  const long total = planes * hq * wq;
   for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
     const int q = (int)(i % wq);
     const long t = i / wq;
-    const int oh = (int)(t % H);
-    const long pl = t / H;
+    const int oh0 = (int)(t % hq) * kAvgRows;
+    const long pl = t / hq;
     const float* xp = x + pl * H * W + VEC * q;
-    float sum[VEC];
+    float rs[kAvgRows + 2][VEC];  // horizontal 3-sums of input rows oh0-1 .. oh0+kAvgRows
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) sum[e] = 0.0f;
-#pragma unroll
-    for (int r = -1; r <= 1; ++r) {
-      const int h = oh + r;
-      if (h < 0 || h >= H) continue;
-      const float* row = xp + (long)h * W;
+    for (int r = 0; r < kAvgRows + 2; ++r) {
+      const int h = oh0 - 1 + r;
+      const bool ok = h >= 0 && h < H;
+      const float* row = xp + (ok ? (long)h * W : 0l);
       float in[VEC + 2], mid[VEC];
       ld_vec<VEC>(row, mid);
       in[0] = (q > 0) ? ld(row - 1) : 0.0f;
@@ -145,12 +147,18 @@ __global__ __launch_bounds__(256) void avgpool2d_k3s1p1_kernel(const float* x, f
       for (int e = 0; e < VEC; ++e) in[1 + e] = mid[e];
       in[VEC + 1] = (VEC * q + VEC < W) ? ld(row + VEC) : 0.0f;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) sum[e] += in[e] + in[e + 1] + in[e + 2];
+      for (int e = 0; e < VEC; ++e) rs[r][e] = ok ? in[e] + in[e + 1] + in[e + 2] : 0.0f;
     }
     const float inv = 1.0f / 9.0f;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) sum[e] *= inv;
-    st_vec<VEC>(y + (pl * H + oh) * W + VEC * q, sum);
+    for (int o = 0; o < kAvgRows; ++o) {
+      const int oh = oh0 + o;
+      if (oh >= H) break;
+      float sum[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) sum[e] = ((0.0f + rs[o][e]) + rs[o + 1][e] + rs[o + 2][e]) * inv;
+      st_vec<VEC>(y + (pl * H + oh) * W + VEC * q, sum);
+    }
   }
 }
 
@@ -448,12 +456,13 @@ extern "C" int eco_pool_forward(const eco_pool_geom* g, const float* x, float* y
   }
   if (two_d && aligned && g->method == ECO_POOL_AVE && g->kernel[1] == 3 && g->kernel[2] == 3 && g->stride[1] == 1 &&
       g->stride[2] == 1 && g->pad[1] == 1 && g->pad[2] == 1 && g->in[2] % 2 == 0 && g->in[1] >= 2 && g->in[2] >= 4) {
+    const long hq = (g->in[1] + kAvgRows - 1) / kAvgRows;
     if (g->in[2] % 4 == 0) {
-      const long total = rows * g->in[1] * (g->in[2] / 4);
+      const long total = rows * hq * (g->in[2] / 4);
       hipLaunchKernelGGL((avgpool2d_k3s1p1_kernel<4>), dim3(grid_for(total)), dim3(kThreads), 0, s, x, y, rows,
                          g->in[1], g->in[2]);
     } else {  // e.g. 14x14: 8-byte accesses
-      const long total = rows * g->in[1] * (g->in[2] / 2);
+      const long total = rows * hq * (g->in[2] / 2);
       hipLaunchKernelGGL((avgpool2d_k3s1p1_kernel<2>), dim3(grid_for(total)), dim3(kThreads), 0, s, x, y, rows,
                          g->in[1], g->in[2]);
     }
