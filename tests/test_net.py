@@ -114,6 +114,29 @@ def test_fused_plan_structure(backend):
         assert keep in net._engine.tensors, keep  # dual outputs / concat tops / permuted volume exist
 
 
+def test_reshape_grows_winograd_buffers(backend):
+    """net.reshape() to a larger clip batch re-plans the Winograd route (transformed-volume scratch, batched
+    plans, per-point weights) and still matches the oracle; shrinking back reuses the storage."""
+    params = None
+    outs = {}
+    net = None
+    for clips in (1, 3, 1):
+        proto = mini("lite", num_clips=clips)
+        spec = NetSpec.from_prototxt(proto)
+        if params is None:
+            params = fillers.synthetic_params(spec, seed=2)
+            net = make_net(backend, proto, params, True, winograd=4)
+        else:
+            net.blobs["data"].reshape(4 * clips, 3, 32, 32)
+            net.reshape()
+        x = fillers.synthetic_frames(4 * clips, 32, 32, seed=clips)
+        ref = orc.forward(spec, params, {"data": x}, fast_pool=False)["fc8"]
+        net.blobs["data"].data[...] = x
+        got = net.forward()["fc8"]
+        assert got.shape == (clips, 10) and relerr(got, ref) < TOL
+        outs[clips] = got.copy()
+
+
 def test_pycaffe_surface(backend):
     proto = mini("lite")
     spec = NetSpec.from_prototxt(proto)
