@@ -177,7 +177,7 @@ class Engine:
                     self.alloc.upload(st["bias"], blobs[1])
                 wn = st.get("wino")
                 if wn is not None:  # u[p] = (G g G^T)[p], each point packed for the (kd,1,1) gather kernel
-                    cout, cin, kd = L.geom["cout"], L.geom["cin"], L.geom["kernel"][0]
+                    cout, cin, kd = L.geom["cout"], L.geom["cin"], wn["kd"]
                     P = wn["points"]
                     u = np.empty((P, cout, cin, kd), np.float32)
                     self.lib.wino_weight_transform(w.ctypes.data, cout, cin, kd, wn["M"], u.ctypes.data)
@@ -371,36 +371,49 @@ class Engine:
             raise NetSpecError(f"no HIP launcher for layer type {t}")
 
     # -- Winograd F(2x2,3x3) path (csrc/eco_wino.hip) ---------------------------------
+    @staticmethod
+    def _wino_dims(L: LayerSpec):
+        """(n, D, H, W, kd) of a stride-1 pad-1 (3x)3x3 convolution's input, D = kd = 1 for 2-D blobs."""
+        shp = L.bottom_shapes[0]
+        return (shp[0], shp[2], shp[3], shp[4], 3) if len(shp) == 5 else (shp[0], 1, shp[2], shp[3], 1)
+
     def _wino_eligible(self, L: LayerSpec) -> bool:
-        """Stride-1, pad-1 3x3x3 convolutions of 5-D blobs with enough channels for the 16 transformed
-        (3,1,1) convolutions (K = 3*cin) to run efficiently: the res3/res4/res5 stride-1 convs.  The 2-D 3x3
-        convs (K = cin = 64..96 per transform point) stay on the direct span kernel."""
+        """Stride-1, pad-1 3x3x3 / 3x3 convolutions whose transformed point-convolutions have a long enough
+        reduction to run efficiently: K = 3*cin >= 192 for the 3-D trunk (res3/res4/res5 stride-1 convs),
+        K = cin >= 128 and cout <= 2*cin for 2-D convs (ECO-Full's 14x14 / 7x7 inception stream).  ECO-Lite's 2-D
+        3x3 convs (cin = 64..96, cout >= cin) stay on the direct span kernel: 4-6 stages per tile and a
+        transformed output volume larger than the input's cost more than the algorithm saves."""
         g = L.geom
-        if not (self.winograd and len(L.bottom_shapes[0]) == 5 and tuple(g["kernel"]) == (3, 3, 3) and
-                tuple(g["stride"]) == (1, 1, 1) and tuple(g["pad"]) == (1, 1, 1) and g["cin"] % 16 == 0 and
-                g["cin"] >= 64 and tuple(L.top_shapes[0][2:]) == tuple(L.bottom_shapes[0][2:])):
+        nd = len(L.bottom_shapes[0]) - 2
+        if not (self.winograd and nd in (2, 3) and tuple(g["kernel"]) == (3,) * nd and
+                tuple(g["stride"]) == (1,) * nd and tuple(g["pad"]) == (1,) * nd and g["cin"] % 16 == 0 and
+                tuple(L.top_shapes[0][2:]) == tuple(L.bottom_shapes[0][2:])):
+            return False
+        if nd == 3 and g["cin"] < 64:
+            return False
+        if nd == 2 and (g["cin"] < 128 or g["cout"] > 2 * g["cin"]):
             return False
         # each transform point is a GEMM over n*D*ceil(H/M)*ceil(W/M) tile positions in 128/256-wide tiles: with
         # a clip or two the deeper stages would be mostly tile padding (measured: a single clip is 8 % faster
         # direct, two clips 16 % faster with Winograd); an explicit winograd=2/4 overrides the size rule
         if self.winograd is True:
-            n, _, D, H, W = L.bottom_shapes[0]
+            n, D, H, W, _ = self._wino_dims(L)
             return n * D * -(-H // 4) * -(-W // 4) >= 256
         return True
 
     def _plan_wino(self, L: LayerSpec, st: dict) -> None:
         g = L.geom
-        n, _, D, H, W = L.bottom_shapes[0]
+        n, D, H, W, kd = self._wino_dims(L)
         # output tile: F(4x4,3x3) does 4x fewer multiplies than direct (F(2x2): 2.25x) and its transformed
         # volumes are 2.25x the activations (F(2x2): 4x); planes that do not tile by 4 pay ceil() padding
         M = self.winograd if self.winograd in (2, 4) else 4
         T = M + 2
         TH, TW = -(-H // M), -(-W // M)
-        gw = hip.conv_geom(n, g["cin"], g["cout"], (D, TH, TW), (3, 1, 1), (1, 1, 1), (1, 0, 0), (D, TH, TW))
+        gw = hip.conv_geom(n, g["cin"], g["cout"], (D, TH, TW), (kd, 1, 1), (1, 1, 1), (kd // 2, 0, 0), (D, TH, TW))
         plan = self.lib.conv_plan(gw, self.num_cu, batch=T * T)   # the T*T points share one launch
         old = st.get("wino")
-        wn = dict(geom=gw, plan=plan, M=M, points=T * T, TH=TH, TW=TW, v_elems=T * T * n * g["cin"] * D * TH * TW,
-                  m_elems=T * T * n * g["cout"] * D * TH * TW)
+        wn = dict(geom=gw, plan=plan, M=M, points=T * T, TH=TH, TW=TW, kd=kd,
+                  v_elems=T * T * n * g["cin"] * D * TH * TW, m_elems=T * T * n * g["cout"] * D * TH * TW)
         if old is not None and (old["points"], old["plan"].wp_elems, old["plan"].ktab_elems) == \
                 (T * T, plan.wp_elems, plan.ktab_elems):
             wn["wp"], wn["ktab"] = old["wp"], old["ktab"]
@@ -414,8 +427,8 @@ class Engine:
         wn = st["wino"]
         gw, plan, M, P = wn["geom"], wn["plan"], wn["M"], wn["points"]
         lib = self.lib
-        n, cin, D, H, W = L.bottom_shapes[0]
-        cout = L.geom["cout"]
+        n, D, H, W, kd = self._wino_dims(L)
+        cin, cout = L.geom["cin"], L.geom["cout"]
         x = self._ptr(L.bottoms[0])
         v, m = self.alloc.ptr(self._wino_buf_v_elems), self.alloc.ptr(self._wino_buf_m_elems)
         wp, kt = self.alloc.ptr(wn["wp"]), self.alloc.ptr(wn["ktab"])
@@ -432,15 +445,15 @@ class Engine:
         self._add(i, f"{label} [winograd {tag} input transform]", lambda s, x=x, v=v, pl=n * cin * D, H=H, W=W, M=M:
                   lib.wino_input_forward(x, v, pl, H, W, M, s),
                   {"kernel": f"eco::wino_input_kernel<{M}>", "flops": 0, "bytes": 4 * (n * cin * D * H * W + P * tin)})
-        self._add(i, f"{label} [{P} transformed (3,1,1) convs]",
+        self._add(i, f"{label} [{P} transformed ({kd},1,1) convs]",
                   lambda s, gw=gw, plan=plan, v=v, wp=wp, kt=kt, epg=epg, ws=ws, tin=tin, tout=tout, P=P:
                   lib.conv_forward_batched(gw, plan, v, wp, kt, epg, ws, P, tin, plan.wp_elems, tout, s),
-                  {"kernel": hip.conv_kernel_name(plan), "flops": 2 * P * tout * cin * 3,
-                   "bytes": 4 * (P * tin + P * cout * cin * 3 + P * tout)})
+                  {"kernel": hip.conv_kernel_name(plan), "flops": 2 * P * tout * cin * kd,
+                   "bytes": 4 * (P * tin + P * cout * cin * kd + P * tout)})
         self._add(i, f"{label} [winograd {tag} output transform]",
                   lambda s, m=m, n=n, cout=cout, D=D, H=H, W=W, M=M, ep=ep: lib.wino_output_forward(m, n, cout, D, H, W, M, ep, s),
                   {"kernel": f"eco::wino_output_kernel<{M}>", "flops": 0,
-                   "bytes": 4 * P * tout + nbytes - 4 * (n * cin * D * H * W + 27 * cin * cout)})
+                   "bytes": 4 * P * tout + nbytes - 4 * (n * cin * D * H * W + 9 * kd * cin * cout)})
 
     def _emit_conv(self, i: int, L: LayerSpec, ep: "hip.ConvEpilogue", label: str) -> None:
         st = self._param_dev[L.name]

@@ -114,6 +114,30 @@ def test_fused_plan_structure(backend):
         assert keep in net._engine.tensors, keep  # dual outputs / concat tops / permuted volume exist
 
 
+def test_winograd_route_for_wide_2d_convs(backend):
+    """2-D 3x3 stride-1 convs with cin >= 128 (ECO-Full's inception 4x/5x stream) take the Winograd route too:
+    input transform, T*T batched 1x1 convs, output transform carrying BN + ReLU and a Concat-slice store."""
+    proto = """name: "wide2d"
+input: "data" input_dim: 3 input_dim: 128 input_dim: 9 input_dim: 10
+layer { name: "c1" type: "Convolution" bottom: "data" top: "c1" convolution_param { num_output: 144 kernel_size: 3 pad: 1 } }
+layer { name: "c1_bn" type: "BN" bottom: "c1" top: "c1_bn" bn_param { frozen: true } }
+layer { name: "c1_relu" type: "ReLU" bottom: "c1_bn" top: "c1_bn" }
+layer { name: "c2" type: "Convolution" bottom: "data" top: "c2" convolution_param { num_output: 32 kernel_size: 1 } }
+layer { name: "cat" type: "Concat" bottom: "c1_bn" bottom: "c2" top: "cat" }
+"""
+    spec = NetSpec.from_prototxt(proto)
+    params = fillers.synthetic_params(spec, seed=5)
+    x = np.random.default_rng(1).standard_normal((3, 128, 9, 10)).astype(np.float32)
+    ref = orc.forward(spec, params, {"data": x}, keep="all", fast_pool=False)
+    for wg, tol in ((4, 2e-4), (2, TOL), (False, TOL)):
+        net = make_net(backend, proto, params, True, winograd=wg)
+        labels = net.op_labels()
+        assert any("winograd" in l for l in labels) == bool(wg), labels
+        net.blobs["data"].data[...] = x
+        out = net.forward()["cat"]
+        assert out.shape == (3, 176, 9, 10) and relerr(out, ref["cat"]) < tol
+
+
 def test_reshape_grows_winograd_buffers(backend):
     """net.reshape() to a larger clip batch re-plans the Winograd route (transformed-volume scratch, batched
     plans, per-point weights) and still matches the oracle; shrinking back reuses the storage."""
