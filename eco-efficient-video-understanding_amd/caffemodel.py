@@ -10,6 +10,13 @@ Only what ``Net::CopyTrainedLayersFrom`` / ``Net::ToProto`` need for the ECO pat
                 legacy num/channels/height/width = 1..4 }
 
 Weights are matched to the net by *layer name*, exactly like the reference.
+
+BN blob styles.  This fork's BN layer keeps (scale, shift, running mean, running **variance**)
+(bn_layer.cpp:29-41,138-164); older releases of the same layer kept the running **inverse std**
+1/sqrt(var + eps) in the fourth blob, and the reference ships the converter between the two
+(caffe_3d/python/bn_convert_style.py:13-30; gen_bn_inference.py:121-134 takes the style as a flag).
+``convert_bn_style`` is that converter on a parameter dict; ``Net.copy_from(path, bn_style="inv_std")``
+applies it while loading so that an inv-std-style file is not silently read as variances.
 """
 from __future__ import annotations
 
@@ -21,6 +28,39 @@ import numpy as np
 
 class CaffemodelError(ValueError):
     pass
+
+
+BN_STYLES = ("variance", "inv_std")
+
+
+def convert_bn_style(params: Dict[str, List[np.ndarray]], bn_layers, conversion: str,
+                     eps: float = 1e-5) -> Dict[str, List[np.ndarray]]:
+    """bn_convert_style.py:13-30 on a {layer: [blobs]} dict: for every layer in ``bn_layers`` (the reference
+    takes every layer whose name ends in ``_bn``; pass those names, or the BN-typed layers of a NetSpec)
+    rewrite the fourth blob, ``var_to_inv_std``: (var + eps)^-0.5, ``inv_std_to_var``: inv_std^-2 - eps.
+    Returns a new dict; the other blobs are shared."""
+    if conversion not in ("var_to_inv_std", "inv_std_to_var"):
+        raise ValueError(f"Unknown conversion {conversion}")
+    out = {k: list(v) for k, v in params.items()}
+    for name in bn_layers:
+        if name not in out:
+            continue
+        blobs = out[name]
+        if len(blobs) != 4:
+            raise CaffemodelError(f"BN layer {name}: expected 4 blobs (scale, shift, mean, var), got {len(blobs)}")
+        b3 = np.asarray(blobs[3], np.float32)
+        if conversion == "var_to_inv_std":
+            new = np.power(b3 + np.float32(eps), np.float32(-0.5))
+        else:
+            new = np.power(b3, np.float32(-2)) - np.float32(eps)
+        blobs[3] = new.astype(np.float32)
+    return out
+
+
+def bn_layer_names(spec) -> List[str]:
+    """BN-typed layers of a NetSpec (a superset of the reference's ``name.endswith('_bn')`` rule for every
+    ECO prototxt, where all BN layers are named ``*_bn``)."""
+    return [L.name for L in spec.layers if L.type == "BN"]
 
 
 def _varint(buf: bytes, pos: int) -> Tuple[int, int]:

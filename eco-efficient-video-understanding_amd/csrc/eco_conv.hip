@@ -61,7 +61,7 @@ struct ConvKernelArgs {
   // ns_short <= ns_long.  Gather kernels: every split tile has ksplit slices (ns_short = ns_long = ksplit).
   int col_long0, col_long1, ns_short, ns_long;
   float* ws;
-  // Batched launches (gridDim.y = batch; the 16 transform points of the Winograd path): element strides of
+  // Batched launches (gridDim.y = batch; the (M+2)^2 transform points of the Winograd path): element strides of
   // the input, the packed weights, the output views and the split-K workspace between batch entries.
   long bstride_x, bstride_w, bstride_out, bstride_ws;
   int batch;
@@ -83,7 +83,20 @@ __device__ __forceinline__ ConvKernelArgs batch_args(const ConvKernelArgs& a0) {
 constexpr int kKoffBits = 26;
 constexpr int kKoffMask = (1 << kKoffBits) - 1;
 constexpr int kNeverTap = 63;  // validity-mask bit that is never set (used by K padding)
-constexpr int kNumCU = 256;    // MI355X
+constexpr int kNumCU = 256;    // MI355X; used when the device cannot be asked (emulator build, query failure)
+
+// Compute units of the calling thread's current device (hipDeviceProp_t::multiProcessorCount, what
+// eco_device_info reports); plans are sized against this unless the caller names a count.
+static int current_device_num_cu() {
+#ifdef ECO_EMU
+  return kNumCU;
+#else
+  int dev = 0, cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return kNumCU;
+  if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) return kNumCU;
+  return cu;
+#endif
+}
 
 
 // Output position n -> (image, spatial index) under the launch's position order.
@@ -907,7 +920,7 @@ static void host_split_layout(const eco_conv_geom* g, int mode, int bn, int sp, 
 }
 
 extern "C" int eco_conv_plan_create(const eco_conv_geom* g, eco_conv_plan* plan) {
-  return eco_conv_plan_create_batched(g, kNumCU, 1, plan);
+  return eco_conv_plan_create_batched(g, 0, 1, plan);
 }
 
 extern "C" int eco_conv_plan_create_ex(const eco_conv_geom* g, int32_t num_cu, eco_conv_plan* plan) {
@@ -916,7 +929,8 @@ extern "C" int eco_conv_plan_create_ex(const eco_conv_geom* g, int32_t num_cu, e
 
 extern "C" int eco_conv_plan_create_batched(const eco_conv_geom* g, int32_t num_cu, int32_t batch, eco_conv_plan* plan) {
   clear_error();
-  ECO_REQUIRE(num_cu >= 1, "conv: num_cu must be positive");
+  ECO_REQUIRE(num_cu >= 0, "conv: num_cu must be positive (or 0 for the current device)");
+  if (num_cu == 0) num_cu = current_device_num_cu();
   ECO_REQUIRE(batch >= 1, "conv: batch must be positive");
   if (int rc = validate_geom(g)) return rc;
   ECO_REQUIRE(plan != nullptr, "conv: null plan");

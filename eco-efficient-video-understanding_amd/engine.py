@@ -127,6 +127,7 @@ class Engine:
         self.ops: List[Tuple[int, str, Callable[[Optional[int]], None], dict]] = []
         self._keep = []                          # ctypes structs referenced by closures
         self._built = False
+        self.generation = 0                      # bumped by every build() / parameter upload (hipGraph cache key)
 
     # ------------------------------------------------------------------ params
     def set_params(self, params: Dict[str, List[np.ndarray]]) -> None:
@@ -160,6 +161,7 @@ class Engine:
         """(Re)upload parameters whose host copy changed; repack conv weights."""
         if not self._dirty_params:
             return
+        self.generation += 1
         for name in list(self._dirty_params):
             L = self.spec.layer(name)
             st = self._param_dev.setdefault(name, {})
@@ -202,13 +204,27 @@ class Engine:
     def build(self) -> None:
         """Allocate blobs and record the launch list for the spec's current shapes."""
         spec = self.spec
+        # Net::Reshape keeps blob contents (net.cpp:843-849, Blob::Reshape only reallocates when the count
+        # grows): storage whose element count is unchanged is carried over to the new plan, so a redundant
+        # net.reshape() neither loses resident inputs nor hands kernels uninitialised buffers.
+        self._old_tensors = self.tensors
         self.tensors = {}
         self.fused_away = {}
         self.ops = []
         self._keep = []
+        self.generation += 1
         # device-side parameter storage (sizes depend on geometry)
         for L in spec.layers:
             st = self._param_dev.setdefault(L.name, {})
+            shapes = param_shapes(L)
+            if shapes and L.name in self.params:
+                # a reshape may change a parameter's shape (e.g. fc K after a spatial reshape with a fixed
+                # global_pool kernel); the reference CHECK-fails in LayerSetUp / Reshape, never reads past the blob
+                have = [tuple(b.shape) for b in self.params[L.name]]
+                want = [tuple(int(d) for d in sh) for sh in shapes]
+                if [_prod(h) for h in have] != [_prod(w) for w in want]:
+                    raise NetSpecError(f"layer {L.name}: parameter shapes {have} do not match the reshaped "
+                                       f"geometry {want}")
             if L.type == "Convolution":
                 g = L.geom
                 geom = hip.conv_geom(L.bottom_shapes[0][0], g["cin"], g["cout"], L.bottom_shapes[0][2:], g["kernel"],
@@ -223,14 +239,16 @@ class Engine:
                 st["geom"], st["plan"] = geom, plan
                 st.pop("wino", None) if not self._wino_eligible(L) else self._plan_wino(L, st)
                 self._dirty_params.add(L.name)  # the gather table depends on the input dims
-            elif L.type == "BN" and "scale" not in st:
+            elif L.type == "BN" and st.get("size") != L.geom["channels"]:
                 st["scale"] = self.alloc.empty(L.geom["channels"], np.float32)
                 st["shift"] = self.alloc.empty(L.geom["channels"], np.float32)
+                st["size"] = L.geom["channels"]
                 self._dirty_params.add(L.name)
-            elif L.type == "InnerProduct" and "w" not in st:
+            elif L.type == "InnerProduct" and st.get("size") != (L.geom["num_output"], L.geom["K"]):
                 st["w"] = self.alloc.empty(L.geom["num_output"] * L.geom["K"], np.float32)
                 if L.geom["bias_term"]:
                     st["bias"] = self.alloc.empty(L.geom["num_output"], np.float32)
+                st["size"] = (L.geom["num_output"], L.geom["K"])
                 self._dirty_params.add(L.name)
         # one scratch buffer serves every split-K convolution (launches are serial on one stream); the same
         # goes for the Winograd path's transformed input / output volumes
@@ -252,6 +270,7 @@ class Engine:
         else:
             for i, L in enumerate(spec.layers):
                 self._emit_unfused(i, L)
+        self._old_tensors = {}
         self._built = True
 
     # -- storage helpers -------------------------------------------------------
@@ -261,7 +280,11 @@ class Engine:
             if _prod(t.shape) != _prod(shape):
                 raise NetSpecError(f"blob {name}: storage of {t.shape} reused for {shape}")
             return t
-        t = _Tensor(self.alloc.empty(_prod(shape), np.float32), shape, name)
+        old = getattr(self, "_old_tensors", {}).get(name)
+        if old is not None and old.owner == name and old.count == _prod(shape):
+            t = _Tensor(old.handle, shape, name)   # same element count: contents survive the rebuild
+        else:
+            t = _Tensor(self.alloc.empty(_prod(shape), np.float32), shape, name)
         self.tensors[name] = t
         return t
 
@@ -370,7 +393,7 @@ class Engine:
         else:  # pragma: no cover
             raise NetSpecError(f"no HIP launcher for layer type {t}")
 
-    # -- Winograd F(2x2,3x3) path (csrc/eco_wino.hip) ---------------------------------
+    # -- Winograd F(MxM,3x3) path, M = 4 by default (csrc/eco_wino.hip) ---------------------------------
     @staticmethod
     def _wino_dims(L: LayerSpec):
         """(n, D, H, W, kd) of a stride-1 pad-1 (3x)3x3 convolution's input, D = kd = 1 for 2-D blobs."""
@@ -526,10 +549,14 @@ class Engine:
             return None
 
         def bn_relu_after(blob: str) -> Optional[Tuple[int, int]]:
-            """(bn idx, relu idx) if `blob` feeds a non-in-place BN whose top is first hit by an in-place ReLU."""
+            """(bn idx, relu idx) if `blob` feeds a non-in-place BN whose top is first hit by an in-place ReLU.
+            The BN must see the value the epilogue holds: an in-place layer on `blob` ahead of the BN in layer
+            order (e.g. conv -> in-place ReLU -> BN) changes it first, so such a BN is not fused."""
             for ci in consumers.get(blob, []):
                 Lb = layers[ci]
-                if Lb.type != "BN" or Lb.inplace:
+                if Lb.inplace:
+                    return None          # the blob is rewritten before any later consumer reads it
+                if Lb.type != "BN":
                     continue
                 tb = Lb.tops[0]
                 cs = consumers.get(tb, [])

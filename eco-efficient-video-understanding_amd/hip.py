@@ -217,7 +217,7 @@ class EcoLib:
         elif batch == 1:
             self._check(self._dll.eco_conv_plan_create_ex(C.byref(g), int(num_cu), C.byref(p)))
         else:
-            self._check(self._dll.eco_conv_plan_create_batched(C.byref(g), 256 if num_cu is None else int(num_cu),
+            self._check(self._dll.eco_conv_plan_create_batched(C.byref(g), 0 if num_cu is None else int(num_cu),
                                                                int(batch), C.byref(p)))
         return p
 
@@ -234,7 +234,7 @@ class EcoLib:
         self._check(self._dll.eco_conv_forward_batched(C.byref(g), C.byref(p), x, wp, ktab, C.byref(ep), workspace,
                                                        batch, stride_x, stride_wp, stride_out, stream))
 
-    # -- Winograd F(2x2,3x3) front / back end ----------------------------------
+    # -- Winograd F(MxM,3x3) front / back end (M = 2 or 4) ----------------------------------
     def wino_weight_transform(self, w_host: int, cout: int, cin: int, kd: int, tile_m: int, u_host: int) -> None:
         self._check(self._dll.eco_wino_weight_transform(w_host, cout, cin, kd, tile_m, u_host))
 

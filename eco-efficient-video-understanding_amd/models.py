@@ -8,9 +8,10 @@ name/``num_output``, and per ``num_segments`` only in the ``r2Dto3D`` dim, the
 ``segment_consensus_st2`` (README.md:85-95).  Those files do not exist on the
 GPU box, so the same graphs are *generated* here from the BN-Inception /
 3D-ResNet-18 structure; layer and blob names are the reference's (weights are
-matched by layer name, net.cpp:852-883).  tests/test_models.py checks the
+matched by layer name, net.cpp:852-883).  tests/test_prototxt_netspec.py checks the
 generated graph field-by-field against the reference files when
-/root/reference is present.
+/root/reference is present, and against the committed extract
+tests/golden/reference_graphs.json everywhere else.
 
 Any user prototxt (including the reference's own files) can be passed to
 ``Net`` directly; these generators only remove the dependency on the files.

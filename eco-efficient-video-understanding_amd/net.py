@@ -69,6 +69,10 @@ class Blob:
         self._param_of = param_of
         self._host: Optional[np.ndarray] = None
         self._head = _HEAD_NONE
+        # Reshape / Split / Dropout(TEST) tops share their bottom's SyncedMemory in the reference
+        # (Blob::ShareData, reshape_layer.cpp:88): such a blob keeps no mirror of its own, its data is a
+        # reshaped view of the storage owner's host copy and its head is the owner's.
+        self._root: Optional["Blob"] = None
 
     # -- shape accessors ----------------------------------------------------
     @property
@@ -109,6 +113,8 @@ class Blob:
             return self._host
         if self._name not in self._net._engine.tensors:
             self._net._engine._ptr(self._name)  # raises KeyError with the fused-away reason
+        if self._root is not None:
+            return self._root.data.reshape(self._shape)
         if self._host is None or self._host.shape != self._shape:
             self._host = np.zeros(self._shape, np.float32)
             if self._head == _HEAD_NONE:
@@ -123,11 +129,12 @@ class Blob:
         """Zero-copy torch view of the HBM buffer (extension; torch plumbing only)."""
         if self._param_of is not None:
             raise AttributeError("parameter blobs have no device view")
-        self._net._flush_host(self._name)
         t = self._net._engine.tensors.get(self._name)
         if t is None:
             self._net._engine._ptr(self._name)  # raises with the fused-away reason
-        self._head = _HEAD_DEVICE
+        owner = self._root if self._root is not None else self
+        self._net._flush_host(owner._name)
+        owner._head = _HEAD_DEVICE
         return t.handle[: self.count].view(self._shape)
 
 
@@ -160,7 +167,8 @@ class Net:
         self._lib = lib
         self._alloc = alloc
         # winograd=False evaluates every convolution directly (the reference's arithmetic order up to the
-        # summation order); the default uses Winograd F(2x2,3x3) for the 3-D trunk's stride-1 3x3x3 convs
+        # summation order); the default (True) routes every stride-1 3x3(x3) conv with cin >= 64 through
+        # Winograd F(4x4,3x3) when the batch is large enough (engine._wino_eligible); 2 / 4 force the tile size
         self._engine = Engine(self._spec, lib, alloc, fuse=fuse, winograd=winograd, num_cu=_num_cu)
         self._pending_input_shapes: Dict[str, tuple] = {}
         self._engine.set_params(params if params is not None else fillers.filler_params(self._spec, seed))
@@ -180,6 +188,11 @@ class Net:
                 self.blobs[name] = b
             else:
                 self.blobs[name] = Blob(self, name, shape)
+        for name, b in self.blobs.items():   # aliases share the mirror / head of the blob that owns the storage
+            t = self._engine.tensors.get(name)
+            b._root = self.blobs[t.owner] if t is not None and t.owner != name and t.owner in self.blobs else None
+            if b._root is not None:
+                b._host, b._head = None, _HEAD_NONE
         self.params: "OrderedDict[str, List[Blob]]" = OrderedDict()
         for L in self._spec.layers:
             if param_shapes(L):
@@ -222,6 +235,8 @@ class Net:
 
     def _flush_host(self, name: str) -> None:
         b = self.blobs[name]
+        if b._root is not None:   # an alias: its storage owner carries the mirror
+            return
         if b._head == _HEAD_HOST and b._host is not None and name in self._engine.tensors:
             self._alloc.upload(self._engine.tensors[name].handle, b._host)
             b._head = _HEAD_SYNCED
@@ -231,7 +246,9 @@ class Net:
         """Net::Reshape (net.cpp:843-849): propagate input-blob reshapes through the graph."""
         self._spec.reshape(self._pending_input_shapes)
         self._pending_input_shapes = {}
-        self._engine.build()
+        self._engine.build()   # storage of unchanged element count (and its contents) is carried over
+        self._graph = None     # a captured launch list refers to the old plan's buffers
+        self._graph_key = None
         self._make_blobs()
 
     def set_params(self, params: Dict[str, List[np.ndarray]]) -> None:
@@ -239,10 +256,16 @@ class Net:
         self._engine.set_params(params)
         self._make_blobs()
 
-    def copy_from(self, path: str) -> None:
-        """Net::CopyTrainedLayersFrom (net.cpp:852-883): match by layer name."""
+    def copy_from(self, path: str, bn_style: str = "variance", bn_eps: float = 1e-5) -> None:
+        """Net::CopyTrainedLayersFrom (net.cpp:852-883): match by layer name.  ``bn_style`` names what the
+        file's BN layers keep in their fourth blob: "variance" (this fork's layer, bn_layer.cpp:38-41) or
+        "inv_std" (the legacy style; converted on load per python/bn_convert_style.py:21-24 with ``bn_eps``)."""
         from . import caffemodel
+        if bn_style not in caffemodel.BN_STYLES:
+            raise ValueError(f"bn_style must be one of {caffemodel.BN_STYLES}")
         loaded = caffemodel.read_caffemodel(path)
+        if bn_style == "inv_std":
+            loaded = caffemodel.convert_bn_style(loaded, caffemodel.bn_layer_names(self._spec), "inv_std_to_var", bn_eps)
         merged = {k: list(v) for k, v in self._engine.params.items()}
         for lname, blobs in loaded.items():
             if lname not in merged:
@@ -252,15 +275,26 @@ class Net:
             merged[lname] = [np.asarray(b, np.float32).reshape(t.shape) for b, t in zip(blobs, merged[lname])]
         self.set_params(merged)
 
-    def save(self, path: str) -> None:
+    def save(self, path: str, bn_style: str = "variance", bn_eps: float = 1e-5) -> None:
+        """Net::ToProto + WriteProtoToBinaryFile; ``bn_style="inv_std"`` writes the legacy BN style
+        (python/bn_convert_style.py:17-20)."""
         from . import caffemodel
-        caffemodel.write_caffemodel(path, self._spec, self._engine.params)
+        if bn_style not in caffemodel.BN_STYLES:
+            raise ValueError(f"bn_style must be one of {caffemodel.BN_STYLES}")
+        params = self._engine.params
+        if bn_style == "inv_std":
+            params = caffemodel.convert_bn_style(params, caffemodel.bn_layer_names(self._spec), "var_to_inv_std", bn_eps)
+        caffemodel.write_caffemodel(path, self._spec, params)
 
     def _forward(self, start: int, end: int) -> None:
         if self._pending_input_shapes:
             self.reshape()
+        # SyncedMemory::to_gpu for what the launches will read: the net inputs always; layer tops only when the
+        # forward starts mid-net (a full forward overwrites every one of them, so a blob the caller merely
+        # inspected through .data is not uploaded again)
         for name in self.blobs:
-            self._flush_host(name)
+            if start > 0 or name in self._spec.inputs:
+                self._flush_host(name)
         self._engine.forward(start, end)
         for name, b in self.blobs.items():
             if name in self._engine.tensors and name not in self._spec.inputs:
@@ -308,15 +342,16 @@ class Net:
     def _graph_replay(self) -> None:
         import torch
         eng = self._engine
-        key = (id(eng.ops), len(eng.ops))
-        if getattr(self, "_graph_key", None) != key or eng._dirty_params:
-            eng._sync_params()                       # uploads happen outside the capture
+        if eng._dirty_params:
+            eng._sync_params()                       # uploads happen outside the capture (bumps the generation)
+        key = eng.generation                         # monotonic: a stale capture can never match a new plan
+        if getattr(self, "_graph_key", None) != key or getattr(self, "_graph", None) is None:
             eng.forward()                            # warm-up on the normal stream
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):                # capture stream becomes torch's current stream
                 eng.forward()
-            self._graph, self._graph_key = g, key
+            self._graph, self._graph_key = g, eng.generation
         self._graph.replay()
 
     def op_labels(self) -> List[str]:

@@ -127,10 +127,11 @@ typedef struct eco_conv_epilogue {
   eco_view act;
 } eco_conv_epilogue;
 
-/* Validates `g` (fills nothing) and chooses the tiling for MI355X (256 CUs). */
+/* Validates `g` (fills nothing) and chooses the tiling for the calling thread's current device (its
+ * compute-unit count as eco_device_info reports it: 256 on MI355X). */
 int eco_conv_plan_create(const eco_conv_geom* g, eco_conv_plan* plan);
-/* Same, for a device with `num_cu` compute units (the CPU test-suite uses tiny values to reach the
- * many-tile code paths with emulator-sized problems). */
+/* Same, for a device with `num_cu` compute units (0 = the current device; the CPU test-suite uses tiny
+ * values to reach the many-tile code paths with emulator-sized problems). */
 int eco_conv_plan_create_ex(const eco_conv_geom* g, int32_t num_cu, eco_conv_plan* plan);
 /* Plan for eco_conv_forward_batched: `batch` entries of this geometry share one launch, so the tile
  * count that is weighed against the device is tiles * batch. */
@@ -154,7 +155,7 @@ int eco_conv_forward(const eco_conv_geom* g, const eco_conv_plan* plan, const fl
 /* `batch` independent convolutions of one geometry / plan in a single launch (gridDim.y = batch):
  * entry b reads x + b*stride_x, weights wp + b*stride_wp (same gather table), and writes through
  * the epilogue's views moved by b*stride_out elements; `workspace` holds batch * plan.ws_bytes.
- * Used for the 16 transform points of the Winograd path.  Gather-kernel plans only. */
+ * Used for the (M+2)^2 transform points of the Winograd path (36 for F(4x4,3x3), 16 for F(2x2,3x3)).  Gather-kernel plans only. */
 int eco_conv_forward_batched(const eco_conv_geom* g, const eco_conv_plan* plan, const float* x,
                              const float* wp, const int32_t* ktab, const eco_conv_epilogue* ep,
                              void* workspace, int32_t batch, int64_t stride_x, int64_t stride_wp,

@@ -26,6 +26,18 @@ def test_header_matches_binding():
     assert declared_symbols() == sorted(hip.EXPORTED_SYMBOLS)
 
 
+def test_header_compiles_as_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must be valid C99 on its own (a cgo / JNI / ctypes-generator user
+    compiles it as C, not C++), and a C translation unit that names every entry point must compile."""
+    subprocess.run(["gcc", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", HEADER],
+                   check=True)
+    tu = tmp_path / "use_all.c"
+    tu.write_text('#include "eco_hip.h"\nvoid* const eco_entry_points[] = {\n' +
+                  "".join(f"  (void*){s},\n" for s in declared_symbols()) + "};\n")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-Wno-pedantic", "-I", os.path.dirname(HEADER), "-c", str(tu),
+                    "-o", str(tmp_path / "use_all.o")], check=True)
+
+
 def test_product_library_exports_every_declared_symbol():
     if not os.path.exists(hip.LIB_PATH):
         import __graft_entry__

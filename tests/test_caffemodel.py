@@ -89,3 +89,47 @@ def test_interop_with_reference_schema(tmp_path):
     open(f, "wb").write(n2.SerializeToString())
     r = caffemodel.read_caffemodel(f)
     assert r["fc"][0].shape == (1, 1, 2, 3) and r["old"][0].tolist() == [[9, 8], [7, 6]]
+
+
+def test_bn_style_conversion_matches_reference_formulas():
+    """python/bn_convert_style.py:17-24: var -> (var+eps)^-0.5 and back inv_std^-2 - eps, 4th blob of BN layers only."""
+    spec = NetSpec.from_prototxt(mini())
+    p = fillers.synthetic_params(spec, seed=3)
+    bn = caffemodel.bn_layer_names(spec)
+    assert bn and all(n.endswith("_bn") or n.endswith("bn") for n in bn)
+    inv = caffemodel.convert_bn_style(p, bn, "var_to_inv_std", eps=1e-5)
+    for n in bn:
+        assert np.allclose(inv[n][3], 1.0 / np.sqrt(p[n][3].astype(np.float64) + 1e-5), rtol=1e-6)
+        assert all(a is b for a, b in zip(inv[n][:3], p[n][:3]))
+    back = caffemodel.convert_bn_style(inv, bn, "inv_std_to_var", eps=1e-5)
+    for n in bn:
+        assert np.allclose(back[n][3], p[n][3], rtol=2e-6, atol=1e-7)
+    conv = [L.name for L in spec.layers if L.type == "Convolution"][0]
+    assert inv[conv][0] is p[conv][0]
+    with pytest.raises(ValueError, match="Unknown conversion"):
+        caffemodel.convert_bn_style(p, bn, "nope")
+
+
+def test_inv_std_style_file_loads_to_the_same_logits(backend, tmp_path):
+    """A legacy inv-std-style .caffemodel read with bn_style="inv_std" gives the logits of the variance-style
+    file; read as variances (the silent failure VERDICT r1 names) it does not."""
+    proto = mini()
+    spec = NetSpec.from_prototxt(proto)
+    p = fillers.synthetic_params(spec, seed=4)
+    kw = {"_backend": (backend.lib, backend.alloc)} if backend.kind == "emu" else {}
+    x = fillers.synthetic_frames(4, 32, 32, seed=6)
+    a = Net(proto, params=p, **kw)
+    ya = a.forward(data=x)["fc8"].copy()
+    f = str(tmp_path / "legacy.caffemodel")
+    a.save(f, bn_style="inv_std")
+    raw = caffemodel.read_caffemodel(f)
+    some_bn = caffemodel.bn_layer_names(spec)[0]
+    assert np.allclose(raw[some_bn][3], 1.0 / np.sqrt(p[some_bn][3] + 1e-5), rtol=1e-5)
+    b = Net(proto, 1, **kw)
+    b.copy_from(f, bn_style="inv_std")
+    yb = b.forward(data=x)["fc8"].copy()
+    assert np.abs(yb - ya).max() / np.abs(ya).max() < 1e-4
+    b.copy_from(f)  # default style: the 4th blobs are taken for variances
+    assert np.abs(b.forward(data=x)["fc8"] - ya).max() / np.abs(ya).max() > 1e-3
+    with pytest.raises(ValueError, match="bn_style"):
+        b.copy_from(f, bn_style="std")
