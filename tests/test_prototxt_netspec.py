@@ -204,3 +204,90 @@ def test_roofline_tool_rederives_survey_totals():
                                      (models.eco_lite_deploy, dict(num_segments=4, num_clips=1), 23.24, 0.294)]:
         fl, fb, lb = rl.totals(NetSpec.from_prototxt(gen(**kw)))
         assert abs(fl / 1e9 - gflop) < 0.01 and abs(fb / 1e9 - fused_gb) < 0.006 and lb > fb
+
+
+# --- graph parity against the committed extract of the reference's own prototxts ------------------------------
+# tests/golden/reference_graphs.json is produced by tests/golden/make_reference_graphs.py from the reference
+# files with the reference's generated schema and an independent restatement of FilterNet / InsertSplits / the
+# per-layer Reshape rules (nothing of this package is imported there).  Unlike the needs_ref tests above it
+# travels to the GPU box, so graph and shape inference is pinned there too.
+def _reference_graphs():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_graphs.json")) as f:
+        return {g["file"]: g for g in json.load(f)["graphs"]}
+
+
+def _geom_subset(L):
+    """The fields of LayerSpec.geom that the extract records, in its spelling."""
+    g, t = L.geom, L.type
+    if t == "Convolution":
+        return dict(kernel=list(g["kernel"]), stride=list(g["stride"]), pad=list(g["pad"]), cin=g["cin"], cout=g["cout"],
+                    bias_term=g["bias_term"])
+    if t == "Pooling":
+        return dict(method=g["method"], kernel=list(g["kernel"]), stride=list(g["stride"]), pad=list(g["pad"]))
+    if t == "BN":
+        return dict(eps=g["eps"], frozen=g["frozen"], channels=g["channels"])
+    if t == "ReLU":
+        return dict(negative_slope=g["negative_slope"])
+    if t == "Dropout":
+        return dict(ratio=g["ratio"])
+    if t == "Reshape":
+        return dict(dims=[int(d) for d in L.param.msg("reshape_param").msg("shape").getall("dim")])
+    if t == "Permute":
+        return dict(order=list(g["order"]))
+    if t == "Concat":
+        return dict(axis=g["axis"])
+    if t == "Eltwise":
+        return dict(op=g["op"], coeff=list(g["coeff"]))
+    if t == "InnerProduct":
+        return dict(num_output=g["num_output"], K=g["K"], bias_term=g["bias_term"])
+    if t == "Accuracy":
+        return dict(top_k=g["top_k"])
+    return {}
+
+
+def _assert_spec_equals_extract(spec, ref):
+    assert spec.name == ref["name"] and spec.inputs == ref["inputs"] and sorted(spec.outputs) == ref["outputs"]
+    assert {k: list(v) for k, v in spec.input_shapes.items()} == ref["input_shapes"]
+    assert len(spec.layers) == len(ref["layers"])
+    for L, R in zip(spec.layers, ref["layers"]):
+        assert (L.name, L.type, L.bottoms, L.tops) == (R["name"], R["type"], R["bottom"], R["top"])
+        assert [list(s) for s in L.top_shapes] == R["top_shapes"], L.name
+        mine, theirs = _geom_subset(L), R["geom"]
+        assert set(mine) == set(theirs), L.name
+        for k in mine:
+            if isinstance(mine[k], float):
+                assert abs(mine[k] - theirs[k]) <= 1e-6 * max(1.0, abs(theirs[k])), (L.name, k)
+            else:
+                assert mine[k] == theirs[k], (L.name, k, mine[k], theirs[k])
+
+
+@pytest.mark.parametrize("backend_kind", ["cpu", pytest.param("gpu", marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("which", ["lite", "full", "ucf101", "hmdb51", "something_something"])
+def test_generated_graph_equals_reference_extract(which, backend_kind):
+    refs = _reference_graphs()
+    if which == "lite":
+        ref, spec = refs["models_ECO_Lite/kinetics/deploy.prototxt"], NetSpec.from_prototxt(models.eco_lite_deploy())
+        assert len(ref["layers"]) == 116 and sum(r["type"] != "Split" for r in ref["layers"]) == 109
+    elif which == "full":
+        ref, spec = refs["models_ECO_Full/kinetics/deploy.prototxt"], NetSpec.from_prototxt(models.eco_full_deploy())
+        assert sum(r["type"] != "Split" for r in ref["layers"]) == 281
+    else:
+        ref = refs[f"models_ECO_Lite/{which}/deploy.prototxt"]
+        fc = [r for r in ref["layers"] if r["type"] == "InnerProduct"][0]
+        drop = [r for r in ref["layers"] if r["type"] == "Dropout"][0]
+        spec = NetSpec.from_prototxt(models.eco_lite_deploy(num_classes=fc["geom"]["num_output"], fc_name=fc["name"],
+                                                            dropout_ratio=drop["geom"]["ratio"]))
+        ref = dict(ref, name=spec.name)  # the dataset prototxts differ in net name, dropout ratio and fc only
+    _assert_spec_equals_extract(spec, ref)
+
+
+@pytest.mark.parametrize("backend_kind", ["cpu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def test_test_phase_evaluator_equals_reference_extract(backend_kind):
+    """ECO_Lite.prototxt filtered to TEST (VideoData source -> inputs data/label, body, loss, top1, top5)."""
+    ref = _reference_graphs()["models_ECO_Lite/kinetics/ECO_Lite.prototxt"]
+    src = ref["source"]
+    assert src["type"] == "VideoData" and src["top"] == ["data", "label"] and src["mean_value"] == [104.0, 117.0, 123.0]
+    spec = NetSpec.from_prototxt(models.test_phase_net(models.eco_lite_deploy(num_clips=src["batch_size"]),
+                                                       src["num_segments"], batch_size=src["batch_size"]))
+    _assert_spec_equals_extract(spec, dict(ref, name=spec.name))
