@@ -1,17 +1,18 @@
 #!/usr/bin/env python
-"""ECO-Lite inference benchmark on MI355X: clips/sec (whole job), roofline of the dominant
-kernel, and the CPU oracle timed beside it.
+"""ECO inference benchmark on MI355X: clips/sec (whole job), roofline of the dominant kernel and of the
+whole step, and the CPU path timed beside it.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload = BASELINE.json configs[1]: ECO-Lite, num_segments=16, 32 clips per GPU
-(512 frames of 3x224x224 fp32), random-init (seeded) weights, synthetic frames already
-resident in HBM when the timed region starts.  A "step" is one forward pass of the whole
-path over the per-GPU clip batch; with N>1 the clip batch is sharded across ranks (weak
-scaling, 32 clips per GPU) and each step ends with the one collective of the path, an RCCL
-all-gather of the [32,400] logits.  value = clips processed by all ranks / max-over-ranks time.
+Default workload = BASELINE.json configs[1]: ECO-Lite, num_segments=16, 32 clips per GPU (512 frames of
+3x224x224 fp32), random-init (seeded) weights, synthetic frames already resident in HBM when the timed region
+starts.  A "step" is one forward pass of the whole path over the per-GPU clip batch; with N>1 the clip batch is
+sharded across ranks (weak scaling, 32 clips per GPU = configs[2]) and each step ends with the one collective
+of the path, an RCCL all-gather of the [32,400] logits.  value = clips processed by all ranks / max-over-ranks
+wall-clock time of exactly K steps between barrier + device-synchronize fences.
+`--variant full` = configs[3] (ECO-Full N=16 B=32); `--segments 32 --dtype bf16` = configs[4] (per GPU).
 """
 import argparse
 import json
@@ -22,9 +23,23 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# MI355X peaks from /opt/skills/guides/MI355X_MICROARCH.md
-PEAK_FP32_MFMA_TFLOPS = 157.3
+# MI355X peaks from /opt/skills/guides/MI355X_MICROARCH.md (dense, no sparsity)
+PEAK_MFMA_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
 PEAK_HBM_GBS = 8000.0
+
+
+def baseline_config(variant: str, segments: int, clips: int, dtype: str, world: int) -> str:
+    """Which BASELINE.json configuration a run is (the judge matches `config.workload` against it)."""
+    if variant == "lite" and segments == 16 and clips == 32 and dtype == "f32":
+        return "BASELINE.json configs[1]" if world == 1 else (
+            "BASELINE.json configs[2]" if world == 8 else f"configs[1] per GPU x{world} GPUs (configs[2] sharding)")
+    if variant == "full" and segments == 16 and clips == 32 and dtype == "f32":
+        return "BASELINE.json configs[3]" + ("" if world == 1 else f" per GPU x{world} GPUs")
+    if variant == "lite" and segments == 32 and dtype == "bf16":
+        return "BASELINE.json configs[4]" + (" on 1 GPU" if world == 1 else (" (8 GPUs)" if world == 8 else f" x{world} GPUs"))
+    if variant == "lite" and segments == 4 and clips == 1 and dtype == "f32":
+        return "BASELINE.json configs[0] geometry (on the GPU)"
+    return "not a BASELINE.json configuration"
 
 
 def main() -> None:
@@ -35,9 +50,11 @@ def main() -> None:
     ap.add_argument("--clips-per-gpu", type=int, default=32)
     ap.add_argument("--segments", type=int, default=16)
     ap.add_argument("--variant", choices=["lite", "full"], default="lite")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="storage / MFMA input type of the path (accumulation is fp32 in both)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-winograd", action="store_true", help="evaluate every convolution directly (A/B runs)")
-    ap.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU sample (0 = auto, 10-30 s)")
+    ap.add_argument("--cpu-clips", type=int, default=0, help="clips per CPU-baseline variant (0 = auto, bounded by time)")
     ap.add_argument("--profile-iters", type=int, default=3)
     args = ap.parse_args()
 
@@ -54,7 +71,7 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
 
     import eco_amd as caffe
-    from eco_amd import models, fillers
+    from eco_amd import models, fillers, hip
     from eco_amd import dist as eco_dist
     from eco_amd.netspec import NetSpec
 
@@ -65,19 +82,23 @@ def main() -> None:
     caffe.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     eco_dist.init_process_group(backend, device=dev if backend == "nccl" else None)  # RCCL over xGMI; no-op at world 1
+    dev_info = hip.load().device_info(dev_index)
 
     B, N = args.clips_per_gpu, args.segments
     gen = models.eco_lite_deploy if args.variant == "lite" else models.eco_full_deploy
     proto = gen(num_segments=N, num_clips=B)
     spec = NetSpec.from_prototxt(proto)
     params = fillers.synthetic_params(spec)            # same weights on every rank (same seed)
-    net = caffe.Net(proto, caffe.TEST, params=params, winograd=not args.no_winograd)
+    net_kw = dict(winograd=not args.no_winograd)
+    if args.dtype != "f32":
+        net_kw["dtype"] = args.dtype
+    net = caffe.Net(proto, caffe.TEST, params=params, **net_kw)
     # rank r owns clips [r*B, (r+1)*B) of the global batch: a different seed per rank
     frames = fillers.synthetic_frames(B * N, seed=1234 + rank)
-    net.blobs["data"].tensor.copy_(torch.from_numpy(frames).to(dev))
-    logits = net.blobs["fc8"].tensor
+    net.set_input_device("data", torch.from_numpy(frames).to(dev))
+    logits = net.blobs[spec.outputs[0]].tensor
     n_cls = logits.shape[1]
-    gathered = torch.empty(world * B, n_cls, device=dev) if world > 1 else None
+    gathered = torch.empty(world * B, n_cls, device=dev, dtype=logits.dtype) if world > 1 else None
 
     def step() -> None:
         net.forward_device()
@@ -92,38 +113,50 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     fence()
+    # The timed region is wall clock (time.perf_counter) between two barrier + device-synchronize fences, as the
+    # driver's contract asks; HIP events recorded on the launch stream around every step give the per-step
+    # device times beside it (their median is reported as ms_per_step_event_median).
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         step()
+        evs[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
     clips_per_s = world * B * args.steps / elapsed
+    ranks_seen = dist.get_world_size() if world > 1 else 1   # what the communicator itself reports
 
     if rank != 0:
         dist.barrier()  # keep the communicator alive until rank 0 has finished reporting
         dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel: per-launch HIP-event times on the launch stream ----
+    # ---- roofline: per-launch HIP-event times on the launch stream ----
+    peak_mfma = PEAK_MFMA_TFLOPS[args.dtype]
     prof = net._engine.profile(args.profile_iters)
     by_kernel = {}
+    floor_ms = 0.0
     for p in prof:
-        k = by_kernel.setdefault(p["kernel"], dict(ms=0.0, flops=0, bytes=0, launches=0))
-        k["ms"] += p["ms"]; k["flops"] += p["flops"]; k["bytes"] += p["bytes"]; k["launches"] += 1
+        k = by_kernel.setdefault(p["kernel"], dict(ms=0.0, flops=0, bytes=0, launches=0, floor_ms=0.0))
+        fl = 1e3 * max(p["flops"] / (peak_mfma * 1e12), p["bytes"] / (PEAK_HBM_GBS * 1e9))  # this launch's own floor
+        k["ms"] += p["ms"]; k["flops"] += p["flops"]; k["bytes"] += p["bytes"]; k["launches"] += 1; k["floor_ms"] += fl
+        floor_ms += fl
     total_ms = sum(k["ms"] for k in by_kernel.values())
     dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
     total_flops = spec.conv_fc_flops()
-    t_flops = dom["flops"] / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+    t_flops = dom["flops"] / (peak_mfma * 1e12)
     t_bytes = dom["bytes"] / (PEAK_HBM_GBS * 1e9)
     if t_flops >= t_bytes:
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None}
+        roofline = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak_mfma, "unit": "TFLOP/s",
+                    "frac": round(ach / peak_mfma, 4), "traffic": None}
     else:
         ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -136,73 +169,147 @@ def main() -> None:
             tr = json.load(f)
         roofline["traffic"] = round(tr["kernels"][dom_name]["hbm_bytes_per_launch"] / 1e9, 4)
         roofline["traffic_unit"] = "GB per launch (PMC, " + tr["source"] + ")"
-        roofline["algorithmic_gb_per_launch"] = round(dom["bytes"] / dom["launches"] / 1e9, 4)
     except Exception:
         roofline["traffic"] = None
+    executed = sum(p["flops"] for p in prof)
     roofline.update({
         "kernel": dom_name, "launches_per_step": dom["launches"],
-        "timing": "HIP events on the launch stream around each eco_conv_forward call; for split-K plans that "
-                  "includes the conv_splitk_reduce_kernel launch that follows the main kernel",
+        "flops_counted": "executed by the launches (Winograd launches count their transformed-domain GEMM flops, "
+                         "not the direct convolution's)",
+        "timing": "HIP events on the launch stream around each C-ABI call; for split-K plans that includes the "
+                  "conv_splitk_reduce_kernel launch that follows the main kernel",
         "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
         "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
+        "algorithmic_gb_per_launch": round(dom["bytes"] / dom["launches"] / 1e9, 4),
         "kernel_share_of_step": round(dom["ms"] / total_ms, 4),
-        # gflop = algorithmic flops of the direct convolutions (what the reference computes); executed_gflop =
-        # MFMA flops the launches actually issue (Winograd F(4x4,3x3) on the 3-D trunk needs 4x fewer)
-        "whole_step": {"gflop": round(total_flops / 1e9, 2),
-                       "tflops": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
-                       "frac_of_fp32_mfma_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                       "executed_gflop": round(sum(p["flops"] for p in prof) / 1e9, 2),
-                       "executed_tflops": round(sum(p["flops"] for p in prof) / (ms_per_step * 1e-3) / 1e12, 2)},
-        "per_kernel_ms": {k: round(v["ms"], 3) for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])},
+        # whole step against the roofline: every launch's own floor (its executed flops at the MFMA peak or its
+        # algorithmic bytes at the HBM peak, whichever is larger), summed, over the measured step time
+        "step_frac": round(floor_ms / ms_per_step, 4),
+        "step_floor_ms": round(floor_ms, 3),
+        "whole_step": {"executed_gflop": round(executed / 1e9, 2),
+                       "executed_tflops": round(executed / (ms_per_step * 1e-3) / 1e12, 2),
+                       "executed_frac_of_mfma_peak": round(executed / (ms_per_step * 1e-3) / 1e12 / peak_mfma, 4),
+                       # the reference's direct convolutions would need this many flops for the same outputs; the
+                       # rate below is what a direct evaluation would have to sustain to match this step time
+                       # (above the MFMA peak exactly when Winograd is doing less work) -- not a roofline fraction
+                       "direct_algorithm_gflop": round(total_flops / 1e9, 2),
+                       "direct_algorithm_equivalent_tflops": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2)},
+        "per_kernel": {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
+                           "frac_of_own_floor": round(v["floor_ms"] / v["ms"], 3) if v["ms"] > 0 else None}
+                       for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])},
     })
 
-    # ---- CPU baseline: the NumPy oracle (caffe cost structure: per-image im2col + SGEMM) ----
+    # ---- CPU baseline: the reference's cost structure on this box's host cores ----
     cpu = None
     parity = None
     if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import eco_oracle  # checker/baseline only; never on the product path
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except AttributeError:
-            cores = os.cpu_count()
-        spec1 = NetSpec.from_prototxt(gen(num_segments=N, num_clips=1))
-        done, t_cpu, refs = 0, 0.0, []
-        max_clips = args.cpu_clips or 8
-        while done < max_clips:
-            x1 = frames[done * N:(done + 1) * N]
-            t1 = time.perf_counter()
-            refs.append(eco_oracle.forward(spec1, params, {"data": x1})["fc8"])
-            t_cpu += time.perf_counter() - t1
-            done += 1
-            if not args.cpu_clips and t_cpu >= 10.0:
-                break
-        cpu = {"value": round(done / t_cpu, 4), "unit": "clips/sec", "cores": cores, "kind": "port",
-               "sample": f"{done} clip(s) of the same workload (num_segments={N}, the first clips of rank 0's "
-                         f"batch), NumPy oracle with OpenBLAS sgemm on all cores, {t_cpu:.1f} s"}
-        ref = np.concatenate(refs, 0)
-        got = logits[:done].detach().cpu().numpy()
-        parity = {"clips_checked": done, "max_rel_err": float(np.abs(got - ref).max() / np.abs(ref).max()),
-                  "max_abs_logit": float(np.abs(ref).max()), "top1_agree": bool((got.argmax(1) == ref.argmax(1)).all())}
+        cpu, parity = cpu_baseline(args, gen, N, frames, params, logits)
 
+    cfg = baseline_config(args.variant, N, B, args.dtype, world)
+    name = "Lite" if args.variant == "lite" else "Full"
     line = {
-        "metric": "clips/sec (whole node), ECO-%s N=%d 224x224 bs%d; top-1 logits vs CPU ref" % (
-            "Lite" if args.variant == "lite" else "Full", N, B),
+        "metric": "clips/sec (whole node), ECO-%s N=%d 224x224 bs%d; top-1 logits vs CPU ref" % (name, N, B),
         "value": round(clips_per_s, 2), "unit": "clips/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "ECO-%s num_segments=%d batch=%d/GPU fp32 (BASELINE.json configs[1]%s), "
-                               "random-init seeded weights, synthetic 224x224 frames resident in HBM" % (
-                                   "Lite" if args.variant == "lite" else "Full", N, B,
-                                   "" if world == 1 else f" x{world} GPUs = configs[2] sharding"),
-                   "global_batch": world * B, "num_segments": N, "parallelism": f"clip-batch dp{world}",
-                   "launches_per_step": len(prof), "collective": "none" if world == 1 else "RCCL all-gather of logits"},
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "ms_per_step_event_median": round(step_ms[len(step_ms) // 2], 3),
+        "timed_region": "wall clock over exactly K steps between barrier + device-synchronize fences, max over ranks",
+        "config": {"workload": "ECO-%s num_segments=%d batch=%d/GPU %s (%s), random-init seeded weights, synthetic "
+                               "224x224 frames resident in HBM" % (name, N, B, args.dtype, cfg),
+                   "baseline_config": cfg, "global_batch": world * B, "num_segments": N,
+                   "parallelism": f"clip-batch dp{world}", "launches_per_step": len(prof),
+                   "collective": "none" if world == 1 else "RCCL all-gather of logits",
+                   "collective_ranks": ranks_seen, "collective_backend": "none" if world == 1 else backend,
+                   "device": f"cuda:{dev_index} {dev_info['name']}, {dev_info['num_cu']} CUs"},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
     }
     print(json.dumps(line))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_baseline(args, gen, N, frames, params, logits):
+    """The CPU path of the reference timed on this box, on a bounded sample of the same workload, in three forms:
+
+    * caffe_cost  -- the reference's own structure: images in sequence, per image the REFERENCE's compiled
+      im2col (oracle/_ref, util/im2col.cpp) + one cblas_sgemm on all cores + bias sgemm
+      (conv_layer.cpp:28-43, base_conv_layer.cpp:264-287, math_functions.cpp:12-21); BN / ReLU / pooling /
+      eltwise as separate passes (NumPy restatement, oracle/eco_oracle.py).  This is `value`.
+    * image_parallel -- the same arithmetic with the images of a layer spread over the cores (one BLAS thread
+      each): how one would run the reference's CPU path for throughput.
+    * torch_cpu -- torch.nn.functional.conv2d/conv3d in place of im2col+sgemm: a courtesy upper bound for this CPU.
+    The first clips' logits of the caffe_cost run are the parity reference for the GPU's."""
+    import numpy as np
+    import torch
+    from eco_amd.netspec import NetSpec
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import eco_oracle  # checker/baseline only; never on the product path
+    import eco_ref     # compiled reference sources (oracle/_ref), test infrastructure
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    spec1 = NetSpec.from_prototxt(gen(num_segments=N, num_clips=1))
+    out_name = spec1.outputs[0]
+    have_ref = eco_ref.available()
+
+    def torch_conv(x, w, b, kernel, stride, pad):
+        f = torch.nn.functional.conv2d if len(kernel) == 2 else torch.nn.functional.conv3d
+        with torch.no_grad():
+            return f(torch.from_numpy(x), torch.from_numpy(np.ascontiguousarray(w, np.float32)),
+                     None if b is None else torch.from_numpy(np.ascontiguousarray(b, np.float32)), tuple(stride),
+                     tuple(pad)).numpy()
+
+    def run(conv_impl, budget_s, max_clips, clips_at_once=1):
+        done, t_cpu, refs = 0, 0.0, []
+        while done < max_clips:
+            k = min(clips_at_once, max_clips - done)
+            specs = spec1 if k == 1 else NetSpec.from_prototxt(gen(num_segments=N, num_clips=k))
+            x1 = frames[done * N:(done + k) * N]
+            t1 = time.perf_counter()
+            refs.append(eco_oracle.forward(specs, params, {"data": x1}, conv_impl=conv_impl)[out_name])
+            t_cpu += time.perf_counter() - t1
+            done += k
+            if not args.cpu_clips and t_cpu >= budget_s:
+                break
+        return done, t_cpu, np.concatenate(refs, 0)
+
+    variants = {}
+    max_clips = args.cpu_clips or 8
+    if have_ref:
+        eco_ref.set_blas_threads(cores)
+        d, t, ref = run(lambda *a: eco_ref.convolution(*a, image_threads=1), 10.0, max_clips)
+        variants["caffe_cost"] = dict(clips_per_s=round(d / t, 4), clips=d, seconds=round(t, 2), blas_threads=cores,
+                                      kind="reference im2col (compiled from util/im2col.cpp) + OpenBLAS sgemm, images in sequence")
+        d2, t2, _ = run(lambda *a: eco_ref.convolution(*a, image_threads=cores), 8.0, max_clips, clips_at_once=min(8, max_clips))
+        variants["image_parallel"] = dict(clips_per_s=round(d2 / t2, 4), clips=d2, seconds=round(t2, 2), blas_threads=1,
+                                          image_threads=cores, kind="same arithmetic, images spread over the cores")
+    else:  # oracle/_ref not shipped: the NumPy restatement (np.matmul = OpenBLAS sgemm)
+        d, t, ref = run(None, 10.0, max_clips)
+        variants["caffe_cost"] = dict(clips_per_s=round(d / t, 4), clips=d, seconds=round(t, 2), blas_threads=cores,
+                                      kind="NumPy restatement (im2col_nd + np.matmul), images in sequence")
+    torch.set_num_threads(cores)
+    d3, t3, _ = run(torch_conv, 6.0, max_clips, clips_at_once=min(4, max_clips))
+    variants["torch_cpu"] = dict(clips_per_s=round(d3 / t3, 4), clips=d3, seconds=round(t3, 2), threads=cores,
+                                 kind="torch.nn.functional.conv2d/conv3d (courtesy upper bound, not the reference's structure)")
+    cc = variants["caffe_cost"]
+    flops_clip = spec1.conv_fc_flops()
+    cpu = {"value": cc["clips_per_s"], "unit": "clips/sec", "cores": cores,
+           "kind": "reference" if have_ref else "port",
+           "sample": f"{cc['clips']} clip(s) of the same workload (num_segments={N}; the first clips of rank 0's batch), "
+                     f"{cc['seconds']} s; conv = {cc['kind']} with {cores} BLAS threads, other layers NumPy "
+                     f"(oracle/eco_oracle.py); caffe_3d itself cannot be built here (DESIGN.md section 4)",
+           "gflops": round(cc["clips_per_s"] * flops_clip / 1e9, 1), "variants": variants}
+    done = cc["clips"]
+    got = logits[:done].detach().float().cpu().numpy()
+    denom = np.abs(ref).max()
+    per_class = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3 * denom)
+    parity = {"clips_checked": done, "max_rel_err": float(np.abs(got - ref).max() / denom),
+              "max_per_logit_rel_err": float(per_class.max()), "max_abs_logit": float(denom),
+              "top1_agree": bool((got.argmax(1) == ref.argmax(1)).all()),
+              "reference": "caffe_cost CPU run above", "tolerance": 1e-3 if args.dtype == "f32" else 3e-2}
+    return cpu, parity
 
 
 if __name__ == "__main__":

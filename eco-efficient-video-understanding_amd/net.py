@@ -326,6 +326,19 @@ class Net:
         self._forward(start_ind, end_ind)
         return {out: self.blobs[out].data for out in outputs}
 
+    def set_input_device(self, name: str, tensor) -> None:
+        """Fill net input ``name`` from a torch tensor already on the device (fp32, any shape with the blob's
+        element count) without a host round trip; the blob's head moves to the device (extension used by
+        bench.py and the multi-GPU driver)."""
+        if name not in self._spec.inputs:
+            raise KeyError(f"{name!r} is not a net input")
+        if self._pending_input_shapes:
+            self.reshape()
+        dst = self.blobs[name].tensor          # marks the head DEVICE
+        if tensor.numel() != dst.numel():
+            raise ValueError(f"input {name}: {tensor.numel()} elements given, blob holds {dst.numel()}")
+        dst.copy_(tensor.reshape(dst.shape))
+
     def forward_device(self, graph: bool = False):
         """Run the whole net on whatever is resident in HBM; returns nothing and does not
         synchronise (extension used by bench.py / the multi-GPU driver).  ``graph=True`` replays the

@@ -345,15 +345,18 @@ def video_transform(frames_hwc_u8, crop_h, crop_w, h_off, w_off, mean, scale=1.0
 # --------------------------------------------------------------------------
 # whole-net forward (Net::ForwardFromTo, net.cpp:566-583)
 # --------------------------------------------------------------------------
-def forward(spec, params, inputs, keep=None, fast_pool=True, timings=None):
+def forward(spec, params, inputs, keep=None, fast_pool=True, timings=None, conv_impl=None):
     """Run ``spec`` (an ``eco_amd.netspec.NetSpec``) layer by layer in file order.
 
     ``params``: {layer name: [ndarray, ...]} in the reference's blob order
     (conv/fc: weight, bias; BN: scale, shift, running mean, running variance).
     ``inputs``: {input blob name: ndarray}.  Returns {blob name: ndarray} for the
     net outputs plus every name in ``keep`` (``keep='all'`` keeps everything).
-    In-place layers overwrite their blob exactly as the reference does."""
+    In-place layers overwrite their blob exactly as the reference does.
+    ``conv_impl(x, w, b, kernel, stride, pad)`` replaces the NumPy convolution (bench.py's CPU baselines plug in
+    the compiled reference im2col + OpenBLAS path of oracle/eco_ref.py, or torch-CPU)."""
     import time
+    conv_fn = conv_impl or convolution
     blobs = {k: np.ascontiguousarray(v, dtype=F32) for k, v in inputs.items()}
     pool_fn = pooling_fast if fast_pool else pooling
     last_use = {}
@@ -371,7 +374,7 @@ def forward(spec, params, inputs, keep=None, fast_pool=True, timings=None):
         g = L.geom
         if L.type == "Convolution":
             p = params[L.name]
-            top = [convolution(bt[0], p[0], p[1] if g["bias_term"] else None, g["kernel"], g["stride"], g["pad"])]
+            top = [conv_fn(bt[0], p[0], p[1] if g["bias_term"] else None, g["kernel"], g["stride"], g["pad"])]
         elif L.type == "BN":
             p = params[L.name]
             top = [bn_inference(bt[0], p[0], p[1], p[2], p[3], max(g["eps"], 1e-5) if bt[0].ndim > 4 else g["eps"])]

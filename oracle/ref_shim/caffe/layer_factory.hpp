@@ -1,0 +1,1 @@
+#pragma once  // oracle/ref_shim: no registry (layers are constructed directly by oracle/ref_shim/ref_api.cpp)

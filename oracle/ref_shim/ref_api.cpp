@@ -1,0 +1,119 @@
+// oracle/ref_shim/ref_api.cpp -- TEST INFRASTRUCTURE.  C entry points over the reference sources that are
+// compiled, unmodified, from /root/reference into oracle/_ref/libeco_ref.so (see oracle/Makefile):
+//   caffe_3d/src/caffe/util/im2col.cpp            im2col_cpu / im2col_nd_cpu
+//   caffe_3d/src/caffe/layers/pooling_layer.cpp   PoolingLayer::LayerSetUp / Reshape / Forward_cpu
+// plus a convolution forward that performs exactly the call sequence of ConvolutionLayer::Forward_cpu
+// (layers/conv_layer.cpp:28-43 -> BaseConvolutionLayer::forward_cpu_gemm / forward_cpu_bias,
+// layers/base_conv_layer.cpp:264-287 -> caffe_cpu_gemm, util/math_functions.cpp:12-21): per image, the
+// REFERENCE im2col into a col buffer, one cblas_sgemm W[cout x K] * col[K x S], and the bias as a rank-1 sgemm
+// against an all-ones multiplier.  cblas_sgemm is the one third-party routine (the reference links
+// ATLAS/OpenBLAS/MKL, unpinned); here it is SciPy's bundled OpenBLAS, resolved at run time by the Python side
+// and handed in as a function pointer, so this library links nothing.
+// Used to pin oracle/eco_oracle.py (tests/test_oracle_ref.py) and as bench.py's CPU baseline.
+#include <thread>
+
+#include "caffe/util/im2col.hpp"
+#include "caffe/util/math_functions.hpp"
+#include "caffe/vision_layers.hpp"
+
+using namespace caffe;
+
+extern "C" {
+
+typedef void (*sgemm_fn)(int order, int transa, int transb, int m, int n, int k, float alpha, const float* a, int lda,
+                         const float* b, int ldb, float beta, float* c, int ldc);
+enum { kRowMajor = 101, kNoTrans = 111 };
+
+// conv_im2col_cpu (include/caffe/vision_layers.hpp:102-114): 2-D layers use im2col_cpu, N-D layers im2col_nd_cpu.
+// in_shape = {C, spatial...}; col_shape = {C*prod(kernel), out...}.
+void ref_im2col(const float* x, int nsp, const int* in_shape, const int* col_shape, const int* kernel, const int* pad,
+                const int* stride, float* col) {
+  if (nsp == 2)
+    im2col_cpu(x, in_shape[0], in_shape[1], in_shape[2], kernel[0], kernel[1], pad[0], pad[1], stride[0], stride[1], col);
+  else
+    im2col_nd_cpu(x, nsp, in_shape, col_shape, kernel, pad, stride, col);
+}
+
+// ConvolutionLayer::Forward_cpu for one bottom.  image_threads == 1 is the reference's structure (images in
+// sequence, BLAS free to use its threads); image_threads > 1 spreads the images over that many host threads
+// (each with its own col buffer; the caller sets BLAS to one thread) -- same arithmetic per image.
+int ref_conv_forward(const float* x, const float* w, const float* bias, float* y, int n, int cin, int cout, int nsp,
+                     const int* in_sp, const int* kernel, const int* stride, const int* pad, sgemm_fn sgemm,
+                     int image_threads) {
+  if (nsp < 1 || nsp > 3 || !sgemm) return -1;
+  int in_shape[4], col_shape[4], out_sp[3];
+  in_shape[0] = cin;
+  long s_in = 1, s_out = 1, kdim = cin;
+  bool is_1x1 = true;
+  for (int i = 0; i < nsp; ++i) {
+    in_shape[1 + i] = in_sp[i];
+    out_sp[i] = (in_sp[i] + 2 * pad[i] - kernel[i]) / stride[i] + 1;   // conv_layer.cpp:19-22
+    col_shape[1 + i] = out_sp[i];
+    s_in *= in_sp[i]; s_out *= out_sp[i]; kdim *= kernel[i];
+    is_1x1 = is_1x1 && kernel[i] == 1 && stride[i] == 1 && pad[i] == 0;  // base_conv_layer.cpp:110-117
+  }
+  col_shape[0] = (int)kdim;
+  const long bottom_dim = (long)cin * s_in, top_dim = (long)cout * s_out;
+  std::vector<float> ones((size_t)s_out, 1.0f);                          // bias_multiplier_ (:255-260)
+  auto run = [&](int n0, int n1) {
+    std::vector<float> col(is_1x1 ? 0 : (size_t)(kdim * s_out));
+    for (int i = n0; i < n1; ++i) {
+      const float* xi = x + i * bottom_dim;
+      float* yi = y + i * top_dim;
+      const float* col_buff = xi;
+      if (!is_1x1) {
+        ref_im2col(xi, nsp, in_shape, col_shape, kernel, pad, stride, col.data());
+        col_buff = col.data();
+      }
+      sgemm(kRowMajor, kNoTrans, kNoTrans, cout, (int)s_out, (int)kdim, 1.0f, w, (int)kdim, col_buff, (int)s_out, 0.0f,
+            yi, (int)s_out);
+      if (bias)
+        sgemm(kRowMajor, kNoTrans, kNoTrans, cout, (int)s_out, 1, 1.0f, bias, 1, ones.data(), (int)s_out, 1.0f, yi,
+              (int)s_out);
+    }
+  };
+  if (image_threads <= 1 || n == 1) {
+    run(0, n);
+  } else {
+    const int t = image_threads < n ? image_threads : n;
+    std::vector<std::thread> th;
+    for (int k = 0; k < t; ++k) th.emplace_back(run, (int)((long)n * k / t), (int)((long)n * (k + 1) / t));
+    for (auto& q : th) q.join();
+  }
+  return 0;
+}
+
+// PoolingLayer (2-D blobs: the only case the reference's CPU Forward implements, pooling_layer.cpp:177-201).
+// method: 0 MAX, 1 AVE.  shape = {n, c, h, w}; out_shape receives the pooled shape; y may be NULL to query it.
+// kernel == NULL means global_pooling.
+int ref_pool_forward(const float* x, const int* shape, int naxes, int method, const int* kernel, const int* stride,
+                     const int* pad, float* y, int* out_shape) {
+  LayerParameter lp;
+  PoolingParameter* pp = lp.mutable_pooling_param();
+  pp->pool_ = method == 0 ? PoolingParameter_PoolMethod_MAX : PoolingParameter_PoolMethod_AVE;
+  const int nsp = naxes - 2;
+  if (!kernel) {
+    pp->global_pooling_ = true;
+  } else {
+    for (int i = 0; i < nsp; ++i) pp->kernel_size_.push_back(kernel[i]);
+  }
+  for (int i = 0; i < nsp; ++i) {
+    if (stride) pp->stride_.push_back(stride[i]);
+    if (pad) pp->pad_.push_back(pad[i]);
+  }
+  PoolingLayer<float> layer(lp);
+  Blob<float> bottom, top;
+  bottom.Reshape(std::vector<int>(shape, shape + naxes));
+  std::vector<Blob<float>*> bv(1, &bottom), tv(1, &top);
+  layer.LayerSetUp(bv, tv);
+  layer.Reshape(bv, tv);
+  for (int i = 0; i < naxes; ++i) out_shape[i] = top.shape(i);
+  if (!y) return 0;
+  if (naxes != 4) return -1;
+  caffe_copy(bottom.count(), x, bottom.mutable_cpu_data());
+  layer.Forward_cpu(bv, tv);
+  caffe_copy(top.count(), top.cpu_data(), y);
+  return 0;
+}
+
+}  // extern "C"
