@@ -1,0 +1,861 @@
+// eco_blocked.hip -- the channel-blocked ("NC8") path on the bf16 matrix cores of gfx950.
+//
+// BASELINE.json configs[4] asks for ECO-Lite in bf16.  v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32
+// MFMA the NCHW kernels of eco_conv.hip use, and every lane must hand it EIGHT consecutive reduction elements of
+// one output channel (A) / one output position (B).  With the reference's N,C,[D,]H,W layout those eight would be
+// eight channel planes apart; so this path keeps activations channel-blocked,
+//
+//     X[n][c/8][d][h][w][c%8]          ("NC8": 8 channels of one position = one 16-byte vector of bf16)
+//
+// which makes a lane's operand ONE 16-byte load (global or LDS), keeps every streaming kernel at 16 bytes per
+// lane with consecutive lanes on consecutive positions, and still lets Concat (channel offsets are multiples of 8
+// in every ECO graph) and r2Dto3D+Permute be pure stride arithmetic in the producer's epilogue.  The layout is
+// internal: the `data` input stays fp32 N,3,H,W (eco_stem_pack_forward re-lays it), the logits leave as fp32
+// [B, classes], and the host mirrors blobs back to N,C,... fp32 when a caller looks at them.
+//
+// Storage type `dt`:  ECO_DT_BF16  -- bf16 activations and weights, fp32 accumulation, fp32 bias / BN parameters:
+//                                     the configs[4] arithmetic.
+//                     ECO_DT_F32X3 -- fp32 activations and weights in the same blocked layout; each operand is
+//                                     split exactly into three bf16 terms (x = x0 + x1 + x2, 8+8+8 mantissa bits)
+//                                     and the six products of order <= 2 are accumulated in fp32: fp32-class
+//                                     results (dropped terms are <= 2^-24 relative, the size of one fp32
+//                                     rounding) at 16/6 of the fp32-MFMA rate.
+//
+// Replaces, for this storage layout, the same reference operators as eco_conv.hip / eco_ops.hip:
+//   ConvolutionLayer::Forward (conv_layer.cpp:28-43, base_conv_layer.cpp:264-287, cudnn_conv_layer.cu:15-65) with
+//   the BN / ReLU / Eltwise / Concat / Reshape+Permute layers fused behind it (bn_layer.cpp:93-207,
+//   relu_layer.cpp:10-20, eltwise_layer.cpp:66-72, concat_layer.cpp:54-70, permute_layer.cpp:9-26),
+//   PoolingLayer::Forward (pooling_layer.cpp:131-147,199-262; cudnn_pooling_layer.cu:13-22) and the
+//   global_pool -> reshape -> dropout -> fc tail (inner_product_layer.cu:14-25).
+#include <float.h>
+#include <string.h>
+
+#include "eco_common.h"
+
+namespace eco {
+
+constexpr int kCbs = 4;   // channel blocks (of 8) per reduction stage: 32 reduction elements, two MFMA k-steps
+
+struct ConvBArgs {
+  const void* x;
+  const uint4* wp;
+  const float* bias;
+  const float* bn_scale;
+  const float* bn_shift;
+  eco_view residual, raw, act;   // blocked views: strides in 8-channel blocks
+  int relu;
+  int cblocks, cout, mpad, nstages, taps;
+  int Di, Hi, Wi, Do, Ho, Wo;
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+  long img_stride_in, cb_stride_in;   // in blocks
+  int s_out, ntot, nblk_m, nblk_n, ksplit;
+  float* ws;
+};
+
+// ---- element helpers: NS = 1 -> bf16 storage, NS = 3 -> fp32 storage split into three bf16 terms -----------------
+template <int NS>
+struct BlockVec;   // the 8 channels of one position as they sit in memory
+template <>
+struct BlockVec<1> { uint4 v; };
+template <>
+struct BlockVec<3> { float4 lo, hi; };
+
+template <int NS>
+__device__ __forceinline__ BlockVec<NS> load_block(const void* base, long block);
+template <>
+__device__ __forceinline__ BlockVec<1> load_block<1>(const void* base, long block) {
+  BlockVec<1> r;
+  r.v = ld((const uint4*)base + block);
+  return r;
+}
+template <>
+__device__ __forceinline__ BlockVec<3> load_block<3>(const void* base, long block) {
+  BlockVec<3> r;
+  r.lo = ld((const float4*)base + 2 * block);
+  r.hi = ld((const float4*)base + 2 * block + 1);
+  return r;
+}
+
+// x = t0 + t1 + t2 exactly, each term a bf16 (round to nearest even at every step: the residuals are exact fp32
+// subtractions, and the third residual fits the 8 significant bits of a bf16).
+__device__ __forceinline__ void split3(float x, unsigned& t0, unsigned& t1, unsigned& t2) {
+  t0 = f32_to_bf16_bits(x);
+  const float r1 = x - bf16_bits_to_f32(t0);
+  t1 = f32_to_bf16_bits(r1);
+  const float r2 = r1 - bf16_bits_to_f32(t1);
+  t2 = f32_to_bf16_bits(r2);
+}
+
+// The NS 16-byte bf16 operand vectors of a block (zeroed when !ok: zero padding of the convolution).
+template <int NS>
+__device__ __forceinline__ void to_operands(const BlockVec<NS>& b, bool ok, uint4 (&out)[NS]);
+template <>
+__device__ __forceinline__ void to_operands<1>(const BlockVec<1>& b, bool ok, uint4 (&out)[1]) {
+  out[0] = ok ? b.v : make_uint4(0u, 0u, 0u, 0u);
+}
+template <>
+__device__ __forceinline__ void to_operands<3>(const BlockVec<3>& b, bool ok, uint4 (&out)[3]) {
+  const float f[8] = {b.lo.x, b.lo.y, b.lo.z, b.lo.w, b.hi.x, b.hi.y, b.hi.z, b.hi.w};
+  unsigned t[3][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) split3(ok ? f[e] : 0.0f, t[0][e], t[1][e], t[2][e]);
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+    out[p] = make_uint4(t[p][0] | (t[p][1] << 16), t[p][2] | (t[p][3] << 16), t[p][4] | (t[p][5] << 16),
+                        t[p][6] | (t[p][7] << 16));
+}
+
+// Four consecutive channels (elements 4*half .. 4*half+3 of a block) to / from memory.
+template <int NS>
+__device__ __forceinline__ void load_quad(const void* base, long block, int half, float (&v)[4]);
+template <>
+__device__ __forceinline__ void load_quad<1>(const void* base, long block, int half, float (&v)[4]) {
+  const uint2 q = ld((const uint2*)base + 2 * block + half);
+  v[0] = bf16_bits_to_f32(q.x & 0xffffu); v[1] = bf16_bits_to_f32(q.x >> 16);
+  v[2] = bf16_bits_to_f32(q.y & 0xffffu); v[3] = bf16_bits_to_f32(q.y >> 16);
+}
+template <>
+__device__ __forceinline__ void load_quad<3>(const void* base, long block, int half, float (&v)[4]) {
+  const float4 q = ld((const float4*)base + 2 * block + half);
+  v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+template <int NS>
+__device__ __forceinline__ void store_quad(void* base, long block, int half, const float (&v)[4]);
+template <>
+__device__ __forceinline__ void store_quad<1>(void* base, long block, int half, const float (&v)[4]) {
+  st((uint2*)base + 2 * block + half, make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])));
+}
+template <>
+__device__ __forceinline__ void store_quad<3>(void* base, long block, int half, const float (&v)[4]) {
+  st((float4*)base + 2 * block + half, make_float4(v[0], v[1], v[2], v[3]));
+}
+
+__device__ __forceinline__ void decode_out(const ConvBArgs& a, int n, int& img, int& sp) {
+  img = n / a.s_out;
+  sp = n - img * a.s_out;
+}
+
+// Fused epilogue (same algebra as conv_epilogue in eco_conv.hip) on blocked views.  Register r of lane l holds
+// channel mw + i*32 + (r&3) + 8*(r>>2) + 4*(l>>5) at position nw + j*32 + (l&31): the four registers of a group
+// g = r>>2 are four consecutive channels = half of one 8-channel block, so lanes l and l+32 together write whole
+// 16-byte (bf16) / 32-byte (fp32) vectors, and consecutive lanes write consecutive vectors.
+template <int TM, int TN, int NS>
+__device__ __forceinline__ void convb_epilogue(const ConvBArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw, int half,
+                                               int l31) {
+  long e_res[TN], e_raw[TN], e_act[TN];
+  bool e_ok[TN];
+  const bool has_bias = a.bias != nullptr, has_bn = a.bn_scale != nullptr, has_res = a.residual.ptr != nullptr;
+  const bool has_raw = a.raw.ptr != nullptr, has_act = a.act.ptr != nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = nw + j * 32 + l31;
+    e_ok[j] = n < a.ntot;
+    int img, sp;
+    decode_out(a, e_ok[j] ? n : 0, img, sp);
+    e_res[j] = has_res ? view_base(a.residual, img, sp) : 0;
+    e_raw[j] = has_raw ? view_base(a.raw, img, sp) : 0;
+    e_act[j] = has_act ? view_base(a.act, img, sp) : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ch0 = mw + i * 32 + 8 * g + 4 * half;
+      if (ch0 >= a.cout) continue;   // cout is a multiple of 8: the quad is inside or outside as a whole
+      const int cbk = (mw + i * 32) / 8 + g;
+      float pb[4], ps[4], ph[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        pb[q] = has_bias ? ld(a.bias + ch0 + q) : 0.0f;
+        ps[q] = has_bn ? ld(a.bn_scale + ch0 + q) : 1.0f;
+        ph[q] = has_bn ? ld(a.bn_shift + ch0 + q) : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!e_ok[j]) continue;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q] + pb[q];
+        if (has_res) {
+          float rv[4];
+          load_quad<NS>(a.residual.ptr, e_res[j] + (long)cbk * a.residual.stride_c, half, rv);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += rv[q];
+        }
+        if (has_raw) store_quad<NS>(a.raw.ptr, e_raw[j] + (long)cbk * a.raw.stride_c, half, v);
+        if (has_act) {
+          float y[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            y[q] = v[q] * ps[q] + ph[q];
+            if (a.relu) y[q] = fmaxf(y[q], 0.0f);
+          }
+          store_quad<NS>(a.act.ptr, e_act[j] + (long)cbk * a.act.stride_c, half, y);
+        }
+      }
+    }
+  }
+}
+
+// Split-K partial sums: ws[slice][channel][position] fp32 (positions contiguous per lane group).
+template <int TM, int TN>
+__device__ __forceinline__ void convb_store_partial(const ConvBArgs& a, f32x16 (&acc)[TM][TN], int slice, int mw, int nw,
+                                                    int half, int l31) {
+  float* base = a.ws + (long)slice * a.cout * a.ntot;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = nw + j * 32 + l31;
+    if (n >= a.ntot) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (ch < a.cout) st(base + (long)ch * a.ntot + n, acc[i][j][r]);
+      }
+  }
+}
+
+// Second pass of split-K: one thread per (position, 8-channel block) sums the slices in a fixed order and applies
+// the epilogue; writes whole blocks.
+template <int NS>
+__global__ __launch_bounds__(256) void convb_splitk_reduce_kernel(const ConvBArgs a) {
+  const long total = (long)(a.cout / 8) * a.ntot;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int cbk = (int)(idx / a.ntot), n = (int)(idx - (long)cbk * a.ntot);
+    int img, sp;
+    decode_out(a, n, img, sp);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int ch0 = cbk * 8 + 4 * half;
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float s = 0.0f;
+        for (int sl = 0; sl < a.ksplit; ++sl) s += ld(a.ws + ((long)sl * a.cout + ch0 + q) * a.ntot + n);
+        v[q] = s + (a.bias ? ld(a.bias + ch0 + q) : 0.0f);
+      }
+      if (a.residual.ptr) {
+        float rv[4];
+        load_quad<NS>(a.residual.ptr, view_base(a.residual, img, sp) + (long)cbk * a.residual.stride_c, half, rv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += rv[q];
+      }
+      if (a.raw.ptr) store_quad<NS>(a.raw.ptr, view_base(a.raw, img, sp) + (long)cbk * a.raw.stride_c, half, v);
+      if (a.act.ptr) {
+        float y[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          y[q] = v[q] * (a.bn_scale ? ld(a.bn_scale + ch0 + q) : 1.0f) + (a.bn_scale ? ld(a.bn_shift + ch0 + q) : 0.0f);
+          if (a.relu) y[q] = fmaxf(y[q], 0.0f);
+        }
+        store_quad<NS>(a.act.ptr, view_base(a.act, img, sp) + (long)cbk * a.act.stride_c, half, y);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on blocked operands.  GEMM view: m = output channel, n = flattened (image, od, oh, ow)
+// position, reduction in stages (cg, tap) of 4 channel blocks = 32 elements, cg-major (consecutive stages walk the
+// taps of the same 32 channels: the re-reads of a tap-shifted window are L1/L2 hits).  Per stage every thread
+// fetches its position's blocks as 16-byte vectors (one predicate per stage for the zero padding: all 32 elements
+// share the tap) and its share of the packed weights wp[plane][stage][4][mpad] (16-byte vectors, consecutive
+// threads on consecutive channels), both land in double-buffered LDS as [block][channel or position] so that a
+// wave's fragment read is 32 consecutive 16-byte vectors per half-wave (conflict-free ds_read_b128), and each wave
+// accumulates TM x TN 32x32 tiles with two MFMA k-steps per stage (x6 products for the split form).
+template <int TM, int TN, int WM, int WN, int NS>
+__global__ __launch_bounds__(256, 2) void convb_kernel(const ConvBArgs a) {
+  constexpr int BM = 32 * TM * WM;
+  constexpr int BN = 32 * TN * WN;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(BN == 128 || BN == 256, "");
+  constexpr int KG = 256 / BN;       // threads sharing one position
+  constexpr int CPT = kCbs / KG;     // channel blocks per thread per stage
+  constexpr int A_V = kCbs * BM;     // weight vectors per stage and split plane
+  constexpr int A_IT = (NS * A_V + 255) / 256;
+
+  ECO_DYNAMIC_LDS(lds_f);
+  uint4* As = (uint4*)lds_f;                  // [2][NS][kCbs][BM]
+  uint4* Bs = As + 2 * NS * kCbs * BM;        // [2][NS][kCbs][BN]
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int ntiles = a.nblk_m * a.nblk_n;
+  const int slice = (int)blockIdx.x / ntiles;
+  const int tile = xcd_remap((int)blockIdx.x - slice * ntiles, ntiles);
+  const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
+  const int m0 = mblk * BM, n0 = nblk * BN;
+  const int s_begin = (int)((long)slice * a.nstages / a.ksplit);
+  const int s_end = (int)((long)(slice + 1) * a.nstages / a.ksplit);
+
+  // ---- this thread's position: input base (in blocks) and tap-validity mask ----
+  const int pos_l = tid % BN;
+  const int kg = uniform(tid / BN);
+  const int khw = a.kh * a.kw;
+  long in_base = 0;
+  unsigned long long mask = 0ull;
+  {
+    const int n = n0 + pos_l;
+    if (n < a.ntot) {
+      int img, sp;
+      decode_out(a, n, img, sp);
+      const int ow = sp % a.Wo, t = sp / a.Wo;
+      const int oh = t % a.Ho, od = t / a.Ho;
+      const int id0 = od * a.sd - a.pd, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
+      in_base = (long)img * a.img_stride_in + ((long)id0 * a.Hi + ih0) * a.Wi + iw0;
+      unsigned long long mw_ = 0ull, mhw = 0ull;
+      for (int xx = 0; xx < a.kw; ++xx) mw_ |= (unsigned long long)((unsigned)(iw0 + xx) < (unsigned)a.Wi) << xx;
+      for (int y = 0; y < a.kh; ++y)
+        if ((unsigned)(ih0 + y) < (unsigned)a.Hi) mhw |= mw_ << (y * a.kw);
+      for (int z = 0; z < a.kd; ++z)
+        if ((unsigned)(id0 + z) < (unsigned)a.Di) mask |= mhw << (z * khw);
+    }
+  }
+
+  // ---- the stage being loaded: uniform (cg, tap) walk ----
+  int l_cg = s_begin / a.taps, l_tap = s_begin - l_cg * a.taps;
+  int l_kx = l_tap % a.kw, l_ky = (l_tap / a.kw) % a.kh, l_kz = l_tap / khw;
+  int l_stage = s_begin;
+  BlockVec<NS> breg[CPT];
+  uint4 areg[A_IT];
+  bool b_ok = false;
+  auto load_stage = [&]() {
+    const long toff = ((long)l_kz * a.Hi + l_ky) * a.Wi + l_kx;
+    b_ok = (mask >> l_tap) & 1ull;
+    const long base = b_ok ? in_base + toff : 0;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      const int c = kg + j * KG;
+      breg[j] = load_block<NS>(a.x, base + (long)(l_cg * kCbs + c) * a.cb_stride_in);
+    }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int idx = tid + i * 256;
+      if ((NS * A_V) % 256 == 0 || idx < NS * A_V) {
+        const int p = idx / A_V, r = idx - p * A_V;
+        const int row = r / BM, m = r - row * BM;
+        areg[i] = ld(a.wp + (((long)p * a.nstages + l_stage) * kCbs + row) * a.mpad + m0 + m);
+      }
+    }
+  };
+  auto advance = [&]() {
+    ++l_stage;
+    ++l_tap;
+    if (++l_kx == a.kw) {
+      l_kx = 0;
+      if (++l_ky == a.kh) {
+        l_ky = 0;
+        if (++l_kz == a.kd) { l_kz = 0; l_tap = 0; ++l_cg; }
+      }
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int idx = tid + i * 256;
+      if ((NS * A_V) % 256 == 0 || idx < NS * A_V) As[buf * NS * A_V + idx] = areg[i];
+    }
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      uint4 ops[NS];
+      to_operands<NS>(breg[j], b_ok, ops);
+      const int c = kg + j * KG;
+#pragma unroll
+      for (int p = 0; p < NS; ++p) Bs[((buf * NS + p) * kCbs + c) * BN + pos_l] = ops[p];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int ks = 0; ks < kCbs / 2; ++ks) {
+      uint4 af[NS][TM], bf[NS][TN];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[p][i] = As[((buf * NS + p) * kCbs + 2 * ks + half) * BM + (wm * TM + i) * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[p][j] = Bs[((buf * NS + p) * kCbs + 2 * ks + half) * BN + (wn * TN + j) * 32 + l31];
+      }
+      // products of total order <= NS-1, smallest terms first
+#pragma unroll
+      for (int ord = NS - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int p = 0; p <= ord; ++p)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16_bf16(af[p][i], bf[ord - p][j], acc[i][j]);
+    }
+  };
+
+  if (s_begin < s_end) {
+    load_stage();
+    store_stage(0);
+    __syncthreads();
+    for (int s = s_begin; s + 1 < s_end; ++s) {
+      const int buf = (s - s_begin) & 1;
+      advance();
+      load_stage();          // next stage's global loads are in flight under this stage's MFMAs
+      compute(buf);
+      store_stage(buf ^ 1);
+      __syncthreads();
+    }
+    compute((s_end - 1 - s_begin) & 1);
+  }
+  if (a.ksplit > 1)
+    convb_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+  else
+    convb_epilogue<TM, TN, NS>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stem input: fp32 N,3,H,W (the `data` blob, VideoData contract) -> zero-padded pixel-interleaved image
+//   P[f][h + 3][w + 3][4] (channel 3 = 0), rows of W + 8 pixels, H + 6 rows
+// in the path's storage type.  For conv1_7x7_s2 (stride 2, pad 3) the seven taps of kernel row ky of output
+// (oh, ow) are then the 28 consecutive elements that start at block (2*oh + ky)*(W+8)/2 + ow: the stem runs as an
+// ordinary blocked convolution with 4 "channel blocks" (kx pairs), a (1,7,1) kernel over rows, stride (1,2,1), no
+// padding and no predicates.  One thread per output block (2 pixels).  HBM-bound: 24 B read, 16 / 32 B written.
+template <int NS>
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* x, void* y, long frames, int H, int W) {
+  const int wb = (W + 8) / 2, hp = H + 6;
+  const long total = frames * hp * wb;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int b = (int)(i % wb);
+    const long t = i / wb;
+    const int r = (int)(t % hp);
+    const long f = t / hp;
+    const int h = r - 3;
+    float v[8];
+#pragma unroll
+    for (int px = 0; px < 2; ++px) {
+      const int w = 2 * b + px - 3;
+      const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[4 * px + c] = ok ? ld(x + ((f * 3 + c) * H + (ok ? h : 0)) * (long)W + (ok ? w : 0)) : 0.0f;
+      v[4 * px + 3] = 0.0f;
+    }
+    const float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
+    store_quad<NS>(y, i, 0, lo);
+    store_quad<NS>(y, i, 1, hi);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Pooling on blocked tensors: one thread per (image, block, od, oh, ow) = eight channels of one output position,
+// every window element one 16-byte (bf16) / two 16-byte (fp32) loads; consecutive lanes take consecutive output
+// positions.  Window rules as pool_kernel in eco_ops.hip (Caffe ceil rule; MAX clips to the image, AVE divides by
+// the window size including padding clipped to in+pad).  Overlapping windows re-read through L1/L2.
+struct PoolBArgs {
+  const void* x;
+  void* y;
+  long total;  // n * cblocks * Do*Ho*Wo
+  int Di, Hi, Wi, Do, Ho, Wo;
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+  int method;
+};
+
+template <int NS>
+__device__ __forceinline__ void block_to_f32(const BlockVec<NS>& b, float (&f)[8]);
+template <>
+__device__ __forceinline__ void block_to_f32<1>(const BlockVec<1>& b, float (&f)[8]) {
+  const unsigned w[4] = {b.v.x, b.v.y, b.v.z, b.v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f[2 * e] = bf16_bits_to_f32(w[e] & 0xffffu); f[2 * e + 1] = bf16_bits_to_f32(w[e] >> 16); }
+}
+template <>
+__device__ __forceinline__ void block_to_f32<3>(const BlockVec<3>& b, float (&f)[8]) {
+  f[0] = b.lo.x; f[1] = b.lo.y; f[2] = b.lo.z; f[3] = b.lo.w; f[4] = b.hi.x; f[5] = b.hi.y; f[6] = b.hi.z; f[7] = b.hi.w;
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void poolb_kernel(const PoolBArgs a) {
+  const long s_in = (long)a.Di * a.Hi * a.Wi;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (long)gridDim.x * 256) {
+    const int ow = (int)(i % a.Wo);
+    long t = i / a.Wo;
+    const int oh = (int)(t % a.Ho);
+    t /= a.Ho;
+    const int od = (int)(t % a.Do);
+    const long ncb = t / a.Do;
+    const long xb = ncb * s_in;
+    int ds = od * a.sd - a.pd, hs = oh * a.sh - a.ph, ws = ow * a.sw - a.pw;
+    float r[8];
+    if (a.method == ECO_POOL_MAX) {
+      const int de = min(ds + a.kd, a.Di), he = min(hs + a.kh, a.Hi), we = min(ws + a.kw, a.Wi);
+      ds = max(ds, 0); hs = max(hs, 0); ws = max(ws, 0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = -FLT_MAX;
+      for (int d = ds; d < de; ++d)
+        for (int h = hs; h < he; ++h)
+          for (int w = ws; w < we; ++w) {
+            float f[8];
+            block_to_f32<NS>(load_block<NS>(a.x, xb + ((long)d * a.Hi + h) * a.Wi + w), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = fmaxf(r[e], f[e]);
+          }
+    } else {
+      int de = min(ds + a.kd, a.Di + a.pd), he = min(hs + a.kh, a.Hi + a.ph), we = min(ws + a.kw, a.Wi + a.pw);
+      const float size = (float)((de - ds) * (he - hs) * (we - ws));
+      ds = max(ds, 0); hs = max(hs, 0); ws = max(ws, 0);
+      de = min(de, a.Di); he = min(he, a.Hi); we = min(we, a.Wi);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = 0.0f;
+      for (int d = ds; d < de; ++d)
+        for (int h = hs; h < he; ++h)
+          for (int w = ws; w < we; ++w) {
+            float f[8];
+            block_to_f32<NS>(load_block<NS>(a.x, xb + ((long)d * a.Hi + h) * a.Wi + w), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] += f[e];
+          }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] /= size;
+    }
+    const float lo[4] = {r[0], r[1], r[2], r[3]}, hi[4] = {r[4], r[5], r[6], r[7]};
+    store_quad<NS>(a.y, i, 0, lo);
+    store_quad<NS>(a.y, i, 1, hi);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// global_pool (AVE over the whole volume) -> reshape -> dropout(TEST) -> fc on a blocked volume x[b][c/8][s][8]:
+// grid = (ceil(n_out/128), b), 1024 threads.  Pooling: one wave per channel block, lanes stride over the s
+// positions accumulating 8 channels each, 64-lane butterfly per channel; then one wave per logit as in
+// global_avgpool_fc_kernel.  fp32 weights / bias / logits whatever the storage type.
+constexpr int kTailBThreads = 1024;
+constexpr int kTailBMaxC = 2048;
+constexpr int kTailBOut = 128;
+
+template <int NS>
+__global__ __launch_bounds__(1024) void global_avgpool_fc_b_kernel(const void* x, const float* w, const float* bias,
+                                                                   float* y, int c, int s, int n_out, int wk, int c0,
+                                                                   int accumulate) {
+  __shared__ float pooled[kTailBMaxC];
+  constexpr int kWaves = kTailBThreads / kWave;
+  const int lane = lane_id();
+  const int wave = uniform((int)(threadIdx.x >> 6));
+  const int b = (int)blockIdx.y;
+  const int cblocks = c / 8;
+  const float inv = 1.0f / (float)s;
+  for (int cb = wave; cb < cblocks; cb += kWaves) {
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+    const long base = ((long)b * cblocks + cb) * s;
+    for (int i = lane; i < s; i += kWave) {
+      float f[8];
+      block_to_f32<NS>(load_block<NS>(x, base + i), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += f[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = wave_sum(acc[e]);
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pooled[cb * 8 + e] = acc[e] * inv;
+    }
+  }
+  __syncthreads();
+  const int o_begin = (int)blockIdx.x * kTailBOut;
+  const int o_end = min(o_begin + kTailBOut, n_out);
+  for (int o = o_begin + wave; o < o_end; o += kWaves) {
+    const float* wr = w + (long)o * wk + c0;
+    float acc = 0.0f;
+    for (int i = lane; i < c; i += kWave) acc += pooled[i] * ld(wr + i);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      float* yp = y + (long)b * n_out + o;
+      float v = acc + (bias ? ld(bias + o) : 0.0f);
+      if (accumulate) v += ld((const float*)yp);
+      st(yp, v);
+    }
+  }
+}
+
+static int grid_for_b(long count) {
+  long g = ceil_div(count, 256);
+  if (g < 1) g = 1;
+  if (g > 1048576) g = 1048576;
+  return (int)g;
+}
+
+static bool is_stem(const eco_conv_geom* g) {
+  return g->cin == 3 && g->in[0] == 1 && g->kernel[0] == 1 && g->kernel[1] == 7 && g->kernel[2] == 7 &&
+         g->stride[1] == 2 && g->stride[2] == 2 && g->pad[1] == 3 && g->pad[2] == 3 && g->in[2] % 2 == 0;
+}
+
+static int ns_of(int dt) { return dt == ECO_DT_BF16 ? 1 : dt == ECO_DT_F32X3 ? 3 : 0; }
+
+static uint16_t host_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static float host_bf16_f32(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+}  // namespace eco
+
+using namespace eco;
+
+static int validate_convb_geom(const eco_conv_geom* g, int dt) {
+  ECO_REQUIRE(g != nullptr, "convb: null geometry");
+  ECO_REQUIRE(ns_of(dt) != 0, "convb: storage type must be ECO_DT_BF16 or ECO_DT_F32X3 (got %d)", dt);
+  ECO_REQUIRE(g->n > 0 && g->cin > 0 && g->cout > 0, "convb: n/cin/cout must be positive");
+  long taps = 1;
+  for (int i = 0; i < 3; ++i) {
+    ECO_REQUIRE(g->in[i] > 0 && g->kernel[i] > 0 && g->stride[i] > 0 && g->pad[i] >= 0,
+                "convb: Filter/stride dimensions must be nonzero (axis %d)", i);
+    const int o = (g->in[i] + 2 * g->pad[i] - g->kernel[i]) / g->stride[i] + 1;
+    ECO_REQUIRE(g->in[i] + 2 * g->pad[i] >= g->kernel[i] && o == g->out[i],
+                "convb: output dim %d is %d, expected (in+2*pad-kernel)/stride+1 = %d", i, g->out[i], o);
+    taps *= g->kernel[i];
+  }
+  ECO_REQUIRE(taps < 63, "convb: %ld kernel taps exceed the 63-tap validity mask", taps);
+  ECO_REQUIRE(g->cout % 8 == 0, "convb: cout = %d is not a multiple of the 8-channel block", g->cout);
+  ECO_REQUIRE(is_stem(g) || g->cin % (8 * kCbs) == 0,
+              "convb: cin = %d is not a multiple of %d (the blocked kernels reduce 32 channels per stage; the only "
+              "other form is the 3-channel 7x7 stride-2 stem)", g->cin, 8 * kCbs);
+  ECO_REQUIRE((long)g->n * g->out[0] * g->out[1] * g->out[2] < 2147483647l, "convb: too many output positions");
+  return ECO_OK;
+}
+
+extern "C" int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t num_cu, eco_convb_plan* plan) {
+  clear_error();
+  if (int rc = validate_convb_geom(g, dt)) return rc;
+  ECO_REQUIRE(plan != nullptr && num_cu >= 0, "convb: bad argument");
+  if (num_cu == 0) num_cu = 256;
+  const int ns = ns_of(dt);
+  int bm;
+  if (g->cout <= 32) bm = 32;
+  else if (g->cout <= 64) bm = 64;
+  else if (g->cout <= 96) bm = 96;
+  else {
+    bm = 128;
+    long best = ceil_div(g->cout, 128) * 128;
+    const int cands[2] = {96, 64};
+    for (int c : cands) {
+      const long padded = ceil_div(g->cout, c) * c;
+      if (padded < best) { best = padded; bm = c; }
+    }
+  }
+  const long ntot = (long)g->n * g->out[0] * g->out[1] * g->out[2];
+  plan->bm = bm;
+  plan->bn = bm == 128 ? 128 : 256;
+  plan->dt = dt;
+  plan->stem = is_stem(g) ? 1 : 0;
+  plan->cblocks = plan->stem ? 4 : g->cin / 8;
+  const int taps = plan->stem ? 7 : g->kernel[0] * g->kernel[1] * g->kernel[2];
+  plan->nstages = (plan->cblocks / kCbs) * taps;
+  plan->mpad = (int)(ceil_div(g->cout, bm) * bm);
+  plan->wp_vecs = (int64_t)ns * plan->nstages * kCbs * plan->mpad;
+  // split-K: with fewer tiles than resident workgroup slots cut the reduction so that tiles * slices fills them
+  // (slices of >= 4 stages; partial sums cost one fp32 write + read of the outputs per slice)
+  plan->ksplit = 1;
+  plan->ws_bytes = 0;
+  const long tiles = ceil_div(g->cout, bm) * ceil_div(ntot, plan->bn);
+  const long slots = 2L * num_cu;
+  if (tiles < slots) {
+    long sp = slots / tiles;
+    if (sp > 8) sp = 8;
+    if (sp > plan->nstages / 4) sp = plan->nstages / 4;
+    if (sp >= 2) {
+      plan->ksplit = (int)sp;
+      plan->ws_bytes = (int64_t)sp * g->cout * ntot * 4;
+    }
+  }
+  return ECO_OK;
+}
+
+extern "C" int eco_convb_pack_weights(const eco_conv_geom* g, const eco_convb_plan* plan, const float* w, void* wp) {
+  clear_error();
+  ECO_REQUIRE(plan && w && wp, "convb pack: null argument");
+  if (int rc = validate_convb_geom(g, plan->dt)) return rc;
+  const int ns = ns_of(plan->dt);
+  uint16_t* out = (uint16_t*)wp;   // [ns][nstages][kCbs][mpad][8]
+  memset(out, 0, (size_t)plan->wp_vecs * 16);
+  const int taps_full = g->kernel[0] * g->kernel[1] * g->kernel[2];
+  const long K = (long)g->cin * taps_full;
+  auto put = [&](int stage, int row, int m, int e, float v) {
+    uint16_t t[3];
+    t[0] = host_bf16(v);
+    const float r1 = v - host_bf16_f32(t[0]);
+    t[1] = host_bf16(r1);
+    t[2] = host_bf16(r1 - host_bf16_f32(t[1]));
+    for (int p = 0; p < ns; ++p)
+      out[((((long)p * plan->nstages + stage) * kCbs + row) * plan->mpad + m) * 8 + e] = t[p];
+  };
+  if (plan->stem) {
+    // stage = kernel row ky; block j, element e <-> (kx, c) = (2*j + e/4, e%4); kx = 7 and c = 3 do not exist
+    for (int m = 0; m < g->cout; ++m)
+      for (int c = 0; c < 3; ++c)
+        for (int ky = 0; ky < 7; ++ky)
+          for (int kx = 0; kx < 7; ++kx)
+            put(ky, kx / 2, m, 4 * (kx % 2) + c, w[(long)m * K + ((long)c * 7 + ky) * 7 + kx]);
+    return ECO_OK;
+  }
+  // stage = cg*taps + tap; row r, element e <-> channel (cg*4 + r)*8 + e
+  for (int m = 0; m < g->cout; ++m)
+    for (int c = 0; c < g->cin; ++c) {
+      const int cb = c / 8, e = c % 8, cg = cb / kCbs, row = cb % kCbs;
+      for (int tap = 0; tap < taps_full; ++tap)
+        put(cg * taps_full + tap, row, m, e, w[(long)m * K + (long)c * taps_full + tap]);
+    }
+  return ECO_OK;
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_convb(const ConvBArgs& a, int ns, hipStream_t stream) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  const int grid = a.nblk_m * a.nblk_n * a.ksplit;
+  const size_t lds = (size_t)2 * ns * kCbs * (BM + BN) * 16;
+  if (ns == 1)
+    hipLaunchKernelGGL((convb_kernel<TM, TN, WM, WN, 1>), dim3(grid), dim3(256), lds, stream, a);
+  else
+    hipLaunchKernelGGL((convb_kernel<TM, TN, WM, WN, 3>), dim3(grid), dim3(256), lds, stream, a);
+  return check_launch("eco_convb_forward");
+}
+
+extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* plan, const void* x, const void* wp,
+                                 const eco_conv_epilogue* ep, void* workspace, void* stream) {
+  clear_error();
+  ECO_REQUIRE(plan && x && wp && ep, "convb: null argument");
+  if (int rc = validate_convb_geom(g, plan->dt)) return rc;
+  ECO_REQUIRE(ep->raw.ptr || ep->act.ptr, "convb: at least one of raw/act outputs is required");
+  ECO_REQUIRE(!ep->bn_scale == !ep->bn_shift, "convb: bn_scale and bn_shift must be given together");
+  const eco_view* views[3] = {&ep->residual, &ep->raw, &ep->act};
+  for (const eco_view* v : views)
+    ECO_REQUIRE(!v->ptr || (v->t >= 1 && v->stride_c >= 1), "convb: view needs t >= 1 and stride_c >= 1");
+  const int ns = ns_of(plan->dt);
+  ConvBArgs a;
+  a.x = x; a.wp = (const uint4*)wp;
+  a.bias = ep->bias; a.bn_scale = ep->bn_scale; a.bn_shift = ep->bn_shift;
+  a.residual = ep->residual; a.raw = ep->raw; a.act = ep->act; a.relu = ep->relu;
+  a.cout = g->cout; a.mpad = plan->mpad; a.nstages = plan->nstages; a.cblocks = plan->cblocks;
+  a.Do = g->out[0]; a.Ho = g->out[1]; a.Wo = g->out[2];
+  if (plan->stem) {
+    // the packed image of eco_stem_pack_forward: rows of (W+8)/2 blocks, H+6 rows; kernel rows are the taps
+    const int H = g->in[1], W = g->in[2];
+    ECO_REQUIRE(plan->cblocks == 4 && plan->nstages == 7, "convb: stem plan does not match geometry");
+    a.Di = 1; a.Hi = H + 6; a.Wi = (W + 8) / 2;
+    a.kd = 1; a.kh = 7; a.kw = 1; a.sd = 1; a.sh = 2; a.sw = 1; a.pd = 0; a.ph = 0; a.pw = 0;
+    a.taps = 7;
+    a.img_stride_in = (long)a.Hi * a.Wi;
+    a.cb_stride_in = 1;
+    ECO_REQUIRE(g->out[2] + 3 <= a.Wi && 2 * (g->out[1] - 1) + 7 <= a.Hi, "convb: stem geometry out of the packed image");
+  } else {
+    ECO_REQUIRE(plan->cblocks == g->cin / 8 && plan->nstages == (plan->cblocks / kCbs) * g->kernel[0] * g->kernel[1] * g->kernel[2],
+                "convb: plan does not match geometry");
+    a.Di = g->in[0]; a.Hi = g->in[1]; a.Wi = g->in[2];
+    a.kd = g->kernel[0]; a.kh = g->kernel[1]; a.kw = g->kernel[2];
+    a.sd = g->stride[0]; a.sh = g->stride[1]; a.sw = g->stride[2];
+    a.pd = g->pad[0]; a.ph = g->pad[1]; a.pw = g->pad[2];
+    a.taps = a.kd * a.kh * a.kw;
+    a.cb_stride_in = (long)a.Di * a.Hi * a.Wi;
+    a.img_stride_in = (long)plan->cblocks * a.cb_stride_in;
+  }
+  a.s_out = a.Do * a.Ho * a.Wo;
+  a.ntot = g->n * a.s_out;
+  a.nblk_m = (int)ceil_div(g->cout, plan->bm);
+  a.nblk_n = (int)ceil_div(a.ntot, plan->bn);
+  ECO_REQUIRE((long)a.nblk_m * plan->bm <= plan->mpad, "convb: plan mpad too small");
+  ECO_REQUIRE(plan->ksplit >= 1 && plan->ksplit <= plan->nstages, "convb: bad split-K factor %d", plan->ksplit);
+  ECO_REQUIRE(plan->ksplit == 1 || (workspace && (int64_t)plan->ksplit * g->cout * a.ntot * 4 <= plan->ws_bytes),
+              "convb: plan needs a %ld-byte workspace", (long)plan->ws_bytes);
+  a.ksplit = plan->ksplit;
+  a.ws = (float*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  switch (plan->bm) {
+    case 128:
+      ECO_REQUIRE(plan->bn == 128 || plan->bn == 256, "convb: bad plan");
+      rc = plan->bn == 128 ? launch_convb<2, 2, 2, 2>(a, ns, s) : launch_convb<2, 4, 2, 2>(a, ns, s);
+      break;
+    case 96: ECO_REQUIRE(plan->bn == 256, "convb: bad plan"); rc = launch_convb<3, 2, 1, 4>(a, ns, s); break;
+    case 64: ECO_REQUIRE(plan->bn == 256, "convb: bad plan"); rc = launch_convb<2, 2, 1, 4>(a, ns, s); break;
+    case 32: ECO_REQUIRE(plan->bn == 256, "convb: bad plan"); rc = launch_convb<1, 2, 1, 4>(a, ns, s); break;
+    default: return fail(ECO_ERR_INVALID, "convb: unsupported block tile bm=%d", plan->bm);
+  }
+  if (rc != ECO_OK || a.ksplit == 1) return rc;
+  const int rgrid = grid_for_b((long)(a.cout / 8) * a.ntot);
+  if (ns == 1) hipLaunchKernelGGL((convb_splitk_reduce_kernel<1>), dim3(rgrid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((convb_splitk_reduce_kernel<3>), dim3(rgrid), dim3(256), 0, s, a);
+  return check_launch("eco_convb_forward(split-K reduce)");
+}
+
+extern "C" int eco_stem_pack_forward(const float* x, void* y, int64_t frames, int32_t h, int32_t w, int32_t dt,
+                                     void* stream) {
+  clear_error();
+  ECO_REQUIRE(x && y && frames > 0 && h > 0 && w > 0 && w % 2 == 0, "stem pack: bad argument (W must be even)");
+  const int ns = ns_of(dt);
+  ECO_REQUIRE(ns != 0, "stem pack: storage type must be ECO_DT_BF16 or ECO_DT_F32X3");
+  const long total = (long)frames * (h + 6) * ((w + 8) / 2);
+  if (ns == 1) hipLaunchKernelGGL((stem_pack_kernel<1>), dim3(grid_for_b(total)), dim3(256), 0, (hipStream_t)stream, x, y, (long)frames, h, w);
+  else hipLaunchKernelGGL((stem_pack_kernel<3>), dim3(grid_for_b(total)), dim3(256), 0, (hipStream_t)stream, x, y, (long)frames, h, w);
+  return check_launch("eco_stem_pack_forward");
+}
+
+extern "C" int eco_poolb_forward(const eco_pool_geom* g, int32_t dt, const void* x, void* y, void* stream) {
+  clear_error();
+  ECO_REQUIRE(g && x && y, "poolb: null argument");
+  const int ns = ns_of(dt);
+  ECO_REQUIRE(ns != 0, "poolb: storage type must be ECO_DT_BF16 or ECO_DT_F32X3");
+  ECO_REQUIRE(g->n > 0 && g->c > 0 && g->c % 8 == 0, "poolb: channels (%d) must be a positive multiple of 8", g->c);
+  ECO_REQUIRE(g->method == ECO_POOL_MAX || g->method == ECO_POOL_AVE, "poolb: unknown pooling method %d", g->method);
+  for (int i = 0; i < 3; ++i) {
+    ECO_REQUIRE(g->in[i] > 0 && g->kernel[i] > 0 && g->stride[i] > 0 && g->pad[i] >= 0 && g->out[i] > 0,
+                "poolb: bad geometry (axis %d)", i);
+    ECO_REQUIRE(g->pad[i] < g->kernel[i], "poolb: pad must be smaller than kernel (axis %d)", i);
+    ECO_REQUIRE((g->out[i] - 1) * g->stride[i] < g->in[i] + g->pad[i], "poolb: last window starts outside the padded input");
+  }
+  PoolBArgs a;
+  a.x = x; a.y = y;
+  a.Di = g->in[0]; a.Hi = g->in[1]; a.Wi = g->in[2];
+  a.Do = g->out[0]; a.Ho = g->out[1]; a.Wo = g->out[2];
+  a.kd = g->kernel[0]; a.kh = g->kernel[1]; a.kw = g->kernel[2];
+  a.sd = g->stride[0]; a.sh = g->stride[1]; a.sw = g->stride[2];
+  a.pd = g->pad[0]; a.ph = g->pad[1]; a.pw = g->pad[2];
+  a.method = g->method;
+  a.total = (long)g->n * (g->c / 8) * a.Do * a.Ho * a.Wo;
+  if (ns == 1) hipLaunchKernelGGL((poolb_kernel<1>), dim3(grid_for_b(a.total)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((poolb_kernel<3>), dim3(grid_for_b(a.total)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("eco_poolb_forward");
+}
+
+extern "C" int eco_global_avgpool_fc_b_forward(const void* x, int32_t dt, const float* w, const float* bias, float* y,
+                                               int64_t b, int64_t c, int64_t s, int64_t n_out, int64_t wk, int64_t c0,
+                                               int accumulate, void* stream) {
+  clear_error();
+  ECO_REQUIRE(x && w && y && b > 0 && c > 0 && s > 0 && n_out > 0, "global_avgpool_fc_b: bad argument");
+  const int ns = ns_of(dt);
+  ECO_REQUIRE(ns != 0, "global_avgpool_fc_b: storage type must be ECO_DT_BF16 or ECO_DT_F32X3");
+  ECO_REQUIRE(c % 8 == 0 && c <= kTailBMaxC, "global_avgpool_fc_b: %ld channels (multiple of 8, at most %d)", (long)c, kTailBMaxC);
+  ECO_REQUIRE(c0 >= 0 && c0 + c <= wk, "global_avgpool_fc_b: weight columns [%ld,%ld) outside row length %ld", (long)c0,
+              (long)(c0 + c), (long)wk);
+  ECO_REQUIRE(b <= 65535 && s < 2147483647l, "global_avgpool_fc_b: batch too large for one launch");
+  dim3 grid((unsigned)ceil_div(n_out, kTailBOut), (unsigned)b);
+  if (ns == 1)
+    hipLaunchKernelGGL((global_avgpool_fc_b_kernel<1>), grid, dim3(kTailBThreads), 0, (hipStream_t)stream, x, w, bias, y,
+                       (int)c, (int)s, (int)n_out, (int)wk, (int)c0, accumulate);
+  else
+    hipLaunchKernelGGL((global_avgpool_fc_b_kernel<3>), grid, dim3(kTailBThreads), 0, (hipStream_t)stream, x, w, bias, y,
+                       (int)c, (int)s, (int)n_out, (int)wk, (int)c0, accumulate);
+  return check_launch("eco_global_avgpool_fc_b_forward");
+}

@@ -12,6 +12,7 @@
 #endif
 
 #include <stdint.h>
+#include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -29,6 +30,41 @@ __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 #endif
 }
+
+// D(32x32) += A(32x16) * B(16x32), bf16 in / fp32 accumulate (v_mfma_f32_32x32x16_bf16, 16x the fp32 rate).
+// Lane l supplies eight consecutive k of row / column l&31: A[l&31][8*(l>>5) + e], B[8*(l>>5) + e][l&31],
+// e = 0..7, packed two per dword (low half = even e) in a 16-byte vector; C/D as above.
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) {
+#ifdef ECO_EMU
+  return emu::mfma_f32_32x32x16_bf16(a, b, c);
+#else
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
+}
+
+// fp32 <-> bf16 (round to nearest even; the GPU form is v_cvt_pk_bf16_f32, the expression below gives the same
+// bits for every finite input and for infinities).
+__device__ __forceinline__ unsigned f32_to_bf16_bits(float f) {
+#ifdef ECO_EMU
+  unsigned u;
+  memcpy(&u, &f, 4);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+#else
+  return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f);
+#endif
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned h) {
+  const unsigned u = h << 16;
+#ifdef ECO_EMU
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+#else
+  return __builtin_bit_cast(float, u);
+#endif
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16); }
 
 // Make a wave-uniform value provably uniform (SGPR) for the compiler.
 __device__ __forceinline__ int uniform(int v) {

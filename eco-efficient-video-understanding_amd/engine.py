@@ -52,7 +52,9 @@ class TorchAllocator:
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
 
     def empty(self, nelems: int, dtype=np.float32):
-        tdt = {np.dtype(np.float32): self.torch.float32, np.dtype(np.int32): self.torch.int32}[np.dtype(dtype)]
+        # uint16 = raw bf16 bits (the blocked bf16 path); torch has no uint16 arithmetic, the buffer is int16
+        tdt = {np.dtype(np.float32): self.torch.float32, np.dtype(np.int32): self.torch.int32,
+               np.dtype(np.uint16): self.torch.int16}[np.dtype(dtype)]
         return self.torch.empty(max(int(nelems), 1), dtype=tdt, device=self.device)
 
     @staticmethod
@@ -61,10 +63,13 @@ class TorchAllocator:
 
     def upload(self, h, arr: np.ndarray) -> None:
         a = np.ascontiguousarray(arr).reshape(-1)
+        if a.dtype == np.uint16:
+            a = a.view(np.int16)
         h[: a.size].copy_(self.torch.from_numpy(a), non_blocking=False)
 
     def download(self, h, nelems: int) -> np.ndarray:
-        return h[:nelems].detach().cpu().numpy()
+        a = h[:nelems].detach().cpu().numpy()
+        return a.view(np.uint16) if a.dtype == np.int16 else a
 
     def stream(self) -> Optional[int]:
         return self.torch.cuda.current_stream(self.device).cuda_stream

@@ -21,7 +21,9 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 8
+ABI_VERSION = 9
+DT_BF16 = 1
+DT_F32X3 = 3
 
 _i32x3 = C.c_int32 * 3
 
@@ -46,6 +48,12 @@ class ConvPlan(C.Structure):
                 ("wp_elems", C.c_int64), ("ktab_elems", C.c_int64),
                 ("mode", C.c_int32), ("ksplit", C.c_int32), ("ws_bytes", C.c_int64),
                 ("split_tiles", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ConvBPlan(C.Structure):
+    _fields_ = [("bm", C.c_int32), ("bn", C.c_int32), ("dt", C.c_int32), ("stem", C.c_int32),
+                ("cblocks", C.c_int32), ("nstages", C.c_int32), ("mpad", C.c_int32), ("ksplit", C.c_int32),
+                ("wp_vecs", C.c_int64), ("ws_bytes", C.c_int64)]
 
 
 class View(C.Structure):
@@ -160,6 +168,15 @@ _SIGNATURES = {
                                        C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "eco_softmax_loss_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                            C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "eco_convb_plan_create": (C.c_int, [C.POINTER(ConvGeom), C.c_int32, C.c_int32, C.POINTER(ConvBPlan)]),
+    "eco_convb_pack_weights": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvBPlan), C.c_void_p, C.c_void_p]),
+    "eco_convb_forward": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvBPlan), C.c_void_p, C.c_void_p,
+                                    C.POINTER(ConvEpilogue), C.c_void_p, C.c_void_p]),
+    "eco_stem_pack_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "eco_poolb_forward": (C.c_int, [C.POINTER(PoolGeom), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eco_global_avgpool_fc_b_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                                  C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
+                                                  C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -244,6 +261,29 @@ class EcoLib:
     def wino_output_forward(self, m: int, n: int, cout: int, d: int, h: int, w: int, tile_m: int, ep: ConvEpilogue,
                             stream=None) -> None:
         self._check(self._dll.eco_wino_output_forward(m, n, cout, d, h, w, tile_m, C.byref(ep), stream))
+
+    # -- channel-blocked bf16-MFMA path (csrc/eco_blocked.hip) ------------------
+    def convb_plan(self, g: ConvGeom, dt: int, num_cu: Optional[int] = None) -> "ConvBPlan":
+        p = ConvBPlan()
+        self._check(self._dll.eco_convb_plan_create(C.byref(g), int(dt), 0 if num_cu is None else int(num_cu), C.byref(p)))
+        return p
+
+    def convb_pack_weights(self, g: ConvGeom, p: "ConvBPlan", w_ptr: int, wp_ptr: int) -> None:
+        self._check(self._dll.eco_convb_pack_weights(C.byref(g), C.byref(p), w_ptr, wp_ptr))
+
+    def convb_forward(self, g: ConvGeom, p: "ConvBPlan", x: int, wp: int, ep: ConvEpilogue,
+                      workspace: Optional[int] = None, stream: Optional[int] = None) -> None:
+        self._check(self._dll.eco_convb_forward(C.byref(g), C.byref(p), x, wp, C.byref(ep), workspace, stream))
+
+    def stem_pack_forward(self, x: int, y: int, frames: int, h: int, w: int, dt: int, stream=None) -> None:
+        self._check(self._dll.eco_stem_pack_forward(x, y, frames, h, w, int(dt), stream))
+
+    def poolb_forward(self, g: PoolGeom, dt: int, x: int, y: int, stream=None) -> None:
+        self._check(self._dll.eco_poolb_forward(C.byref(g), int(dt), x, y, stream))
+
+    def global_avgpool_fc_b_forward(self, x, dt, w, bias, y, b, c, s, n_out, wk, c0=0, accumulate=False, stream=None) -> None:
+        self._check(self._dll.eco_global_avgpool_fc_b_forward(x, int(dt), w, bias, y, b, c, s, n_out, wk, c0,
+                                                              int(accumulate), stream))
 
     # -- stand-alone operators -----------------------------------------------
     def pool_forward(self, g: PoolGeom, x: int, y: int, stream=None) -> None:

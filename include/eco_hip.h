@@ -12,7 +12,8 @@
  *     stream is passed as an opaque `void*` that must be a hipStream_t or NULL),
  *   - tensors are fp32, row-major N,C,[D,]H,W exactly like caffe `Blob`
  *     (include/caffe/blob.hpp:24-282); weights keep the reference layouts
- *     ([Cout,Cin,(kd,)kh,kw], BN 4 x [1,C], fc [out,in]),
+ *     ([Cout,Cin,(kd,)kh,kw], BN 4 x [1,C], fc [out,in]); the bf16 path at the end of this
+ *     header keeps its activations channel-blocked internally,
  *   - every function returns ECO_OK or a negative error code and never aborts,
  *     allocates, or synchronises: the caller owns memory and the stream
  *     (the reference LOG(FATAL)s instead; `eco_last_error()` carries the text a
@@ -34,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 8
+#define ECO_ABI_VERSION 9
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -247,6 +248,50 @@ int eco_accuracy_forward(const float* x, const float* label, float* out, int64_t
 int eco_softmax_loss_forward(const float* x, const float* label, float* out, int64_t outer, int64_t c,
                              int64_t inner, int32_t normalize, int32_t has_ignore_label,
                              int32_t ignore_label, void* stream);
+
+/* ---- channel-blocked ("NC8") path on the bf16 matrix cores (csrc/eco_blocked.hip) -------------------------
+ *
+ * BASELINE.json configs[4] (ECO-Lite, bf16).  Activations are kept as X[n][c/8][d][h][w][c%8] so that the eight
+ * reduction elements a lane feeds v_mfma_f32_32x32x16_bf16 are one 16-byte vector; the layout is internal to
+ * this path (the `data` input is the reference's fp32 N,3,H,W blob, the logits leave as fp32 [B, classes]).
+ * Same operators, epilogue algebra and error conventions as the fp32 entry points above; in every
+ * eco_view / eco_conv_epilogue handed to these functions `ptr` addresses elements of the storage type and the
+ * strides count 8-channel blocks:  block(img, c, sp) = (img / t)*stride_b + (img % t)*stride_t + (c/8)*stride_c + sp.
+ * bias / bn_scale / bn_shift / fc weights / logits are fp32 for both storage types. */
+#define ECO_DT_BF16 1  /* bf16 storage; products of bf16 operands accumulated in fp32                         */
+#define ECO_DT_F32X3 3 /* fp32 storage; each operand split exactly into 3 bf16 terms, the 6 products of order */
+                       /* <= 2 accumulated in fp32: fp32-class results on the bf16 matrix cores              */
+
+typedef struct eco_convb_plan {
+  int32_t bm, bn;    /* block tile: output channels x output positions                                  */
+  int32_t dt;        /* ECO_DT_*                                                                         */
+  int32_t stem;      /* 1: the 3-channel 7x7 stride-2 pad-3 stem; x is the image of eco_stem_pack_forward */
+  int32_t cblocks;   /* input channel blocks reduced over (cin/8; 4 for the stem)                        */
+  int32_t nstages;   /* reduction stages of 32 elements: (cblocks/4) * taps                              */
+  int32_t mpad;      /* cout rounded up to a multiple of bm                                              */
+  int32_t ksplit;    /* > 1: reduction cut into ksplit slices, summed by a second deterministic launch   */
+  int64_t wp_vecs;   /* 16-byte vectors in the packed weights: terms * nstages * 4 * mpad                */
+  int64_t ws_bytes;  /* device scratch eco_convb_forward needs (0 if ksplit == 1)                        */
+} eco_convb_plan;
+
+/* Requirements: cout % 8 == 0 and cin % 32 == 0, or the stem geometry (cin 3, 2-D 7x7, stride 2, pad 3, even W).
+ * num_cu = 0 sizes the plan for 256 compute units. */
+int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t num_cu, eco_convb_plan* plan);
+/* HOST function: caffe weights w[cout][cin][kd][kh][kw] (fp32) -> wp[term][stage][4][mpad][8] bf16
+ * (stage = channel-group*taps + tap; ECO_DT_F32X3 stores the three bf16 terms of every weight). */
+int eco_convb_pack_weights(const eco_conv_geom* g, const eco_convb_plan* plan, const float* w, void* wp);
+/* ConvolutionLayer::Forward_gpu (+ fused BN / ReLU / Eltwise / Concat / Reshape+Permute) on blocked tensors. */
+int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* plan, const void* x, const void* wp,
+                      const eco_conv_epilogue* ep, void* workspace, void* stream);
+/* fp32 N,3,H,W frames (the VideoData contract, video_data_layer.cpp:107-119) -> the zero-padded pixel-interleaved
+ * image the stem plan reads: y[f][h+3][w+3][4] in the storage type, (H+6) x (W+8) pixels per frame. */
+int eco_stem_pack_forward(const float* x, void* y, int64_t frames, int32_t h, int32_t w, int32_t dt, void* stream);
+/* PoolingLayer::Forward_gpu on a blocked tensor x[n][c/8][in...][8] -> y[n][c/8][out...][8] (rules of eco_pool_forward). */
+int eco_poolb_forward(const eco_pool_geom* g, int32_t dt, const void* x, void* y, void* stream);
+/* eco_global_avgpool_fc_forward on a blocked volume x[b][c/8][s][8]. */
+int eco_global_avgpool_fc_b_forward(const void* x, int32_t dt, const float* w, const float* bias, float* y,
+                                    int64_t b, int64_t c, int64_t s, int64_t n_out, int64_t wk, int64_t c0,
+                                    int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

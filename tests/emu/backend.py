@@ -40,7 +40,8 @@ class NumpyAllocator:
         dll.emu_set_strict(1)
 
     def empty(self, nelems: int, dtype=np.float32) -> np.ndarray:
-        a = np.full(max(int(nelems), 1), np.nan if np.dtype(dtype) == np.float32 else -1, dtype=dtype)
+        dt = np.dtype(dtype)   # poison: NaN (fp32 and, as 0xffff, bf16 bits) or -1
+        a = np.full(max(int(nelems), 1), np.nan if dt == np.float32 else (0xFFFF if dt == np.uint16 else -1), dtype=dt)
         self._dll.emu_register_buffer(a.ctypes.data, a.nbytes)
         return a
 

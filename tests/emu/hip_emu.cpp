@@ -24,6 +24,8 @@ struct WaveState {
   float xa[2][kWave];
   float xb[2][kWave];
   int xi[2][kWave];
+  uint4 qa[2][kWave];
+  uint4 qb[2][kWave];
 };
 
 struct Fiber {
@@ -239,6 +241,44 @@ emu_f32x16 mfma_f32_32x32x2f32(float a, float b, emu_f32x16 c) {
     float acc = d[r];
     acc = std::fmaf(w.xa[slot][i], w.xb[slot][j], acc);            // k = 0
     acc = std::fmaf(w.xa[slot][i + 32], w.xb[slot][j + 32], acc);  // k = 1
+    d[r] = acc;
+  }
+  return d;
+}
+
+static inline float bf16_bits_to_f32(unsigned h) {
+  unsigned u = h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
+emu_f32x16 mfma_f32_32x32x16_bf16(uint4 a, uint4 b, emu_f32x16 c) {
+  WaveState& w = my_wave();
+  if (w.nlanes != kWave) {
+    std::fprintf(stderr, "hip_emu: MFMA issued by a partial wave (%d lanes)\n", w.nlanes);
+    std::abort();
+  }
+  const int slot = wave_rendezvous_begin(w);
+  const int lane = tls_cur->lane;
+  w.qa[slot][lane] = a;
+  w.qb[slot][lane] = b;
+  wave_rendezvous_wait(w);
+  const int j = lane & 31;
+  const int hi = lane >> 5;
+  emu_f32x16 d = c;
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = d[r];
+    for (int g = 0; g < 2; ++g) {          // k = 8*g + e held by lanes i + 32*g (A) and j + 32*g (B)
+      const unsigned* pa = &w.qa[slot][i + 32 * g].x;
+      const unsigned* pb = &w.qb[slot][j + 32 * g].x;
+      for (int e = 0; e < 8; ++e) {
+        const unsigned ha = (pa[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+        const unsigned hb = (pb[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+        acc = std::fmaf(bf16_bits_to_f32(ha), bf16_bits_to_f32(hb), acc);
+      }
+    }
     d[r] = acc;
   }
   return d;

@@ -13,6 +13,7 @@
 //       A: lane l holds A[i = l&31][k = l>>5];  B: lane l holds B[k = l>>5][j = l&31];
 //       C/D: lane l, reg r holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31],
 //     accumulated as a k-ordered fmaf chain (bitwise what the hardware does).
+//   * MFMA 32x32x16 bf16 (the blocked bf16 path): same C/D map, eight consecutive k per lane (see below).
 //   * global loads/stores made through eco::ld / eco::st are bounds-checked against
 //     buffers registered with emu_register_buffer() -- an out-of-range access that
 //     would fault (or silently corrupt) on the GPU aborts the test with a message.
@@ -39,6 +40,14 @@ struct float2 {
   float x, y;
 };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+struct uint4 {
+  unsigned x, y, z, w;
+};
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+struct uint2 {
+  unsigned x, y;
+};
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
 typedef void* hipStream_t;
 typedef int hipError_t;
@@ -70,6 +79,11 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem_bytes, const std::function<vo
 void syncthreads();
 float wave_xchg_f32(float v, int src_lane);          // value of `v` held by src_lane
 emu_f32x16 mfma_f32_32x32x2f32(float a, float b, emu_f32x16 c);
+// v_mfma_f32_32x32x16_bf16: lane l holds A[i = l&31][k = 8*(l>>5) + e] and B[k = 8*(l>>5) + e][j = l&31] as eight
+// bf16 (e = 0..7, two per dword, low half first); C/D as for the f32 form.  Products are exact in fp32 and are
+// accumulated here in k order with one rounding each (the hardware's internal order is unspecified: compare
+// with a tolerance).
+emu_f32x16 mfma_f32_32x32x16_bf16(uint4 a, uint4 b, emu_f32x16 c);
 int readfirstlane(int v);
 void* dyn_smem();
 bool check_access(const void* p, size_t bytes, bool write);  // false = out of bounds (counted)

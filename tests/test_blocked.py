@@ -1,0 +1,211 @@
+"""The channel-blocked bf16-MFMA kernels (csrc/eco_blocked.hip) against the CPU oracle, through the C ABI, on the
+emulator (CPU suite) and on the GPU (-m gpu).
+
+Tolerances.  ECO_DT_BF16: operands are bf16 (the oracle is fed the same bf16-rounded inputs and weights, so the
+products agree exactly), accumulation is fp32, and each stored output is rounded once to bf16: |err| <=
+2^-8 |y| (half a bf16 ulp is 2^-9) + accumulation-order noise.  ECO_DT_F32X3: operands are split exactly into three
+bf16 terms and the six products of order <= 2 are kept: fp32-class, 2e-5 of the largest output as for the fp32
+kernels."""
+import numpy as np
+import pytest
+
+import eco_oracle as orc
+from eco_amd import blocked, hip
+
+BF16, F32X3 = hip.DT_BF16, hip.DT_F32X3
+DTS = [pytest.param(BF16, id="bf16"), pytest.param(F32X3, id="f32x3")]
+
+
+def dev_blocked(backend, x, dt):
+    raw = blocked.to_blocked(x, dt)
+    return backend.dev(raw)
+
+
+def host_blocked(backend, h, shape, dt):
+    n = int(np.prod(shape))
+    raw = np.asarray(backend.alloc.download(h, n))
+    return blocked.from_blocked(raw, shape, dt)
+
+
+def empty_blocked(backend, shape, dt):
+    return backend.empty(shape, blocked.STORAGE[dt])
+
+
+def bptr(backend, h, dt, offset_blocks=0):
+    return backend.alloc.ptr(h) + offset_blocks * 8 * (2 if dt == BF16 else 4)
+
+
+def check(got, ref, dt, what=""):
+    scale = np.abs(ref).max() + 1e-30
+    if dt == BF16:
+        err = np.abs(got - ref) - 2.0 ** -8 * np.abs(ref)
+        assert err.max() <= 2e-5 * scale, (what, float(err.max() / scale))
+    else:
+        assert np.abs(got - ref).max() <= 2e-5 * scale, (what, float(np.abs(got - ref).max() / scale))
+
+
+def quant(x, dt):
+    return blocked.bf16_round(x) if dt == BF16 else np.asarray(x, np.float32)
+
+
+CONVS = [  # n, cin, cout, in_sp, kernel, stride, pad
+    (2, 32, 64, (9, 9), (3, 3), (1, 1), (1, 1)),          # 2-D 3x3 same
+    (3, 64, 96, (7, 7), (1, 1), (1, 1), (0, 0)),          # 1x1, bm = 96
+    (2, 32, 32, (4, 6, 6), (3, 3, 3), (2, 2, 2), (1, 1, 1)),   # 3-D strided, bm = 32
+    (1, 64, 160, (3, 5, 5), (3, 3, 3), (1, 1, 1), (1, 1, 1)),  # 3-D same, cout 160 -> bm 96 (2 M-blocks)
+    (2, 96, 128, (6, 6), (3, 3), (2, 2), (1, 1)),         # bm = 128, three stages per tap group
+]
+
+
+def run_convb(backend, dt, n, cin, cout, in_sp, kernel, stride, pad, num_cu=None, seed=0, residual=False,
+              bn=True, raw=True):
+    rng = np.random.default_rng(seed)
+    out_sp = tuple((in_sp[i] + 2 * pad[i] - kernel[i]) // stride[i] + 1 for i in range(len(in_sp)))
+    x = quant(rng.normal(size=(n, cin) + in_sp).astype(np.float32), dt)
+    w = quant((rng.normal(size=(cout, cin) + kernel) / np.sqrt(cin * np.prod(kernel))).astype(np.float32), dt)
+    b = rng.normal(size=cout).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.normal(size=cout).astype(np.float32)
+    res = quant(rng.normal(size=(n, cout) + out_sp).astype(np.float32), dt) if residual else None
+    g = hip.conv_geom(n, cin, cout, in_sp, kernel, stride, pad, out_sp)
+    plan = backend.lib.convb_plan(g, dt, num_cu)
+    wp = np.zeros(plan.wp_vecs * 8, np.uint16)
+    backend.lib.convb_pack_weights(g, plan, w.ctypes.data, wp.ctypes.data)
+    S = int(np.prod(out_sp))
+    y_raw, y_act = empty_blocked(backend, (n, cout) + out_sp, dt), empty_blocked(backend, (n, cout) + out_sp, dt)
+    ep = hip.ConvEpilogue()
+    ep.bias = backend.ptr(backend.dev(b))
+    ep.residual = hip.View(bptr(backend, dev_blocked(backend, res, dt), dt), (cout // 8) * S, 0, S, 1) if residual else hip.null_view()
+    ep.raw = hip.View(bptr(backend, y_raw, dt), (cout // 8) * S, 0, S, 1) if raw else hip.null_view()
+    ep.bn_scale = backend.ptr(backend.dev(sc)) if bn else None
+    ep.bn_shift = backend.ptr(backend.dev(sh)) if bn else None
+    ep.relu = 1 if bn else 0
+    ep.act = hip.View(bptr(backend, y_act, dt), (cout // 8) * S, 0, S, 1)
+    ws = backend.empty((max(plan.ws_bytes, 4) // 4,)) if plan.ws_bytes else None
+    backend.lib.convb_forward(g, plan, bptr(backend, dev_blocked(backend, x, dt), dt), backend.ptr(backend.dev(wp)), ep,
+                              backend.ptr(ws) if ws is not None else None)
+    v = orc.convolution(x, w, b, kernel, stride, pad)
+    if residual:
+        v = v + res
+    a = v * sc.reshape((1, -1) + (1,) * len(out_sp)) + sh.reshape((1, -1) + (1,) * len(out_sp)) if bn else v
+    if bn:
+        a = np.maximum(a, 0)
+    if raw:
+        check(host_blocked(backend, y_raw, v.shape, dt), v, dt, "raw")
+    check(host_blocked(backend, y_act, a.shape, dt), a, dt, "act")
+    return plan
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", CONVS, ids=[f"c{i}" for i in range(len(CONVS))])
+def test_convb_matches_oracle(backend, dt, case):
+    run_convb(backend, dt, *case)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_convb_residual_and_split_k(backend, dt):
+    plan = run_convb(backend, dt, 1, 64, 64, (4, 5, 5), (3, 3, 3), (1, 1, 1), (1, 1, 1), num_cu=8, residual=True)
+    assert plan.ksplit > 1 and plan.ws_bytes > 0
+    run_convb(backend, dt, 2, 32, 64, (6, 6), (3, 3), (1, 1), (1, 1), residual=True, bn=False, raw=False)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_convb_stem_7x7(backend, dt):
+    """conv1_7x7_s2 form: fp32 N,3,H,W frames -> eco_stem_pack_forward -> the stem plan."""
+    rng = np.random.default_rng(5)
+    n, H, W, cout = 2, 20, 24, 32
+    x = rng.uniform(-120, 130, size=(n, 3, H, W)).astype(np.float32)
+    w = (rng.normal(size=(cout, 3, 7, 7)) / 12).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    out_sp = ((H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1)
+    g = hip.conv_geom(n, 3, cout, (H, W), (7, 7), (2, 2), (3, 3), out_sp)
+    plan = backend.lib.convb_plan(g, dt)
+    assert plan.stem == 1 and plan.nstages == 7 and plan.cblocks == 4
+    wp = np.zeros(plan.wp_vecs * 8, np.uint16)
+    backend.lib.convb_pack_weights(g, plan, w.ctypes.data, wp.ctypes.data)
+    packed = backend.empty((n * (H + 6) * (W + 8) * 4,), blocked.STORAGE[dt])
+    backend.lib.stem_pack_forward(backend.ptr(backend.dev(x)), backend.alloc.ptr(packed), n, H, W, dt)
+    S = out_sp[0] * out_sp[1]
+    y = empty_blocked(backend, (n, cout) + out_sp, dt)
+    ep = hip.ConvEpilogue()
+    ep.bias = backend.ptr(backend.dev(b))
+    ep.residual, ep.act = hip.null_view(), hip.null_view()
+    ep.bn_scale = ep.bn_shift = None
+    ep.relu = 0
+    ep.raw = hip.View(bptr(backend, y, dt), (cout // 8) * S, 0, S, 1)
+    backend.lib.convb_forward(g, plan, backend.alloc.ptr(packed), backend.ptr(backend.dev(wp)), ep, None)
+    ref = orc.convolution(quant(x, dt), quant(w, dt), b, (7, 7), (2, 2), (3, 3))
+    check(host_blocked(backend, y, ref.shape, dt), ref, dt)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_convb_concat_slice_and_permuted_store(backend, dt):
+    """Blocked views: a channel slice of a Concat top, and r2Dto3D + Permute [B*T,C,H,W] -> [B,C,T,H,W]."""
+    rng = np.random.default_rng(9)
+    B, T, cin, cout, H = 2, 3, 32, 32, 5
+    n, S = B * T, H * H
+    x = quant(rng.normal(size=(n, cin, H, H)).astype(np.float32), dt)
+    w = quant((rng.normal(size=(cout, cin, 1, 1)) / 6).astype(np.float32), dt)
+    g = hip.conv_geom(n, cin, cout, (H, H), (1, 1), (1, 1), (0, 0), (H, H))
+    plan = backend.lib.convb_plan(g, dt)
+    wp = np.zeros(plan.wp_vecs * 8, np.uint16)
+    backend.lib.convb_pack_weights(g, plan, w.ctypes.data, wp.ctypes.data)
+    ctot, c0 = 96, 40
+    cat = empty_blocked(backend, (n, ctot, H, H), dt)
+    vol = empty_blocked(backend, (B, cout, T, H, H), dt)
+    ep = hip.ConvEpilogue()
+    ep.bias = None
+    ep.residual = hip.null_view()
+    ep.bn_scale = ep.bn_shift = None
+    ep.relu = 0
+    ep.raw = hip.View(bptr(backend, cat, dt, (c0 // 8) * S), (ctot // 8) * S, 0, S, 1)
+    ep.act = hip.View(bptr(backend, vol, dt), (cout // 8) * T * S, S, T * S, T)
+    backend.lib.convb_forward(g, plan, bptr(backend, dev_blocked(backend, x, dt), dt), backend.ptr(backend.dev(wp)), ep, None)
+    ref = orc.convolution(x, w, None, (1, 1), (1, 1), (0, 0))
+    got_cat = host_blocked(backend, cat, (n, ctot, H, H), dt)
+    check(got_cat[:, c0:c0 + cout], ref, dt, "concat slice")
+    got_vol = host_blocked(backend, vol, (B, cout, T, H, H), dt)
+    check(got_vol, ref.reshape(B, T, cout, H, H).transpose(0, 2, 1, 3, 4), dt, "permuted volume")
+
+
+POOLS = [((2, 16, 9, 9), "MAX", (3, 3), (2, 2), (0, 0)), ((1, 8, 7, 7), "AVE", (3, 3), (1, 1), (1, 1)),
+         ((2, 8, 4, 5, 5), "AVE", (4, 5, 5), (1, 1, 1), (0, 0, 0)), ((1, 16, 3, 6, 6), "MAX", (2, 3, 3), (1, 2, 2), (0, 1, 1))]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape,method,k,s,p", POOLS)
+def test_poolb_matches_oracle(backend, dt, shape, method, k, s, p):
+    from eco_amd.netspec import pooled_dim
+    x = quant(np.random.default_rng(2).normal(size=shape).astype(np.float32), dt)
+    out_sp = tuple(pooled_dim(shape[2 + i], k[i], s[i], p[i]) for i in range(len(k)))
+    g = hip.pool_geom(shape[0], shape[1], shape[2:], k, s, p, out_sp, method)
+    y = empty_blocked(backend, shape[:2] + out_sp, dt)
+    backend.lib.poolb_forward(g, dt, bptr(backend, dev_blocked(backend, x, dt), dt), bptr(backend, y, dt))
+    ref = orc.pooling(x, method, k, s, p)
+    check(host_blocked(backend, y, ref.shape, dt), ref, dt)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_global_avgpool_fc_b(backend, dt):
+    rng = np.random.default_rng(4)
+    B, Cc, S, n_out = 3, 64, 2 * 3 * 3, 10
+    x = quant(rng.normal(size=(B, Cc, 2, 3, 3)).astype(np.float32), dt)
+    w = rng.normal(size=(n_out, Cc)).astype(np.float32)
+    b = rng.normal(size=n_out).astype(np.float32)
+    y = backend.empty((B, n_out))
+    backend.lib.global_avgpool_fc_b_forward(bptr(backend, dev_blocked(backend, x, dt), dt), dt, backend.ptr(backend.dev(w)),
+                                            backend.ptr(backend.dev(b)), backend.ptr(y), B, Cc, S, n_out, Cc)
+    ref = x.reshape(B, Cc, S).mean(2) @ w.T + b
+    assert np.abs(backend.host(y, ref.shape) - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_convb_rejects_unblocked_geometries(backend):
+    g = hip.conv_geom(1, 24, 32, (4, 4), (1, 1), (1, 1), (0, 0), (4, 4))
+    with pytest.raises(hip.EcoError, match="multiple of 32"):
+        backend.lib.convb_plan(g, BF16)
+    g = hip.conv_geom(1, 32, 12, (4, 4), (1, 1), (1, 1), (0, 0), (4, 4))
+    with pytest.raises(hip.EcoError, match="multiple of the 8-channel block"):
+        backend.lib.convb_plan(g, BF16)
+    g = hip.conv_geom(1, 32, 32, (4, 4), (1, 1), (1, 1), (0, 0), (4, 4))
+    with pytest.raises(hip.EcoError, match="storage type"):
+        backend.lib.convb_plan(g, 2)
