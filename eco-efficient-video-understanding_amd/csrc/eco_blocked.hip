@@ -330,8 +330,10 @@ __global__ __launch_bounds__(256, 2) void convb_kernel(const ConvBArgs a) {
     const long base = b_ok ? in_base + toff : 0;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-      const int c = kg + j * KG;
-      breg[j] = load_block<NS>(a.x, base + (long)(l_cg * kCbs + c) * a.cb_stride_in);
+      // the last channel group of a cin that is not a multiple of 32 is padded with zero WEIGHTS; its loads are
+      // clamped to the last real block (finite data times zero)
+      const int cb = min(l_cg * kCbs + kg + j * KG, a.cblocks - 1);
+      breg[j] = load_block<NS>(a.x, base + (long)cb * a.cb_stride_in);
     }
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -630,9 +632,9 @@ static int validate_convb_geom(const eco_conv_geom* g, int dt) {
   }
   ECO_REQUIRE(taps < 63, "convb: %ld kernel taps exceed the 63-tap validity mask", taps);
   ECO_REQUIRE(g->cout % 8 == 0, "convb: cout = %d is not a multiple of the 8-channel block", g->cout);
-  ECO_REQUIRE(is_stem(g) || g->cin % (8 * kCbs) == 0,
-              "convb: cin = %d is not a multiple of %d (the blocked kernels reduce 32 channels per stage; the only "
-              "other form is the 3-channel 7x7 stride-2 stem)", g->cin, 8 * kCbs);
+  ECO_REQUIRE(is_stem(g) || g->cin % 8 == 0,
+              "convb: cin = %d is not a multiple of the 8-channel block (the only other form is the 3-channel 7x7 "
+              "stride-2 stem)", g->cin);
   ECO_REQUIRE((long)g->n * g->out[0] * g->out[1] * g->out[2] < 2147483647l, "convb: too many output positions");
   return ECO_OK;
 }
@@ -663,7 +665,7 @@ extern "C" int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t
   plan->stem = is_stem(g) ? 1 : 0;
   plan->cblocks = plan->stem ? 4 : g->cin / 8;
   const int taps = plan->stem ? 7 : g->kernel[0] * g->kernel[1] * g->kernel[2];
-  plan->nstages = (plan->cblocks / kCbs) * taps;
+  plan->nstages = (int)ceil_div(plan->cblocks, kCbs) * taps;   // a partial last channel group is zero-padded
   plan->mpad = (int)(ceil_div(g->cout, bm) * bm);
   plan->wp_vecs = (int64_t)ns * plan->nstages * kCbs * plan->mpad;
   // split-K: with fewer tiles than resident workgroup slots cut the reduction so that tiles * slices fills them
@@ -726,10 +728,21 @@ static int launch_convb(const ConvBArgs& a, int ns, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   const int grid = a.nblk_m * a.nblk_n * a.ksplit;
   const size_t lds = (size_t)2 * ns * kCbs * (BM + BN) * 16;
-  if (ns == 1)
+  if (ns == 1) {
     hipLaunchKernelGGL((convb_kernel<TM, TN, WM, WN, 1>), dim3(grid), dim3(256), lds, stream, a);
-  else
+  } else {
+#ifndef ECO_EMU
+    // the split form stages three operand planes: 96-135 KB of the CU's 160 KB, above the default dynamic-LDS cap
+    static thread_local bool raised = false;
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute((const void*)convb_kernel<TM, TN, WM, WN, 3>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return fail(ECO_ERR_RUNTIME, "convb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+      raised = true;
+    }
+#endif
     hipLaunchKernelGGL((convb_kernel<TM, TN, WM, WN, 3>), dim3(grid), dim3(256), lds, stream, a);
+  }
   return check_launch("eco_convb_forward");
 }
 
@@ -761,7 +774,8 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
     a.cb_stride_in = 1;
     ECO_REQUIRE(g->out[2] + 3 <= a.Wi && 2 * (g->out[1] - 1) + 7 <= a.Hi, "convb: stem geometry out of the packed image");
   } else {
-    ECO_REQUIRE(plan->cblocks == g->cin / 8 && plan->nstages == (plan->cblocks / kCbs) * g->kernel[0] * g->kernel[1] * g->kernel[2],
+    ECO_REQUIRE(plan->cblocks == g->cin / 8 &&
+                    plan->nstages == (int)ceil_div(plan->cblocks, kCbs) * g->kernel[0] * g->kernel[1] * g->kernel[2],
                 "convb: plan does not match geometry");
     a.Di = g->in[0]; a.Hi = g->in[1]; a.Wi = g->in[2];
     a.kd = g->kernel[0]; a.kh = g->kernel[1]; a.kw = g->kernel[2];

@@ -81,12 +81,13 @@ class TorchAllocator:
 class _Tensor:
     """A materialised blob: storage handle + logical shape (aliases share a handle)."""
 
-    __slots__ = ("handle", "shape", "owner")
+    __slots__ = ("handle", "shape", "owner", "dt")
 
-    def __init__(self, handle, shape, owner: str) -> None:
+    def __init__(self, handle, shape, owner: str, dt: int = 0) -> None:
         self.handle = handle
         self.shape = tuple(int(s) for s in shape)
         self.owner = owner  # blob name that owns the storage
+        self.dt = dt        # 0: fp32 in the reference's N,C,... layout; hip.DT_*: channel-blocked storage (blocked.py)
 
     @property
     def count(self) -> int:
@@ -112,11 +113,23 @@ def bn_eps(L: LayerSpec) -> float:
 
 class Engine:
     def __init__(self, spec: NetSpec, lib: hip.EcoLib, alloc, fuse: bool = True, winograd=True,
-                 num_cu: Optional[int] = None) -> None:
+                 num_cu: Optional[int] = None, dtype: str = "f32") -> None:
         self.spec = spec
         self.lib = lib
         self.alloc = alloc
         self.fuse = fuse
+        # "f32": fp32 N,C,[D,]H,W blobs, fp32 MFMA kernels (eco_conv.hip).  "bf16" / "f32x3": the channel-blocked
+        # path on the bf16 matrix cores (eco_blocked.hip) with bf16 storage / fp32 storage and exactly split
+        # operands; fused plan only, every convolution evaluated directly.
+        if dtype not in ("f32", "bf16", "f32x3"):
+            raise ValueError("dtype must be 'f32', 'bf16' or 'f32x3'")
+        self.dtype = dtype
+        self.dt = {"f32": 0, "bf16": hip.DT_BF16, "f32x3": hip.DT_F32X3}[dtype]
+        if self.dt and not fuse:
+            raise NetSpecError("the blocked bf16-MFMA path runs the fused plan only (fuse=True)")
+        self.esize = 2 if self.dt == hip.DT_BF16 else 4        # bytes per stored activation element
+        self.cblk = 8 if self.dt else 1                        # channels per view stride unit
+        self.store_np = np.uint16 if self.dt == hip.DT_BF16 else np.float32
         # Winograd F(MxM,3x3) for the stride-1 3x3x3 convs of the 3-D trunk: False = direct evaluation, 2 / 4 =
         # output tile M, True = pick M per layer (4 where the planes are large enough to tile by 4)
         if winograd not in (False, True, 2, 4):
@@ -171,7 +184,15 @@ class Engine:
             L = self.spec.layer(name)
             st = self._param_dev.setdefault(name, {})
             blobs = self.params[name]
-            if L.type == "Convolution":
+            if L.type == "Convolution" and self.dt:
+                bp = st["bplan"]
+                wpb = np.empty(bp.wp_vecs * 8, np.uint16)
+                w = np.ascontiguousarray(blobs[0], np.float32)
+                self.lib.convb_pack_weights(st["geom"], bp, w.ctypes.data, wpb.ctypes.data)
+                self.alloc.upload(st["wp"], wpb)
+                if L.geom["bias_term"]:
+                    self.alloc.upload(st["bias"], blobs[1])
+            elif L.type == "Convolution":
                 g: hip.ConvGeom = st["geom"]
                 plan: hip.ConvPlan = st["plan"]
                 wp = np.empty(plan.wp_elems, np.float32)
@@ -234,6 +255,9 @@ class Engine:
                 g = L.geom
                 geom = hip.conv_geom(L.bottom_shapes[0][0], g["cin"], g["cout"], L.bottom_shapes[0][2:], g["kernel"],
                                      g["stride"], g["pad"], L.top_shapes[0][2:])
+                if self.dt:
+                    self._plan_blocked_conv(L, st, geom)
+                    continue
                 plan = self.lib.conv_plan(geom, self.num_cu)
                 old = st.get("plan")
                 if old is None or (old.wp_elems, old.ktab_elems) != (plan.wp_elems, plan.ktab_elems):
@@ -258,6 +282,7 @@ class Engine:
         # one scratch buffer serves every split-K convolution (launches are serial on one stream); the same
         # goes for the Winograd path's transformed input / output volumes
         ws_bytes = max([st["plan"].ws_bytes for st in self._param_dev.values() if "plan" in st] +
+                       [st["bplan"].ws_bytes for st in self._param_dev.values() if "bplan" in st] +
                        [st["wino"]["points"] * st["wino"]["plan"].ws_bytes for st in self._param_dev.values()
                         if "wino" in st] + [0])
         for key in ("v_elems", "m_elems"):
@@ -269,7 +294,7 @@ class Engine:
             self._ws = self.alloc.empty((ws_bytes + 3) // 4, np.float32)
             self._ws_bytes = ws_bytes
         for n in spec.inputs:
-            self._materialize(n, spec.blob_shapes[n])
+            self._materialize(n, spec.blob_shapes[n], plain=True)
         if self.fuse:
             self._build_fused()
         else:
@@ -279,29 +304,51 @@ class Engine:
         self._built = True
 
     # -- storage helpers -------------------------------------------------------
-    def _materialize(self, name: str, shape) -> _Tensor:
+    def _materialize(self, name: str, shape, plain: bool = False) -> _Tensor:
+        """Storage for blob `name`.  In the blocked modes every activation with a channel axis is channel-blocked
+        in the path's storage type; `plain` keeps the reference's fp32 layout (net inputs, the logits)."""
         if name in self.tensors:
             t = self.tensors[name]
             if _prod(t.shape) != _prod(shape):
                 raise NetSpecError(f"blob {name}: storage of {t.shape} reused for {shape}")
             return t
+        dt = 0 if (plain or not self.dt) else self.dt
+        if dt and (len(shape) < 2 or shape[1] % 8):
+            raise NetSpecError(f"blob {name} {tuple(shape)}: the blocked path needs a channel count that is a multiple of 8")
         old = getattr(self, "_old_tensors", {}).get(name)
-        if old is not None and old.owner == name and old.count == _prod(shape):
-            t = _Tensor(old.handle, shape, name)   # same element count: contents survive the rebuild
+        if old is not None and old.owner == name and old.count == _prod(shape) and old.dt == dt:
+            t = _Tensor(old.handle, shape, name, dt)   # same element count: contents survive the rebuild
         else:
-            t = _Tensor(self.alloc.empty(_prod(shape), np.float32), shape, name)
+            t = _Tensor(self.alloc.empty(_prod(shape), self.store_np if dt else np.float32), shape, name, dt)
         self.tensors[name] = t
         return t
 
     def _alias(self, name: str, src: str, shape) -> None:
         s = self.tensors[src]
-        self.tensors[name] = _Tensor(s.handle, shape, s.owner)
+        if s.dt and tuple(shape[:2]) != tuple(s.shape[:2]):
+            raise NetSpecError(f"blob {name}: a Reshape that moves the channel axis of the channel-blocked blob {src} "
+                               "is not available on the blocked path")
+        self.tensors[name] = _Tensor(s.handle, shape, s.owner, s.dt)
 
     def _ptr(self, name: str, offset_elems: int = 0) -> int:
         if name not in self.tensors:
             why = self.fused_away.get(name, "not produced")
             raise KeyError(f"blob {name!r} is not materialised ({why}); build the net with fuse=False to observe it")
-        return self.alloc.ptr(self.tensors[name].handle) + 4 * int(offset_elems)
+        t = self.tensors[name]
+        return self.alloc.ptr(t.handle) + (self.esize if t.dt else 4) * int(offset_elems)
+
+    def _view(self, name: str, channels: int, spatial: int, c0: int = 0, ctot: Optional[int] = None) -> "hip.View":
+        """Dense [N, C, S] view of blob `name` (or of channels [c0, c0+channels) of its ctot channels) in the
+        stride units of the active path: elements (fp32 path) or 8-channel blocks (blocked paths)."""
+        ctot = channels if ctot is None else ctot
+        if self.cblk > 1 and (c0 % self.cblk or ctot % self.cblk):
+            raise NetSpecError(f"blob {name}: channel offset {c0} / count {ctot} is not a multiple of {self.cblk}")
+        return hip.View(self._ptr(name, c0 * spatial), (ctot // self.cblk) * spatial, 0, spatial, 1)
+
+    def _no_blocked(self, L: LayerSpec) -> None:
+        raise NetSpecError(f"layer {L.name} ({L.type}) has no stand-alone kernel on the blocked {self.dtype} path: that "
+                           "path runs fused ECO graphs (conv+BN+ReLU+Eltwise epilogues, Concat / Permute as views, "
+                           "Pooling, the pool+fc tail); use dtype='f32' for this net")
 
     def _pdev(self, layer: str, key: str) -> int:
         return self.alloc.ptr(self._param_dev[layer][key])
@@ -327,6 +374,8 @@ class Engine:
             return
         top = L.tops[0]
         inplace = top in L.bottoms
+        if self.dt and t not in ("Convolution", "Pooling"):
+            self._no_blocked(L)
         if not inplace:
             self._materialize(top, L.top_shapes[0])
         if t == "Convolution":
@@ -334,7 +383,7 @@ class Engine:
             ep = hip.ConvEpilogue()
             ep.bias = self._pdev(L.name, "bias") if L.geom["bias_term"] else None
             ep.residual = hip.null_view()
-            ep.raw = hip.plain_view(self._ptr(top), L.geom["cout"], _prod(L.top_shapes[0][2:]))
+            ep.raw = self._view(top, L.geom["cout"], _prod(L.top_shapes[0][2:]))
             ep.bn_scale = None
             ep.bn_shift = None
             ep.relu = 0
@@ -412,6 +461,8 @@ class Engine:
         (64->192, 56x56) 3.24 -> 2.33 ms -- even there, where the transformed output volume is 2.8 GB."""
         g = L.geom
         nd = len(L.bottom_shapes[0]) - 2
+        if self.dt:
+            return False
         if not (self.winograd and nd in (2, 3) and tuple(g["kernel"]) == (3,) * nd and
                 tuple(g["stride"]) == (1,) * nd and tuple(g["pad"]) == (1,) * nd and g["cin"] % 16 == 0 and
                 tuple(L.top_shapes[0][2:]) == tuple(L.bottom_shapes[0][2:])):
@@ -480,7 +531,60 @@ class Engine:
                   {"kernel": f"eco::wino_output_kernel<{M}>", "flops": 0,
                    "bytes": 4 * P * tout + nbytes - 4 * (n * cin * D * H * W + 9 * kd * cin * cout)})
 
+    # -- blocked bf16-MFMA path (csrc/eco_blocked.hip) --------------------------------
+    def _plan_blocked_conv(self, L: LayerSpec, st: dict, geom) -> None:
+        g = L.geom
+        bp = self.lib.convb_plan(geom, self.dt, self.num_cu)
+        old = st.get("bplan")
+        if old is None or old.wp_vecs != bp.wp_vecs:
+            st["wp"] = self.alloc.empty(bp.wp_vecs * 8, np.uint16)
+            if g["bias_term"]:
+                st["bias"] = self.alloc.empty(g["cout"], np.float32)
+        if bp.stem:   # zero-padded pixel-interleaved copy of the fp32 frames (eco_stem_pack_forward)
+            n, _, H, W = L.bottom_shapes[0]
+            need = n * (H + 6) * (W + 8) * 4
+            if st.get("stem_elems") != need:
+                st["stem_buf"] = self.alloc.empty(need, self.store_np)
+                st["stem_elems"] = need
+        st["geom"], st["bplan"] = geom, bp
+        st.pop("plan", None)
+        st.pop("wino", None)
+        self._dirty_params.add(L.name)
+
+    def _emit_blocked_conv(self, i: int, L: LayerSpec, ep: "hip.ConvEpilogue", label: str) -> None:
+        st = self._param_dev[L.name]
+        g, bp = st["geom"], st["bplan"]
+        lib, dt = self.lib, self.dt
+        src = self.tensors[L.bottoms[0]]
+        wp = self.alloc.ptr(st["wp"])
+        ws = self.alloc.ptr(self._ws) if bp.ws_bytes else None
+        self._keep.append((g, bp, ep))
+        n_out = _prod(L.top_shapes[0])
+        k = L.geom["cin"] * _prod(L.geom["kernel"])
+        es = self.esize
+        outs = bool(ep.raw.ptr) + bool(ep.act.ptr) + bool(ep.residual.ptr)
+        if bp.stem:
+            if src.dt:
+                raise NetSpecError(f"{L.name}: the 3-channel stem reads the fp32 frames, got a blocked blob")
+            n, _, H, W = L.bottom_shapes[0]
+            x, buf = self._ptr(L.bottoms[0]), self.alloc.ptr(st["stem_buf"])
+            self._add(i, f"{label} [stem pack]", lambda s, x=x, buf=buf, n=n, H=H, W=W: lib.stem_pack_forward(x, buf, n, H, W, dt, s),
+                      {"kernel": "eco::stem_pack_kernel", "flops": 0, "bytes": 4 * n * 3 * H * W + es * st["stem_elems"]})
+            self._add(i, label, lambda s, g=g, bp=bp, buf=buf, wp=wp, ep=ep, ws=ws: lib.convb_forward(g, bp, buf, wp, ep, ws, s),
+                      {"kernel": hip.convb_kernel_name(bp), "flops": 2 * n_out * k,
+                       "bytes": es * st["stem_elems"] + 2 * k * L.geom["cout"] + es * n_out * outs})
+            return
+        if not src.dt:
+            raise NetSpecError(f"{L.name}: input blob {L.bottoms[0]} is not channel-blocked")
+        x = self._ptr(L.bottoms[0])
+        self._add(i, label, lambda s, g=g, bp=bp, x=x, wp=wp, ep=ep, ws=ws: lib.convb_forward(g, bp, x, wp, ep, ws, s),
+                  {"kernel": hip.convb_kernel_name(bp), "flops": 2 * n_out * k,
+                   "bytes": es * _prod(L.bottom_shapes[0]) + 2 * k * L.geom["cout"] + es * n_out * outs})
+
     def _emit_conv(self, i: int, L: LayerSpec, ep: "hip.ConvEpilogue", label: str) -> None:
+        if self.dt:
+            self._emit_blocked_conv(i, L, ep, label)
+            return
         st = self._param_dev[L.name]
         g, plan = st["geom"], st["plan"]
         x = self._ptr(L.bottoms[0])
@@ -506,6 +610,13 @@ class Engine:
         pg = hip.pool_geom(b[0], b[1], b[2:], g["kernel"], g["stride"], g["pad"], L.top_shapes[0][2:], g["method"])
         self._keep.append(pg)
         lib = self.lib
+        if self.dt:
+            dt = self.dt
+            if not self.tensors[L.bottoms[0]].dt:
+                raise NetSpecError(f"{L.name}: input blob {L.bottoms[0]} is not channel-blocked")
+            self._add(i, L.name, lambda s, pg=pg, x=x, y=y: lib.poolb_forward(pg, dt, x, y, s),
+                      {"kernel": "eco::poolb_kernel", "flops": 0, "bytes": self.esize * (_prod(b) + _prod(L.top_shapes[0]))})
+            return
         self._add(i, L.name, lambda s, pg=pg, x=x, y=y: lib.pool_forward(pg, x, y, s),
                   {"kernel": hip.pool_kernel_name(pg), "flops": 0,
                    "bytes": 4 * (_prod(b) + _prod(L.top_shapes[0]))})
@@ -520,6 +631,8 @@ class Engine:
         for k, (b, bs) in enumerate(zip(L.bottoms, L.bottom_shapes)):
             cx = bs[ax]
             if k not in skip:
+                if self.dt:
+                    self._no_blocked(L)
                 x = self._ptr(b)
                 self._add(i, f"{L.name}[{k}]", lambda s, x=x, y=y, outer=outer, cx=cx, cy=cy, c0=c0, inner=inner:
                           lib.concat_copy(x, y, outer, cx, cy, c0, inner, s))
@@ -608,7 +721,7 @@ class Engine:
             if len(E.bottoms) == 2 and len(others) == 1 and all(c == 1.0 for c in E.geom["coeff"]) \
                     and self._resolve(others[0]) in self.tensors:
                 r = self._resolve(others[0])
-                ep.residual = hip.plain_view(self._ptr(r), cout, S)
+                ep.residual = self._view(r, cout, S)
                 self.fused_away[value] = f"summed into {E.tops[0]} inside the epilogue of {L.name}"
                 absorbed[ei] = L.name
                 value = E.tops[0]
@@ -630,7 +743,7 @@ class Engine:
         rest = [c for c in consumers.get(value, []) if absorbed.get(c) != L.name]
         if act_blob is None or rest or value in outputs:
             self._materialize(value, L.top_shapes[0])
-            ep.raw = hip.plain_view(self._ptr(value), cout, S)
+            ep.raw = self._view(value, cout, S)
         else:
             self.fused_away[value] = f"only exists inside the fused epilogue of {L.name}"
         # 4. activated output and its destination
@@ -638,7 +751,7 @@ class Engine:
             dest = self._act_destination(act_blob, L, layers, consumers, outputs, absorbed, concat_skip)
             if dest is None:
                 self._materialize(act_blob, L.top_shapes[0])
-                ep.act = hip.plain_view(self._ptr(act_blob), cout, S)
+                ep.act = self._view(act_blob, cout, S)
             else:
                 ep.act = dest
         self._emit_conv(i, L, ep, label)
@@ -665,7 +778,7 @@ class Engine:
                 self._materialize(Lc.tops[0], Lc.top_shapes[0])
             concat_skip.setdefault(cs[0], []).append(k)
             self.fused_away[act_blob] = f"written directly into channels [{c0},{c0 + cout}) of {Lc.tops[0]}"
-            return hip.View(self._ptr(Lc.tops[0], c0 * S), ctot * S, 0, S, 1)
+            return self._view(Lc.tops[0], cout, S, c0, ctot)
         # (b) r2Dto3D Reshape [-1,T,C,H,W] followed by Permute [0,2,1,3,4]
         if Lc.type == "Reshape" and len(tshape) == 4 and len(Lc.top_shapes[0]) == 5:
             rs = Lc.top_shapes[0]
@@ -683,7 +796,7 @@ class Engine:
             absorbed[pcs[0]] = L.name
             self.fused_away[act_blob] = f"written through {Lc.name}+{Lp.name} directly into {Lp.tops[0]}"
             self.fused_away[Lc.tops[0]] = self.fused_away[act_blob]
-            return hip.View(self._ptr(Lp.tops[0]), Cc * T * S, S, T * S, T)
+            return hip.View(self._ptr(Lp.tops[0]), (Cc // self.cblk) * T * S, S, T * S, T)
         return None
 
     def _try_fuse_tail(self, i, L, layers, sole_consumer, absorbed) -> bool:
@@ -715,12 +828,19 @@ class Engine:
             absorbed[c] = L.name
         for nm in (L.tops[0], blob):
             self.fused_away[nm] = f"only exists inside the fused {L.name}+{Lf.name} tail"
-        self._materialize(Lf.tops[0], Lf.top_shapes[0])
+        self._materialize(Lf.tops[0], Lf.top_shapes[0], plain=True)
         x, y = self._ptr(L.bottoms[0]), self._ptr(Lf.tops[0])
         w = self._pdev(Lf.name, "w")
         bias = self._pdev(Lf.name, "bias") if Lf.geom["bias_term"] else None
         B, Cc, S, n_out = b[0], b[1], _prod(b[2:]), Lf.geom["num_output"]
         lib = self.lib
+        if self.dt:
+            dt = self.dt
+            self._add(i, f"{L.name}+{Lf.name}", lambda s, x=x, w=w, bias=bias, y=y, B=B, Cc=Cc, S=S, n_out=n_out:
+                      lib.global_avgpool_fc_b_forward(x, dt, w, bias, y, B, Cc, S, n_out, Cc, 0, False, s),
+                      {"kernel": "eco::global_avgpool_fc_b_kernel", "flops": 2 * B * n_out * Cc,
+                       "bytes": self.esize * B * Cc * S + 4 * (n_out * Cc + B * n_out)})
+            return True
         self._add(i, f"{L.name}+{Lf.name}", lambda s, x=x, w=w, bias=bias, y=y, B=B, Cc=Cc, S=S, n_out=n_out:
                   lib.global_avgpool_fc_forward(x, w, bias, y, B, Cc, S, n_out, Cc, 0, False, s),
                   {"kernel": "eco::global_avgpool_fc_kernel", "flops": 2 * B * n_out * Cc,

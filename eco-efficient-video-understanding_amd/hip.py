@@ -101,6 +101,12 @@ def conv_kernel_name(plan: ConvPlan) -> str:
     return f"eco::conv_mfma_kernel<{tm}, {tn}, {wm}, {wn}, {plan.kc}, {plan.mode}>"
 
 
+def convb_kernel_name(plan: "ConvBPlan") -> str:
+    """Device kernel eco_convb_forward launches for this plan, as rocprofv3 prints it."""
+    tm, tn, wm, wn = _CONV_TILES[(plan.bm, plan.bn)]
+    return f"eco::convb_kernel<{tm}, {tn}, {wm}, {wn}, {1 if plan.dt == DT_BF16 else 3}>"
+
+
 def pool_kernel_name(g: "PoolGeom") -> str:
     """Device kernel eco_pool_forward picks for this geometry (mirrors the dispatch in csrc/eco_ops.hip;
     the float4 fast paths additionally need 16-byte aligned pointers, which torch allocations are)."""

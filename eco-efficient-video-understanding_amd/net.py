@@ -132,6 +132,9 @@ class Blob:
         t = self._net._engine.tensors.get(self._name)
         if t is None:
             self._net._engine._ptr(self._name)  # raises with the fused-away reason
+        if t.dt:
+            raise AttributeError(f"blob {self._name!r} is stored channel-blocked ({self._net._engine.dtype} path); "
+                                 "only fp32 N,C,... blobs (net inputs, logits) have a device view -- use .data")
         owner = self._root if self._root is not None else self
         self._net._flush_host(owner._name)
         owner._head = _HEAD_DEVICE
@@ -147,7 +150,8 @@ class _LayerView:
 
 class Net:
     def __init__(self, model, weights=None, phase=TEST, *, fuse: bool = True, winograd: bool = True,
-                 device: Optional[int] = None, params: Optional[Dict[str, List[np.ndarray]]] = None, seed: int = 0,
+                 dtype: str = "f32", device: Optional[int] = None,
+                 params: Optional[Dict[str, List[np.ndarray]]] = None, seed: int = 0,
                  _backend=None, _num_cu: Optional[int] = None) -> None:
         # pycaffe accepts Net(model, phase) and Net(model, weights, phase)
         if isinstance(weights, int) and not isinstance(weights, bool):
@@ -169,7 +173,11 @@ class Net:
         # winograd=False evaluates every convolution directly (the reference's arithmetic order up to the
         # summation order); the default (True) routes every stride-1 3x3(x3) conv with cin >= 64 through
         # Winograd F(4x4,3x3) when the batch is large enough (engine._wino_eligible); 2 / 4 force the tile size
-        self._engine = Engine(self._spec, lib, alloc, fuse=fuse, winograd=winograd, num_cu=_num_cu)
+        # dtype: "f32" (default) = the reference's fp32 blobs on the fp32 MFMA kernels; "bf16" = bf16 storage and
+        # bf16 MFMA with fp32 accumulation (BASELINE configs[4]); "f32x3" = fp32 storage, operands split exactly
+        # into three bf16 terms on the bf16 matrix cores.  The last two keep activations channel-blocked internally;
+        # .data still hands out N,C,... fp32 arrays.
+        self._engine = Engine(self._spec, lib, alloc, fuse=fuse, winograd=winograd, num_cu=_num_cu, dtype=dtype)
         self._pending_input_shapes: Dict[str, tuple] = {}
         self._engine.set_params(params if params is not None else fillers.filler_params(self._spec, seed))
         self._engine.build()
@@ -231,14 +239,23 @@ class Net:
         if hasattr(self._alloc, "synchronize"):
             self._alloc.synchronize()
         t = eng.tensors[name]
-        return self._alloc.download(t.handle, t.count)
+        raw = self._alloc.download(t.handle, t.count)
+        if t.dt:   # channel-blocked storage -> the reference's N,C,... fp32 layout
+            from . import blocked
+            return blocked.from_blocked(np.asarray(raw), t.shape, t.dt).reshape(-1)
+        return raw
 
     def _flush_host(self, name: str) -> None:
         b = self.blobs[name]
         if b._root is not None:   # an alias: its storage owner carries the mirror
             return
         if b._head == _HEAD_HOST and b._host is not None and name in self._engine.tensors:
-            self._alloc.upload(self._engine.tensors[name].handle, b._host)
+            t = self._engine.tensors[name]
+            if t.dt:
+                from . import blocked
+                self._alloc.upload(t.handle, blocked.to_blocked(b._host.reshape(t.shape), t.dt))
+            else:
+                self._alloc.upload(t.handle, b._host)
             b._head = _HEAD_SYNCED
 
     # -- API ----------------------------------------------------------------

@@ -267,14 +267,14 @@ typedef struct eco_convb_plan {
   int32_t dt;        /* ECO_DT_*                                                                         */
   int32_t stem;      /* 1: the 3-channel 7x7 stride-2 pad-3 stem; x is the image of eco_stem_pack_forward */
   int32_t cblocks;   /* input channel blocks reduced over (cin/8; 4 for the stem)                        */
-  int32_t nstages;   /* reduction stages of 32 elements: (cblocks/4) * taps                              */
+  int32_t nstages;   /* reduction stages of 32 elements: ceil(cblocks/4) * taps (zero-padded weights)       */
   int32_t mpad;      /* cout rounded up to a multiple of bm                                              */
   int32_t ksplit;    /* > 1: reduction cut into ksplit slices, summed by a second deterministic launch   */
   int64_t wp_vecs;   /* 16-byte vectors in the packed weights: terms * nstages * 4 * mpad                */
   int64_t ws_bytes;  /* device scratch eco_convb_forward needs (0 if ksplit == 1)                        */
 } eco_convb_plan;
 
-/* Requirements: cout % 8 == 0 and cin % 32 == 0, or the stem geometry (cin 3, 2-D 7x7, stride 2, pad 3, even W).
+/* Requirements: cout % 8 == 0 and cin % 8 == 0, or the stem geometry (cin 3, 2-D 7x7, stride 2, pad 3, even W).
  * num_cu = 0 sizes the plan for 256 compute units. */
 int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t num_cu, eco_convb_plan* plan);
 /* HOST function: caffe weights w[cout][cin][kd][kh][kw] (fp32) -> wp[term][stage][4][mpad][8] bf16

@@ -345,7 +345,8 @@ def video_transform(frames_hwc_u8, crop_h, crop_w, h_off, w_off, mean, scale=1.0
 # --------------------------------------------------------------------------
 # whole-net forward (Net::ForwardFromTo, net.cpp:566-583)
 # --------------------------------------------------------------------------
-def forward(spec, params, inputs, keep=None, fast_pool=True, timings=None, conv_impl=None):
+def forward(spec, params, inputs, keep=None, fast_pool=True, timings=None, conv_impl=None, store_hook=None,
+            input_hook=None):
     """Run ``spec`` (an ``eco_amd.netspec.NetSpec``) layer by layer in file order.
 
     ``params``: {layer name: [ndarray, ...]} in the reference's blob order
@@ -354,10 +355,14 @@ def forward(spec, params, inputs, keep=None, fast_pool=True, timings=None, conv_
     net outputs plus every name in ``keep`` (``keep='all'`` keeps everything).
     In-place layers overwrite their blob exactly as the reference does.
     ``conv_impl(x, w, b, kernel, stride, pad)`` replaces the NumPy convolution (bench.py's CPU baselines plug in
-    the compiled reference im2col + OpenBLAS path of oracle/eco_ref.py, or torch-CPU)."""
+    the compiled reference im2col + OpenBLAS path of oracle/eco_ref.py, or torch-CPU).
+    ``store_hook(blob name, array)`` / ``input_hook`` transform a top / an input before it is stored: the
+    bf16-storage comparisons round there exactly where the blocked path rounds (tests/test_blocked.py)."""
     import time
     conv_fn = conv_impl or convolution
     blobs = {k: np.ascontiguousarray(v, dtype=F32) for k, v in inputs.items()}
+    if input_hook is not None:
+        blobs = {k: np.ascontiguousarray(input_hook(k, v), dtype=F32) for k, v in blobs.items()}
     pool_fn = pooling_fast if fast_pool else pooling
     last_use = {}
     for i, L in enumerate(spec.layers):
@@ -409,7 +414,7 @@ def forward(spec, params, inputs, keep=None, fast_pool=True, timings=None, conv_
             raise NotImplementedError(L.type)
         for name, v, shp in zip(L.tops, top, L.top_shapes):
             assert tuple(v.shape) == tuple(shp), (L.name, v.shape, shp)
-            blobs[name] = v
+            blobs[name] = v if store_hook is None else np.ascontiguousarray(store_hook(name, v), dtype=F32)
         if wanted is not None:
             for b in L.bottoms:
                 if last_use.get(b) == i and b not in wanted and b not in L.tops:

@@ -54,6 +54,7 @@ CONVS = [  # n, cin, cout, in_sp, kernel, stride, pad
     (2, 32, 32, (4, 6, 6), (3, 3, 3), (2, 2, 2), (1, 1, 1)),   # 3-D strided, bm = 32
     (1, 64, 160, (3, 5, 5), (3, 3, 3), (1, 1, 1), (1, 1, 1)),  # 3-D same, cout 160 -> bm 96 (2 M-blocks)
     (2, 96, 128, (6, 6), (3, 3), (2, 2), (1, 1)),         # bm = 128, three stages per tap group
+    (2, 24, 40, (5, 5), (3, 3), (1, 1), (1, 1)),          # cin = 24: zero-padded last channel group; cout 40
 ]
 
 
@@ -200,8 +201,8 @@ def test_global_avgpool_fc_b(backend, dt):
 
 
 def test_convb_rejects_unblocked_geometries(backend):
-    g = hip.conv_geom(1, 24, 32, (4, 4), (1, 1), (1, 1), (0, 0), (4, 4))
-    with pytest.raises(hip.EcoError, match="multiple of 32"):
+    g = hip.conv_geom(1, 20, 32, (4, 4), (1, 1), (1, 1), (0, 0), (4, 4))
+    with pytest.raises(hip.EcoError, match="multiple of the 8-channel block"):
         backend.lib.convb_plan(g, BF16)
     g = hip.conv_geom(1, 32, 12, (4, 4), (1, 1), (1, 1), (0, 0), (4, 4))
     with pytest.raises(hip.EcoError, match="multiple of the 8-channel block"):
@@ -209,3 +210,76 @@ def test_convb_rejects_unblocked_geometries(backend):
     g = hip.conv_geom(1, 32, 32, (4, 4), (1, 1), (1, 1), (0, 0), (4, 4))
     with pytest.raises(hip.EcoError, match="storage type"):
         backend.lib.convb_plan(g, 2)
+
+
+# ---- whole nets on the blocked path --------------------------------------------------------------------------
+def _mini_lite(num_segments=4, num_clips=2):
+    from eco_amd import models
+    # width_div=4: every channel count stays a multiple of the 8-channel block (96/4 = 24, a partial last stage)
+    return models.eco_lite_deploy(num_segments=num_segments, num_clips=num_clips, num_classes=10, input_size=32, width_div=4)
+
+
+def oracle_blocked(spec, params, x, dt, stored):
+    """The oracle with the storage rounding of the blocked path: weights rounded to the storage type, and every
+    blob the engine materialises rounded when it is stored (`stored` = its blob names); everything else fp32."""
+    if dt != BF16:
+        return orc.forward(spec, params, {"data": x}, keep="all", fast_pool=False)
+    qp = {k: [blocked.bf16_round(b) if (i == 0 and spec.layer(k).type == "Convolution") else b for i, b in enumerate(v)]
+          for k, v in params.items()}
+    return orc.forward(spec, qp, {"data": x}, keep="all", fast_pool=False,
+                       store_hook=lambda name, v: blocked.bf16_round(v) if name in stored else v,
+                       input_hook=lambda name, v: blocked.bf16_round(v))
+
+
+@pytest.mark.parametrize("dtype,dt", [("bf16", BF16), ("f32x3", F32X3)])
+def test_mini_eco_lite_blocked(backend, dtype, dt):
+    from eco_amd import fillers
+    from eco_amd.net import Net
+    from eco_amd.netspec import NetSpec
+    proto = _mini_lite()
+    spec = NetSpec.from_prototxt(proto)
+    params = fillers.synthetic_params(spec, seed=7)
+    x = fillers.synthetic_frames(8, 32, 32, seed=3)
+    kw = {"_backend": (backend.lib, backend.alloc)} if backend.kind == "emu" else {}
+    net = Net(proto, params=params, dtype=dtype, **kw)
+    net.blobs["data"].data[...] = x
+    out = net.forward()["fc8"].copy()
+    stored = {n for n, t in net._engine.tensors.items() if t.dt}
+    ref = oracle_blocked(spec, params, x, dt, stored)
+    scale = np.abs(ref["fc8"]).max()
+    # bf16: against the oracle with the same storage rounding (accumulation order and double rounding remain);
+    # f32x3: fp32-class
+    assert np.abs(out - ref["fc8"]).max() <= (2e-2 if dt == BF16 else 2e-5) * scale
+    if dt == BF16:  # and against the plain fp32 oracle within the stated bf16 tolerance
+        full = orc.forward(spec, params, {"data": x})["fc8"]
+        assert np.abs(out - full).max() <= 3e-2 * np.abs(full).max()
+    seen = 0
+    for name, t in net._engine.tensors.items():
+        got = net.blobs[name].data
+        r = ref[name].reshape(got.shape)
+        tol = (2e-2 if dt == BF16 else 2e-5) * (np.abs(r).max() + 1e-30)
+        assert np.abs(got - r).max() <= tol, name
+        seen += 1
+    assert seen >= 10
+    with pytest.raises(AttributeError, match="channel-blocked"):
+        net.blobs["res2b_bn"].tensor
+    assert any("stem pack" in l for l in net.op_labels())
+
+
+def test_blocked_path_refuses_unfused_and_foreign_graphs(backend):
+    from eco_amd import fillers
+    from eco_amd.net import Net
+    from eco_amd.netspec import NetSpec, NetSpecError
+    kw = {"_backend": (backend.lib, backend.alloc)} if backend.kind == "emu" else {}
+    proto = _mini_lite()
+    with pytest.raises(NetSpecError, match="fused plan only"):
+        Net(proto, dtype="bf16", fuse=False, **kw)
+    with pytest.raises(ValueError, match="dtype"):
+        Net(proto, dtype="fp16", **kw)
+    lone_relu = """
+    input: "data" input_dim: 1 input_dim: 3 input_dim: 32 input_dim: 32
+    layer { name: "c" type: "Convolution" bottom: "data" top: "c" convolution_param { num_output: 32 kernel_size: 7 stride: 2 pad: 3 } }
+    layer { name: "r" type: "ReLU" bottom: "c" top: "c" }
+    """
+    with pytest.raises(NetSpecError, match="no stand-alone kernel on the blocked"):
+        Net(lone_relu, dtype="bf16", **kw)

@@ -128,3 +128,105 @@ def test_caffe_time_style_report():
     # Winograd size rule and expands to three launches
     assert "Average Forward pass" in out.stdout and out.stdout.count("forward:") == 37 + 2
     assert out.stdout.count("winograd F(4x4,3x3)") == 2
+
+
+def _fast_oracle(spec, params, x, **kw):
+    """The CPU oracle with its convolutions on the compiled reference im2col + OpenBLAS sgemm (oracle/_ref) when
+    that library travelled with the snapshot: same arithmetic, several times faster than the NumPy im2col."""
+    try:
+        import eco_ref
+        if eco_ref.available():
+            return orc.forward(spec, params, {"data": x}, conv_impl=lambda *a: eco_ref.convolution(*a), **kw)
+    except Exception:
+        pass
+    return orc.forward(spec, params, {"data": x}, **kw)
+
+
+def test_eco_full_c4_n16_b32():
+    """BASELINE.json configs[3]: ECO-Full, num_segments=16, 32 clips.  Three clips of the batch against the CPU
+    oracle (each run alone: 129 GFLOP per clip on the CPU), and the size-independent properties for the rest:
+    row i of the batch == that clip alone on the GPU, permuting clips permutes logits."""
+    N, B = 16, 32
+    proto = models.eco_full_deploy(num_segments=N, num_clips=B)
+    spec = NetSpec.from_prototxt(proto)
+    assert abs(spec.conv_fc_flops() / 1e9 - 4122.43) < 0.01  # SURVEY.md section 8d
+    params = fillers.synthetic_params(spec)
+    x = fillers.synthetic_frames(B * N)
+    net = Net(proto, params=params)
+    out = net.forward(data=x)["fc8"].copy()
+    assert out.shape == (B, 400) and np.isfinite(out).all()
+    scale = np.abs(out).max()
+    proto1 = models.eco_full_deploy(num_segments=N, num_clips=1)
+    spec1 = NetSpec.from_prototxt(proto1)
+    for clip in (0, 13, 31):
+        ref = _fast_oracle(spec1, params, x[clip * N:(clip + 1) * N])["fc8"]
+        assert relerr(out[clip:clip + 1], ref) < TOL and out[clip].argmax() == ref.argmax(), clip
+    net1 = Net(proto1, params=params)
+    for clip in (5, 22):
+        alone = net1.forward(data=x[clip * N:(clip + 1) * N])["fc8"]
+        assert np.abs(alone[0] - out[clip]).max() < 1e-5 * scale, clip
+    perm = np.random.default_rng(1).permutation(B)
+    xp = x.reshape(B, N, 3, 224, 224)[perm].reshape(B * N, 3, 224, 224)
+    outp = net.forward(data=xp)["fc8"]
+    assert np.abs(outp - out[perm]).max() < 1e-5 * scale
+
+
+BF16_TOL = 3e-2   # bf16 storage: 2^-9 relative rounding per stored activation / weight, ~40 stored tensors deep
+
+
+def test_eco_lite_c5_bf16_n32():
+    """BASELINE.json configs[4]: ECO-Lite num_segments=32 (r2Dto3D 32x96x28x28, global_pool 8x7x7), bf16, 32 clips
+    per GPU.  The oracle stays fp32; two comparisons for clip 0: (a) against the oracle run with the same storage
+    rounding (weights and every stored activation rounded to bf16 where the blocked path rounds) -- what remains
+    is accumulation order and double rounding; (b) against the plain fp32 oracle within the stated bf16 tolerance
+    (3e-2 of the largest logit; measured value printed).  Then the clip-independence / permutation properties at
+    the full batch."""
+    from eco_amd import blocked
+    N, B = 32, 32
+    proto = models.eco_lite_deploy(num_segments=N, num_clips=B)
+    spec = NetSpec.from_prototxt(proto)
+    assert abs(spec.conv_fc_flops() / 1e9 - 5950.25) < 0.01
+    assert spec.blob_shapes["res2b_bn"] == (B, 96, 32, 28, 28) and spec.blob_shapes["res5b_bn"] == (B, 512, 8, 7, 7)
+    params = fillers.synthetic_params(spec)
+    x = fillers.synthetic_frames(B * N)
+    net = Net(proto, params=params, dtype="bf16")
+    out = net.forward(data=x)["fc8"].copy()
+    assert out.shape == (B, 400) and np.isfinite(out).all()
+    scale = np.abs(out).max()
+    stored = {n for n, t in net._engine.tensors.items() if t.dt}
+    spec1 = NetSpec.from_prototxt(models.eco_lite_deploy(num_segments=N, num_clips=1))
+    qp = {k: [blocked.bf16_round(b) if (i == 0 and spec1.layer(k).type == "Convolution") else b for i, b in enumerate(v)]
+          for k, v in params.items()}
+    ref_q = _fast_oracle(spec1, qp, x[:N], store_hook=lambda name, v: blocked.bf16_round(v) if name in stored else v,
+                         input_hook=lambda name, v: blocked.bf16_round(v))["fc8"]
+    ref = _fast_oracle(spec1, params, x[:N])["fc8"]
+    e_q, e_f = relerr(out[:1], ref_q), relerr(out[:1], ref)
+    print(f"bf16 N=32: rel err vs rounding-aware oracle {e_q:.3e}, vs fp32 oracle {e_f:.3e}, max|logit| {np.abs(ref).max():.1f}")
+    assert e_q < BF16_TOL and e_f < BF16_TOL
+    net1 = Net(models.eco_lite_deploy(num_segments=N, num_clips=1), params=params, dtype="bf16")
+    alone = net1.forward(data=x[17 * N:18 * N])["fc8"]
+    assert np.abs(alone[0] - out[17]).max() < 1e-5 * scale
+    perm = np.random.default_rng(0).permutation(B)
+    xp = x.reshape(B, N, 3, 224, 224)[perm].reshape(B * N, 3, 224, 224)
+    outp = net.forward(data=xp)["fc8"]
+    assert np.abs(outp - out[perm]).max() < 1e-5 * scale
+
+
+def test_eco_lite_c2_f32x3():
+    """configs[1] geometry on the split-operand path (fp32 storage, three exact bf16 terms per operand, six MFMA
+    products): fp32-class logits -- the fp32 tolerance of 1e-3 applies, measured value printed -- and it agrees
+    with the fp32-MFMA path of the same build."""
+    N, B = 16, 32
+    proto = models.eco_lite_deploy(num_segments=N, num_clips=B)
+    spec = NetSpec.from_prototxt(proto)
+    params = fillers.synthetic_params(spec)
+    x = fillers.synthetic_frames(B * N)
+    out = Net(proto, params=params, dtype="f32x3").forward(data=x)["fc8"].copy()
+    scale = np.abs(out).max()
+    spec1 = NetSpec.from_prototxt(models.eco_lite_deploy(num_segments=N, num_clips=1))
+    ref = _fast_oracle(spec1, params, x[:N])["fc8"]
+    native = Net(proto, params=params, winograd=False).forward(data=x)["fc8"]
+    print(f"f32x3: rel err vs CPU oracle {relerr(out[:1], ref):.3e}; fp32-MFMA direct path vs oracle "
+          f"{relerr(native[:1], ref):.3e}; f32x3 vs fp32-MFMA over 32 clips {np.abs(out - native).max() / scale:.3e}")
+    assert relerr(out[:1], ref) < TOL and out[0].argmax() == ref.argmax()
+    assert np.abs(out - native).max() < 1e-4 * scale
