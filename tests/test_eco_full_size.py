@@ -205,11 +205,13 @@ def test_eco_lite_c5_bf16_n32():
     assert e_q < BF16_TOL and e_f < BF16_TOL
     net1 = Net(models.eco_lite_deploy(num_segments=N, num_clips=1), params=params, dtype="bf16")
     alone = net1.forward(data=x[17 * N:18 * N])["fc8"]
-    assert np.abs(alone[0] - out[17]).max() < 1e-5 * scale
+    # a single clip gets other split-K factors: another fp32 summation order, so a stored bf16 value may round
+    # the other way now and then -- far below the storage tolerance, but not bit-identical
+    assert np.abs(alone[0] - out[17]).max() < 5e-3 * scale
     perm = np.random.default_rng(0).permutation(B)
     xp = x.reshape(B, N, 3, 224, 224)[perm].reshape(B * N, 3, 224, 224)
     outp = net.forward(data=xp)["fc8"]
-    assert np.abs(outp - out[perm]).max() < 1e-5 * scale
+    assert np.abs(outp - out[perm]).max() < 5e-3 * scale   # tile boundaries move with the clip order
 
 
 def test_eco_lite_c2_f32x3():
