@@ -424,6 +424,166 @@ __global__ __launch_bounds__(256, 2) void convb_kernel(const ConvBArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// bf16 storage: the same implicit GEMM with both operands staged by LDS-DMA (global_load_lds_dwordx4) and larger
+// wave tiles.  Why: with 16x the MFMA rate the register-staged kernel above is bound by the LDS array, not by the
+// matrix cores -- a 2x2 wave tile reads 1 KB of fragments per MFMA and every staged KB costs a 13-cycle
+// ds_write_b128 issue plus 8 LDS-array cycles: reads + writes fill the 256 B/clk array at ~36 % MFMA utilisation
+// (measured: 0.9 PFLOP/s on res3).  Here
+//   * a wave owns TM x TN = 4x2 tiles (128 channels x 64 positions, 128 accumulator registers): 6 fragment reads
+//     per 8 MFMAs instead of 4 per 4,
+//   * the stage's weight rows and position blocks go global -> LDS without passing through VGPRs: one
+//     instruction moves 64 lanes x 16 B into 1 KB of LDS (half the LDS-array cycles of ds_write_b128, no VGPR
+//     staging, no store issue), consecutive lanes = consecutive channels / positions, which is exactly the
+//     [block][m or n] fragment layout (conflict-free ds_read_b128),
+//   * zero padding costs nothing: a lane whose tap falls outside the image points its DMA at a 16-byte zero page,
+//   * every lane serves ONE position for the whole reduction (wave w stages positions [64*(w % (BN/64)), +64) of
+//     the blocks kb = w / (BN/64) (+ 4/(BN/64)...)), so the per-stage address is one add.
+// Pipeline (three stage buffers): the DMA of stage s+2 is issued at the top of stage s, so every piece has two
+// stages of MFMAs to land.  Top of stage s: wait until all but this wave's newest stage of pieces has landed
+// (s_waitcnt vmcnt(P)), then one workgroup barrier -- it publishes stage s to every wave and, because every wave
+// has finished the MFMAs of stage s-1 by then, frees that stage's buffer for the DMA of stage s+2.  The buffers
+// are separate __shared__ arrays and the stage loop is unrolled by three so that every access names its array
+// statically: hipcc orders a ds_read behind outstanding LDS-DMA by alias analysis, and with one array it drains
+// the whole DMA queue in front of every fragment read (measured in the ISA: s_waitcnt vmcnt(0) before the first
+// ds_read of each stage).
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void convb_dma_kernel(const ConvBArgs a, const uint4* zero_page) {
+  constexpr int BM = 32 * TM * WM;
+  constexpr int BN = 32 * TN * WN;
+  constexpr int BMP = (BM + 63) / 64 * 64;   // weight rows staged per block (whole 64-lane pieces)
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(BN == 128 || BN == 256, "");
+  constexpr int NCH = BN / 64;               // 64-position chunks of the tile
+  constexpr int B_PER_WAVE = kCbs * NCH / 4; // DMA pieces of the position operand per wave and stage (2 or 4)
+  constexpr int KB_STEP = 4 / NCH;           // wave w stages blocks kb = w / NCH + q * KB_STEP
+  constexpr int A_PER_WAVE = kCbs * BMP / 64 / 4;   // DMA pieces of the weight operand per wave and stage
+  constexpr int P = B_PER_WAVE + A_PER_WAVE;        // pieces in flight per wave and stage
+
+  __shared__ __attribute__((aligned(16))) uint4 A0[kCbs * BMP], A1[kCbs * BMP], A2[kCbs * BMP];
+  __shared__ __attribute__((aligned(16))) uint4 B0[kCbs * BN], B1[kCbs * BN], B2[kCbs * BN];
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int ntiles = a.nblk_m * a.nblk_n;
+  const int slice = (int)blockIdx.x / ntiles;
+  const int tile = xcd_remap((int)blockIdx.x - slice * ntiles, ntiles);
+  const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
+  const int m0 = mblk * BM, n0 = nblk * BN;
+  const int s_begin = (int)((long)slice * a.nstages / a.ksplit);
+  const int s_end = (int)((long)(slice + 1) * a.nstages / a.ksplit);
+
+  // ---- the one position this lane stages: chunk (wave % NCH), lane ----
+  const int chunk = wave % NCH, kb0 = wave / NCH;
+  const int khw = a.kh * a.kw;
+  long in_base = 0;
+  unsigned long long mask = 0ull;
+  {
+    const int n = n0 + chunk * 64 + lane;
+    if (n < a.ntot) {
+      int img, sp;
+      decode_out(a, n, img, sp);
+      const int ow = sp % a.Wo, t = sp / a.Wo;
+      const int oh = t % a.Ho, od = t / a.Ho;
+      const int id0 = od * a.sd - a.pd, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
+      in_base = (long)img * a.img_stride_in + ((long)id0 * a.Hi + ih0) * a.Wi + iw0;
+      unsigned long long mw_ = 0ull, mhw = 0ull;
+      for (int xx = 0; xx < a.kw; ++xx) mw_ |= (unsigned long long)((unsigned)(iw0 + xx) < (unsigned)a.Wi) << xx;
+      for (int y = 0; y < a.kh; ++y)
+        if ((unsigned)(ih0 + y) < (unsigned)a.Hi) mhw |= mw_ << (y * a.kw);
+      for (int z = 0; z < a.kd; ++z)
+        if ((unsigned)(id0 + z) < (unsigned)a.Di) mask |= mhw << (z * khw);
+    }
+  }
+  const uint4* const xv = (const uint4*)a.x;
+  // out-of-image taps read the zero page: one integer select per piece (no divergent second instruction)
+  const long zoff = (long)(((intptr_t)zero_page - (intptr_t)xv) / 16);
+
+  // the stage whose DMA is issued next: uniform (cg, tap) walk
+  int l_cg = s_begin / a.taps, l_tap = s_begin - l_cg * a.taps;
+  int l_kx = l_tap % a.kw, l_ky = (l_tap / a.kw) % a.kh, l_kz = l_tap / khw;
+  int l_stage = s_begin;
+  auto issue_stage = [&](uint4* Ab, uint4* Bb) {   // DMA of stage l_stage into (Ab, Bb), then step the walk
+    const long toff = ((long)l_kz * a.Hi + l_ky) * a.Wi + l_kx;
+    // all-ones where the tap is inside the image.  Opaque to the optimiser: a recognisable select gets turned
+    // into a divergent branch with one copy of the DMA instruction in each arm, and then a wave with both kinds
+    // of lanes issues more pieces than wait_dma_all_but<P> accounts for.
+    long sel = -(long)((mask >> l_tap) & 1ull);
+    ECO_OPAQUE64(sel);
+#pragma unroll
+    for (int q = 0; q < B_PER_WAVE; ++q) {
+      const int kb = kb0 + q * KB_STEP;
+      const int cb = min(l_cg * kCbs + kb, a.cblocks - 1);   // zero-weight padding group: any finite data
+      const long real = in_base + toff + (long)cb * a.cb_stride_in;
+      glds16(xv + (zoff ^ ((zoff ^ real) & sel)), Bb + kb * BN + chunk * 64);
+    }
+#pragma unroll
+    for (int q = 0; q < A_PER_WAVE; ++q) {
+      const int piece = wave + 4 * q;       // piece = row * (BMP/64) + m-chunk
+      const int row = piece / (BMP / 64), mc = piece % (BMP / 64);
+      glds16(a.wp + ((long)l_stage * kCbs + row) * a.mpad + m0 + mc * 64 + lane, Ab + row * BMP + mc * 64);
+    }
+    ++l_stage;
+    ++l_tap;
+    if (++l_kx == a.kw) {
+      l_kx = 0;
+      if (++l_ky == a.kh) {
+        l_ky = 0;
+        if (++l_kz == a.kd) { l_kz = 0; l_tap = 0; ++l_cg; }
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto compute = [&](const uint4* Ab, const uint4* Bb) {
+#pragma unroll
+    for (int ks = 0; ks < kCbs / 2; ++ks) {
+      uint4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = Ab[(2 * ks + half) * BMP + (wm * TM + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bb[(2 * ks + half) * BN + (wn * TN + j) * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
+    }
+  };
+  // One stage: its own pieces (issued two stages ago) have landed once at most the newest stage's P are pending.
+  auto stage = [&](int s, const uint4* Ab, const uint4* Bb, uint4* An, uint4* Bn) {
+    if (s + 1 < s_end) wait_dma_all_but<P>(); else wait_dma_all_but<0>();
+    wg_barrier_nodrain();
+    if (s + 2 < s_end) issue_stage(An, Bn);
+    sched_fence();
+    compute(Ab, Bb);
+  };
+
+  if (s_begin < s_end) {
+    issue_stage(A0, B0);
+    if (s_begin + 1 < s_end) issue_stage(A1, B1);
+    for (int s = s_begin; s < s_end; s += 3) {
+      stage(s, A0, B0, A2, B2);
+      if (s + 1 < s_end) stage(s + 1, A1, B1, A0, B0);
+      if (s + 2 < s_end) stage(s + 2, A2, B2, A1, B1);
+    }
+  }
+  if (a.ksplit > 1)
+    convb_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+  else
+    convb_epilogue<TM, TN, 1>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Stem input: fp32 N,3,H,W (the `data` blob, VideoData contract) -> zero-padded pixel-interleaved image
 //   P[f][h + 3][w + 3][4] (channel 3 = 0), rows of W + 8 pixels, H + 6 rows
 // in the path's storage type.  For conv1_7x7_s2 (stride 2, pad 3) the seven taps of kernel row ky of output
@@ -661,12 +821,19 @@ extern "C" int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t
   const long ntot = (long)g->n * g->out[0] * g->out[1] * g->out[2];
   plan->bm = bm;
   plan->bn = bm == 128 ? 128 : 256;
+  if (ns == 1) {
+    // LDS-DMA kernel (bf16): 4x2 wave tiles -- 256 x 128 blocks for the wide layers (res4 / res5), 128 x 256 for
+    // 128-channel layers (res3) when the problem has enough positions to fill such tiles
+    if (bm == 128 && g->cout % 256 == 0 && ntot >= 4096) { plan->bm = bm = 256; plan->bn = 128; }
+    else if (bm == 128 && ntot >= 8192) plan->bn = 256;
+  }
   plan->dt = dt;
   plan->stem = is_stem(g) ? 1 : 0;
   plan->cblocks = plan->stem ? 4 : g->cin / 8;
   const int taps = plan->stem ? 7 : g->kernel[0] * g->kernel[1] * g->kernel[2];
   plan->nstages = (int)ceil_div(plan->cblocks, kCbs) * taps;   // a partial last channel group is zero-padded
-  plan->mpad = (int)(ceil_div(g->cout, bm) * bm);
+  // whole 64-row pieces are staged per M-block (LDS-DMA moves 64 lanes x 16 bytes): pad the rows accordingly
+  plan->mpad = (int)((ceil_div(g->cout, bm) - 1) * bm + ceil_div(bm, 64) * 64);
   plan->wp_vecs = (int64_t)ns * plan->nstages * kCbs * plan->mpad;
   // split-K: with fewer tiles than resident workgroup slots cut the reduction so that tiles * slices fills them
   // (slices of >= 4 stages; partial sums cost one fp32 write + read of the outputs per slice)
@@ -723,13 +890,45 @@ extern "C" int eco_convb_pack_weights(const eco_conv_geom* g, const eco_convb_pl
   return ECO_OK;
 }
 
+// 16 bytes of zeros in device memory: the DMA source of out-of-image taps (one per device, never freed).
+static const uint4* device_zero_page() {
+#ifdef ECO_EMU
+  alignas(16) static const uint4 z = {0u, 0u, 0u, 0u};
+  emu_register_buffer(&z, sizeof(z));   // the test harness clears its registry between tests
+  return &z;
+#else
+  static thread_local const uint4* page[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!page[dev]) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+    page[dev] = (const uint4*)p;
+  }
+  return page[dev];
+#endif
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_convb_dma(const ConvBArgs& a, hipStream_t stream) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, BMP = (BM + 63) / 64 * 64;
+  const uint4* zp = device_zero_page();
+  if (!zp) return fail(ECO_ERR_RUNTIME, "convb: cannot allocate the zero page");
+  ECO_REQUIRE((((uintptr_t)a.x | (uintptr_t)a.wp) & 15) == 0, "convb: input and packed weights must be 16-byte aligned");
+  const int grid = a.nblk_m * a.nblk_n * a.ksplit;
+  static_assert(3 * kCbs * (BMP + BN) * 16 <= 160 * 1024, "three stage buffers must fit the CU's LDS");
+  hipLaunchKernelGGL((convb_dma_kernel<TM, TN, WM, WN>), dim3(grid), dim3(256), 0, stream, a, zp);
+  return check_launch("eco_convb_forward");
+}
+
 template <int TM, int TN, int WM, int WN>
 static int launch_convb(const ConvBArgs& a, int ns, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   const int grid = a.nblk_m * a.nblk_n * a.ksplit;
   const size_t lds = (size_t)2 * ns * kCbs * (BM + BN) * 16;
   if (ns == 1) {
-    hipLaunchKernelGGL((convb_kernel<TM, TN, WM, WN, 1>), dim3(grid), dim3(256), lds, stream, a);
+    return launch_convb_dma<TM, TN, WM, WN>(a, stream);
   } else {
 #ifndef ECO_EMU
     // the split form stages three operand planes: 96-135 KB of the CU's 160 KB, above the default dynamic-LDS cap
@@ -789,7 +988,7 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
   a.ntot = g->n * a.s_out;
   a.nblk_m = (int)ceil_div(g->cout, plan->bm);
   a.nblk_n = (int)ceil_div(a.ntot, plan->bn);
-  ECO_REQUIRE((long)a.nblk_m * plan->bm <= plan->mpad, "convb: plan mpad too small");
+  ECO_REQUIRE((long)(a.nblk_m - 1) * plan->bm + (plan->bm + 63) / 64 * 64 <= plan->mpad, "convb: plan mpad too small");
   ECO_REQUIRE(plan->ksplit >= 1 && plan->ksplit <= plan->nstages, "convb: bad split-K factor %d", plan->ksplit);
   ECO_REQUIRE(plan->ksplit == 1 || (workspace && (int64_t)plan->ksplit * g->cout * a.ntot * 4 <= plan->ws_bytes),
               "convb: plan needs a %ld-byte workspace", (long)plan->ws_bytes);
@@ -798,9 +997,14 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
   hipStream_t s = (hipStream_t)stream;
   int rc;
   switch (plan->bm) {
+    case 256:
+      ECO_REQUIRE(plan->bn == 128 && ns == 1, "convb: bad plan");
+      rc = launch_convb_dma<4, 2, 2, 2>(a, s);
+      break;
     case 128:
       ECO_REQUIRE(plan->bn == 128 || plan->bn == 256, "convb: bad plan");
-      rc = plan->bn == 128 ? launch_convb<2, 2, 2, 2>(a, ns, s) : launch_convb<2, 4, 2, 2>(a, ns, s);
+      if (ns == 1 && plan->bn == 256) rc = launch_convb_dma<4, 2, 1, 4>(a, s);
+      else rc = plan->bn == 128 ? launch_convb<2, 2, 2, 2>(a, ns, s) : launch_convb<2, 4, 2, 2>(a, ns, s);
       break;
     case 96: ECO_REQUIRE(plan->bn == 256, "convb: bad plan"); rc = launch_convb<3, 2, 1, 4>(a, ns, s); break;
     case 64: ECO_REQUIRE(plan->bn == 256, "convb: bad plan"); rc = launch_convb<2, 2, 1, 4>(a, ns, s); break;

@@ -66,6 +66,41 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned h) {
 }
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16); }
 
+// LDS-DMA: every lane copies 16 bytes from its own global address straight into LDS at
+// `lds_wave_base + 16*lane` (global_load_lds_dwordx4: no VGPR staging, no ds_write; the LDS base is wave-uniform,
+// in M0).  Asynchronous on the GPU: the bytes are in LDS once the issuing wave's vmcnt has counted the piece down
+// (wait_dma_all_but) AND a workgroup barrier has been passed by the reader.  Issued from inline asm on purpose:
+// hipcc orders ds_reads behind LDS-DMA it can see by alias analysis and, in a multi-buffer pipeline, ends up
+// draining the whole queue (s_waitcnt vmcnt(0)) in front of fragment reads; the kernels that use this do their
+// own counting, and exactly one instruction is issued per call, whatever the lanes' addresses.
+__device__ __forceinline__ void glds16(const uint4* gptr, uint4* lds_wave_base) {
+#ifdef ECO_EMU
+  lds_wave_base[emu::tls_cur->lane] = emu::check_access(gptr, 16, false) ? *gptr : uint4{0u, 0u, 0u, 0u};
+#else
+  const unsigned lds_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(gptr) : "memory", "m0");
+#endif
+}
+
+// Pipelined LDS-DMA needs two things __syncthreads() cannot give: a wait for all but the newest N DMA pieces of
+// this wave (s_waitcnt vmcnt(N); __syncthreads() drains everything) and a barrier that does not drain.  Both are
+// no-ops / a plain barrier under the emulator, where the DMA is synchronous.
+template <int N>
+__device__ __forceinline__ void wait_dma_all_but() {
+#ifndef ECO_EMU
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+__device__ __forceinline__ void wg_barrier_nodrain() {
+#ifdef ECO_EMU
+  emu::syncthreads();
+#else
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#endif
+}
+
 // Make a wave-uniform value provably uniform (SGPR) for the compiler.
 __device__ __forceinline__ int uniform(int v) {
 #ifdef ECO_EMU
@@ -141,8 +176,10 @@ __device__ __forceinline__ void st(T* p, T v) {
 // base register get merged into ds_read2_b64, which the LDS serves at half the rate of two ds_read_b64.
 #ifdef ECO_EMU
 #define ECO_OPAQUE(v) ((void)(v))
+#define ECO_OPAQUE64(v) ((void)(v))
 #else
 #define ECO_OPAQUE(v) asm volatile("" : "+v"(v))
+#define ECO_OPAQUE64(v) asm volatile("" : "+v"(v))
 #endif
 
 // XCD-aware workgroup remap (MI355X: 8 XCDs, hardware places block b on XCD b % 8, each

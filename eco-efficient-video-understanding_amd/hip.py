@@ -103,8 +103,11 @@ def conv_kernel_name(plan: ConvPlan) -> str:
 
 def convb_kernel_name(plan: "ConvBPlan") -> str:
     """Device kernel eco_convb_forward launches for this plan, as rocprofv3 prints it."""
+    if plan.dt == DT_BF16:   # LDS-DMA kernel
+        tm, tn, wm, wn = {(256, 128): (4, 2, 2, 2), (128, 256): (4, 2, 1, 4)}.get((plan.bm, plan.bn)) or _CONV_TILES[(plan.bm, plan.bn)]
+        return f"eco::convb_dma_kernel<{tm}, {tn}, {wm}, {wn}>"
     tm, tn, wm, wn = _CONV_TILES[(plan.bm, plan.bn)]
-    return f"eco::convb_kernel<{tm}, {tn}, {wm}, {wn}, {1 if plan.dt == DT_BF16 else 3}>"
+    return f"eco::convb_kernel<{tm}, {tn}, {wm}, {wn}, 3>"
 
 
 def pool_kernel_name(g: "PoolGeom") -> str:

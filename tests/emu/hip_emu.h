@@ -40,7 +40,7 @@ struct float2 {
   float x, y;
 };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
-struct uint4 {
+struct alignas(16) uint4 {
   unsigned x, y, z, w;
 };
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }

@@ -55,6 +55,8 @@ CONVS = [  # n, cin, cout, in_sp, kernel, stride, pad
     (1, 64, 160, (3, 5, 5), (3, 3, 3), (1, 1, 1), (1, 1, 1)),  # 3-D same, cout 160 -> bm 96 (2 M-blocks)
     (2, 96, 128, (6, 6), (3, 3), (2, 2), (1, 1)),         # bm = 128, three stages per tap group
     (2, 24, 40, (5, 5), (3, 3), (1, 1), (1, 1)),          # cin = 24: zero-padded last channel group; cout 40
+    (1, 32, 256, (66, 66), (1, 1), (1, 1), (0, 0)),       # bf16: 256 x 128 LDS-DMA tile (cout % 256 == 0, >= 4096 positions)
+    (1, 64, 128, (2, 65, 65), (3, 1, 1), (1, 1, 1), (1, 0, 0)),   # bf16: 128 x 256 LDS-DMA tile (>= 8192 positions)
 ]
 
 
