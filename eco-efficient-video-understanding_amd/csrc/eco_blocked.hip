@@ -42,7 +42,7 @@ struct ConvBArgs {
   const float* bias;
   const float* bn_scale;
   const float* bn_shift;
-  eco_view residual, raw, act;   // blocked views: strides in 8-channel blocks
+  eco_view residual, raw, act, act2;   // blocked views: strides in 8-channel blocks
   int relu;
   int cblocks, cout, mpad, nstages, taps;
   int Di, Hi, Wi, Do, Ho, Wo;
@@ -142,10 +142,10 @@ __device__ __forceinline__ void decode_out(const ConvBArgs& a, int n, int& img, 
 template <int TM, int TN, int NS>
 __device__ __forceinline__ void convb_epilogue(const ConvBArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw, int half,
                                                int l31) {
-  long e_res[TN], e_raw[TN], e_act[TN];
+  long e_res[TN], e_raw[TN], e_act[TN], e_act2[TN];
   bool e_ok[TN];
   const bool has_bias = a.bias != nullptr, has_bn = a.bn_scale != nullptr, has_res = a.residual.ptr != nullptr;
-  const bool has_raw = a.raw.ptr != nullptr, has_act = a.act.ptr != nullptr;
+  const bool has_raw = a.raw.ptr != nullptr, has_act = a.act.ptr != nullptr, has_act2 = has_act && a.act2.ptr != nullptr;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = nw + j * 32 + l31;
@@ -155,6 +155,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvBArgs& a, f32x16 (&acc)
     e_res[j] = has_res ? view_base(a.residual, img, sp) : 0;
     e_raw[j] = has_raw ? view_base(a.raw, img, sp) : 0;
     e_act[j] = has_act ? view_base(a.act, img, sp) : 0;
+    e_act2[j] = has_act2 ? view_base(a.act2, img, sp) : 0;
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -191,6 +192,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvBArgs& a, f32x16 (&acc)
             if (a.relu) y[q] = fmaxf(y[q], 0.0f);
           }
           store_quad<NS>(a.act.ptr, e_act[j] + (long)cbk * a.act.stride_c, half, y);
+          if (has_act2) store_quad<NS>(a.act2.ptr, e_act2[j] + (long)cbk * a.act2.stride_c, half, y);
         }
       }
     }
@@ -250,6 +252,7 @@ __global__ __launch_bounds__(256) void convb_splitk_reduce_kernel(const ConvBArg
           if (a.relu) y[q] = fmaxf(y[q], 0.0f);
         }
         store_quad<NS>(a.act.ptr, view_base(a.act, img, sp) + (long)cbk * a.act.stride_c, half, y);
+        if (a.act2.ptr) store_quad<NS>(a.act2.ptr, view_base(a.act2, img, sp) + (long)cbk * a.act2.stride_c, half, y);
       }
     }
   }
@@ -952,14 +955,15 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
   if (int rc = validate_convb_geom(g, plan->dt)) return rc;
   ECO_REQUIRE(ep->raw.ptr || ep->act.ptr, "convb: at least one of raw/act outputs is required");
   ECO_REQUIRE(!ep->bn_scale == !ep->bn_shift, "convb: bn_scale and bn_shift must be given together");
-  const eco_view* views[3] = {&ep->residual, &ep->raw, &ep->act};
+  ECO_REQUIRE(!ep->act2.ptr || ep->act.ptr, "convb: act2 needs act");
+  const eco_view* views[4] = {&ep->residual, &ep->raw, &ep->act, &ep->act2};
   for (const eco_view* v : views)
     ECO_REQUIRE(!v->ptr || (v->t >= 1 && v->stride_c >= 1), "convb: view needs t >= 1 and stride_c >= 1");
   const int ns = ns_of(plan->dt);
   ConvBArgs a;
   a.x = x; a.wp = (const uint4*)wp;
   a.bias = ep->bias; a.bn_scale = ep->bn_scale; a.bn_shift = ep->bn_shift;
-  a.residual = ep->residual; a.raw = ep->raw; a.act = ep->act; a.relu = ep->relu;
+  a.residual = ep->residual; a.raw = ep->raw; a.act = ep->act; a.act2 = ep->act2; a.relu = ep->relu;
   a.cout = g->cout; a.mpad = plan->mpad; a.nstages = plan->nstages; a.cblocks = plan->cblocks;
   a.Do = g->out[0]; a.Ho = g->out[1]; a.Wo = g->out[2];
   if (plan->stem) {

@@ -39,7 +39,7 @@ struct ConvKernelArgs {
   const float* bias;
   const float* bn_scale;
   const float* bn_shift;
-  eco_view residual, raw, act;
+  eco_view residual, raw, act, act2;
   int relu;
   int cin, cout, mpad, kpad;
   int Di, Hi, Wi, Do, Ho, Wo;
@@ -76,6 +76,7 @@ __device__ __forceinline__ ConvKernelArgs batch_args(const ConvKernelArgs& a0) {
   if (a.residual.ptr) a.residual.ptr += bz * a0.bstride_out;
   if (a.raw.ptr) a.raw.ptr += bz * a0.bstride_out;
   if (a.act.ptr) a.act.ptr += bz * a0.bstride_out;
+  if (a.act2.ptr) a.act2.ptr += bz * a0.bstride_out;
   if (a.ws) a.ws += bz * a0.bstride_ws;
   return a;
 }
@@ -140,10 +141,10 @@ __device__ __forceinline__ int col_slices(const ConvKernelArgs& a, int col) {
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw,
                                               int half, int l31) {
-  long e_res[TN], e_raw[TN], e_act[TN];
+  long e_res[TN], e_raw[TN], e_act[TN], e_act2[TN];
   bool e_ok[TN];
   const bool has_bias = a.bias != nullptr, has_bn = a.bn_scale != nullptr, has_res = a.residual.ptr != nullptr;
-  const bool has_raw = a.raw.ptr != nullptr, has_act = a.act.ptr != nullptr;
+  const bool has_raw = a.raw.ptr != nullptr, has_act = a.act.ptr != nullptr, has_act2 = has_act && a.act2.ptr != nullptr;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = nw + j * 32 + l31;
@@ -154,6 +155,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&
     e_res[j] = has_res ? view_base(a.residual, img, sp) : 0;
     e_raw[j] = has_raw ? view_base(a.raw, img, sp) : 0;
     e_act[j] = has_act ? view_base(a.act, img, sp) : 0;
+    e_act2[j] = has_act2 ? view_base(a.act2, img, sp) : 0;
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -193,7 +195,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&
           for (int q = 0; q < 4; ++q) {
             float y = v[q] * ps[q] + ph[q];
             if (a.relu) y = fmaxf(y, 0.0f);
-            if (chg + q < a.cout) st(a.act.ptr + e_act[j] + (long)(chg + q) * a.act.stride_c, y);
+            if (chg + q < a.cout) {
+              st(a.act.ptr + e_act[j] + (long)(chg + q) * a.act.stride_c, y);
+              if (has_act2) st(a.act2.ptr + e_act2[j] + (long)(chg + q) * a.act2.stride_c, y);
+            }
           }
         }
       }
@@ -278,6 +283,11 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKerne
       float* o = a.act.ptr + view_base(a.act, img, sp) + (long)ch * a.act.stride_c;
       if (VEC == 4) st((float4*)o, make_float4(y[0], y[1 % VEC], y[2 % VEC], y[3 % VEC]));
       else st(o, y[0]);
+      if (a.act2.ptr) {
+        float* o2 = a.act2.ptr + view_base(a.act2, img, sp) + (long)ch * a.act2.stride_c;
+        if (VEC == 4) st((float4*)o2, make_float4(y[0], y[1 % VEC], y[2 % VEC], y[3 % VEC]));
+        else st(o2, y[0]);
+      }
     }
   }
 }
@@ -1123,13 +1133,15 @@ static int conv_forward_impl(const eco_conv_geom* g, const eco_conv_plan* plan, 
   if (int rc = check_view(ep->residual, "residual")) return rc;
   if (int rc = check_view(ep->raw, "raw")) return rc;
   if (int rc = check_view(ep->act, "act")) return rc;
+  if (int rc = check_view(ep->act2, "act2")) return rc;
+  ECO_REQUIRE(!ep->act2.ptr || ep->act.ptr, "conv: act2 (second destination of the activated output) needs act");
   ECO_REQUIRE(plan->k == g->cin * g->kernel[0] * g->kernel[1] * g->kernel[2] && plan->kc == 16 &&
                   plan->kpad % plan->kc == 0 && plan->mpad % 4 == 0,
               "conv: plan does not match geometry");
   ConvKernelArgs a;
   a.x = x; a.wp = wp; a.ktab = ktab;
   a.bias = ep->bias; a.bn_scale = ep->bn_scale; a.bn_shift = ep->bn_shift;
-  a.residual = ep->residual; a.raw = ep->raw; a.act = ep->act; a.relu = ep->relu;
+  a.residual = ep->residual; a.raw = ep->raw; a.act = ep->act; a.act2 = ep->act2; a.relu = ep->relu;
   a.cin = g->cin; a.cout = g->cout; a.mpad = plan->mpad; a.kpad = plan->kpad;
   a.Di = g->in[0]; a.Hi = g->in[1]; a.Wi = g->in[2];
   a.Do = g->out[0]; a.Ho = g->out[1]; a.Wo = g->out[2];
@@ -1195,7 +1207,7 @@ static int conv_forward_impl(const eco_conv_geom* g, const eco_conv_plan* plan, 
     return !v.ptr || (((uintptr_t)v.ptr & 15) == 0 && v.stride_b % 4 == 0 && v.stride_t % 4 == 0 && v.stride_c % 4 == 0);
   };
   const bool vec4 = a.s_out % 4 == 0 && (!a.dmajor || (a.Ho * a.Wo) % 4 == 0) && a.n_split0 % 4 == 0 && (a.ntot - a.n_split0) % 4 == 0 &&
-                    ((uintptr_t)a.ws & 15) == 0 && vec_ok(a.residual) && vec_ok(a.raw) && vec_ok(a.act);
+                    ((uintptr_t)a.ws & 15) == 0 && vec_ok(a.residual) && vec_ok(a.raw) && vec_ok(a.act) && vec_ok(a.act2);
   long rblocks = ceil_div((long)a.cout * (a.ntot - a.n_split0), 256L * (vec4 ? 4 : 1));
   if (rblocks > 262144) rblocks = 262144;
   if (vec4)

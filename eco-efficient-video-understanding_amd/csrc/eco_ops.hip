@@ -254,24 +254,28 @@ constexpr int kTailOutPerBlock = 128;
 // grid = (ceil(n_out / 128), b), 1024 threads.  Each workgroup pools its clip's C channels into LDS
 // (one wave per channel, two channels in flight per wave, 64-lane butterfly reduce), then its 16 waves
 // produce 128 logits (one wave per logit: lanes stride over C, butterfly reduce).
+// `t` > 1: the clip's volume is spread over t consecutive images of c x s each (a 2-D stream's frames,
+// x[b*t + f][c][s]) and the mean runs over all t*s values of a channel: 2-D global pool + segment consensus.
 __global__ __launch_bounds__(1024) void global_avgpool_fc_kernel(const float* x, const float* w, const float* bias,
-                                                                 float* y, int c, int s, int n_out, int wk, int c0,
-                                                                 int accumulate) {
+                                                                 float* y, int c, int s, int t, int n_out, int wk,
+                                                                 int c0, int accumulate) {
   __shared__ float pooled[kTailMaxC];
   constexpr int kWaves = kTailThreads / kWave;
   const int lane = lane_id();
   const int wave = uniform((int)(threadIdx.x >> 6));
   const int b = (int)blockIdx.y;
-  const float* xb = x + (long)b * c * s;
-  const float inv = 1.0f / (float)s;
+  const float* xb = x + (long)b * t * c * s;
+  const float inv = 1.0f / ((float)s * (float)t);
+  const long fstride = (long)c * s;
   for (int ch = wave; ch < c; ch += 2 * kWaves) {
     const int ch2 = ch + kWaves;
     const float* xp = xb + (long)ch * s;
     const float* xq = xb + (long)(ch2 < c ? ch2 : ch) * s;
     float a0 = 0.0f, a1 = 0.0f;
-    for (int i = lane; i < s; i += kWave) {
-      a0 += ld(xp + i);
-      a1 += ld(xq + i);
+    for (int i = lane; i < s * t; i += kWave) {
+      const int f = i / s, r = i - f * s;
+      a0 += ld(xp + f * fstride + r);
+      a1 += ld(xq + f * fstride + r);
     }
     a0 = wave_sum(a0);
     a1 = wave_sum(a1);
@@ -559,16 +563,22 @@ extern "C" int eco_inner_product_forward(const float* x, const float* w, const f
 extern "C" int eco_global_avgpool_fc_forward(const float* x, const float* w, const float* bias, float* y, int64_t b,
                                              int64_t c, int64_t s, int64_t n_out, int64_t wk, int64_t c0,
                                              int accumulate, void* stream) {
+  return eco_global_avgpool_fc_seg_forward(x, w, bias, y, b, 1, c, s, n_out, wk, c0, accumulate, stream);
+}
+
+extern "C" int eco_global_avgpool_fc_seg_forward(const float* x, const float* w, const float* bias, float* y, int64_t b,
+                                                 int64_t t, int64_t c, int64_t s, int64_t n_out, int64_t wk, int64_t c0,
+                                                 int accumulate, void* stream) {
   clear_error();
   ECO_REQUIRE(x && w && y, "global_avgpool_fc: null argument");
-  ECO_REQUIRE(b > 0 && c > 0 && s > 0 && n_out > 0, "global_avgpool_fc: bad shape");
+  ECO_REQUIRE(b > 0 && c > 0 && s > 0 && n_out > 0 && t > 0 && s * t < 2147483647l, "global_avgpool_fc: bad shape");
   ECO_REQUIRE(c <= kTailMaxC, "global_avgpool_fc: %ld channels exceed the %d-channel LDS buffer", (long)c, kTailMaxC);
   ECO_REQUIRE(c0 >= 0 && c0 + c <= wk, "global_avgpool_fc: weight columns [%ld,%ld) outside row length %ld", (long)c0,
               (long)(c0 + c), (long)wk);
   ECO_REQUIRE(b <= 65535 && s < 2147483647l, "global_avgpool_fc: batch too large for one launch");
   dim3 grid((unsigned)ceil_div(n_out, kTailOutPerBlock), (unsigned)b);
   hipLaunchKernelGGL((global_avgpool_fc_kernel), grid, dim3(kTailThreads), 0, (hipStream_t)stream, x, w, bias, y, (int)c,
-                     (int)s, (int)n_out, (int)wk, (int)c0, accumulate);
+                     (int)s, (int)t, (int)n_out, (int)wk, (int)c0, accumulate);
   return check_launch("eco_global_avgpool_fc_forward");
 }
 

@@ -118,7 +118,7 @@ struct WinoOutArgs {
   const float* bias;
   const float* bn_scale;
   const float* bn_shift;
-  eco_view residual, raw, act;
+  eco_view residual, raw, act, act2;
   int relu;
   int n, cout, D, H, W, TH, TW;
 };
@@ -161,6 +161,7 @@ __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const WinoOut
     const long o_res = a.residual.ptr ? view_base(a.residual, img, 0) + (long)ch * a.residual.stride_c : 0;
     const long o_raw = a.raw.ptr ? view_base(a.raw, img, 0) + (long)ch * a.raw.stride_c : 0;
     const long o_act = a.act.ptr ? view_base(a.act, img, 0) + (long)ch * a.act.stride_c : 0;
+    const long o_act2 = a.act2.ptr ? view_base(a.act2, img, 0) + (long)ch * a.act2.stride_c : 0;
 #pragma unroll
     for (int p = 0; p < M; ++p) {
       const int h = M * th + p;
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const WinoOut
             ((float*)&ov)[e] = o;
           }
           st((vec_t*)(a.act.ptr + o_act + sp), ov);
+          if (a.act2.ptr) st((vec_t*)(a.act2.ptr + o_act2 + sp), ov);
         }
       }
     }
@@ -277,12 +279,13 @@ extern "C" int eco_wino_output_forward(const float* m, int32_t n, int32_t cout, 
   ECO_REQUIRE(tile_m == 2 || tile_m == 4, "winograd: output tile must be 2 or 4, got %d", tile_m);
   ECO_REQUIRE(ep->raw.ptr || ep->act.ptr, "winograd output transform: at least one of raw/act outputs is required");
   ECO_REQUIRE(!ep->bn_scale == !ep->bn_shift, "winograd output transform: bn_scale and bn_shift must be given together");
-  const eco_view* views[3] = {&ep->residual, &ep->raw, &ep->act};
+  ECO_REQUIRE(!ep->act2.ptr || ep->act.ptr, "winograd output transform: act2 needs act");
+  const eco_view* views[4] = {&ep->residual, &ep->raw, &ep->act, &ep->act2};
   for (const eco_view* v : views)
     ECO_REQUIRE(!v->ptr || (v->t >= 1 && v->stride_c >= 1), "winograd output transform: view needs t >= 1 and stride_c >= 1");
   WinoOutArgs a;
   a.m = m; a.bias = ep->bias; a.bn_scale = ep->bn_scale; a.bn_shift = ep->bn_shift;
-  a.residual = ep->residual; a.raw = ep->raw; a.act = ep->act; a.relu = ep->relu;
+  a.residual = ep->residual; a.raw = ep->raw; a.act = ep->act; a.act2 = ep->act2; a.relu = ep->relu;
   a.n = n; a.cout = cout; a.D = d; a.H = h; a.W = w;
   a.TH = (h + tile_m - 1) / tile_m; a.TW = (w + tile_m - 1) / tile_m;
   const long tiles = (long)n * cout * d * a.TH * a.TW;
@@ -293,7 +296,7 @@ extern "C" int eco_wino_output_forward(const float* m, int32_t n, int32_t cout, 
     while (vec > 1 && (((uintptr_t)v.ptr % (4 * vec)) || v.stride_b % vec || v.stride_t % vec || v.stride_c % vec)) vec /= 2;
   };
   while (vec > 1 && w % vec) vec /= 2;
-  limit(a.residual); limit(a.raw); limit(a.act);
+  limit(a.residual); limit(a.raw); limit(a.act); limit(a.act2);
   const dim3 grid(wino_grid(tiles)), block(kWinoThreads);
   hipStream_t st_ = (hipStream_t)stream;
   if (tile_m == 2) {

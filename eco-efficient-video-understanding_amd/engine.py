@@ -691,7 +691,8 @@ class Engine:
                 continue
             if L.type == "Convolution":
                 self._fuse_conv(i, L, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed, concat_skip)
-            elif L.type == "Pooling" and self._try_fuse_tail(i, L, layers, sole_consumer, absorbed):
+            elif L.type == "Pooling" and (self._try_fuse_tail(i, L, layers, sole_consumer, absorbed) or
+                                          self._try_fuse_two_stream_tail(i, L, layers, absorbed)):
                 pass
             elif L.type == "Concat":
                 if L.tops[0] not in self.tensors:
@@ -752,6 +753,13 @@ class Engine:
             if dest is None:
                 self._materialize(act_blob, L.top_shapes[0])
                 ep.act = self._view(act_blob, cout, S)
+                # a blob with several consumers, one of them r2Dto3D + Permute (ECO-Full feeds
+                # inception_3c_double_3x3_1_bn to its 2-D stream AND to the 3-D trunk): second destination
+                second = self._permuted_destination(act_blob, L, layers, consumers, outputs, absorbed, sole=False)
+                if second is not None:
+                    ep.act2 = second
+                    label += "+" + "+".join(layers[c].name for c, v in absorbed.items()
+                                            if v == L.name and layers[c].type in ("Reshape", "Permute"))
             else:
                 ep.act = dest
         self._emit_conv(i, L, ep, label)
@@ -780,22 +788,39 @@ class Engine:
             self.fused_away[act_blob] = f"written directly into channels [{c0},{c0 + cout}) of {Lc.tops[0]}"
             return self._view(Lc.tops[0], cout, S, c0, ctot)
         # (b) r2Dto3D Reshape [-1,T,C,H,W] followed by Permute [0,2,1,3,4]
-        if Lc.type == "Reshape" and len(tshape) == 4 and len(Lc.top_shapes[0]) == 5:
+        return self._permuted_destination(act_blob, L, layers, consumers, outputs, absorbed, sole=True)
+
+    def _permuted_destination(self, act_blob, L, layers, consumers, outputs, absorbed, sole: bool):
+        """View that writes a conv's [B*T,C,H,W] output through r2Dto3D (Reshape [-1,T,C,H,W]) + Permute
+        [0,2,1,3,4] straight into the [B,C,T,H,W] volume (reshape_layer.cpp:88, permute_layer.cpp:9-26), or None.
+        sole=True: the Reshape is the blob's only consumer (the blob itself is then never stored); sole=False: it
+        is one of several (the view becomes the epilogue's second destination)."""
+        tshape = L.top_shapes[0]
+        S = _prod(tshape[2:])
+        cs = [c for c in consumers.get(act_blob, []) if absorbed.get(c) != L.name]
+        if act_blob in outputs or len(tshape) != 4 or (sole and len(cs) != 1) or (not sole and len(cs) < 2):
+            return None
+        for ci in cs:
+            Lc = layers[ci]
+            if Lc.type != "Reshape" or len(Lc.top_shapes[0]) != 5:
+                continue
             rs = Lc.top_shapes[0]
             if tuple(rs[2:]) != tuple(tshape[1:]):
-                return None
+                continue
             pcs = consumers.get(Lc.tops[0], [])
             if len(pcs) != 1 or Lc.tops[0] in outputs:
-                return None
+                continue
             Lp = layers[pcs[0]]
             if Lp.type != "Permute" or list(Lp.geom["order"]) != [0, 2, 1, 3, 4]:
-                return None
+                continue
             T, Cc = rs[1], rs[2]
             self._materialize(Lp.tops[0], Lp.top_shapes[0])
-            absorbed[cs[0]] = L.name
+            absorbed[ci] = L.name
             absorbed[pcs[0]] = L.name
-            self.fused_away[act_blob] = f"written through {Lc.name}+{Lp.name} directly into {Lp.tops[0]}"
-            self.fused_away[Lc.tops[0]] = self.fused_away[act_blob]
+            why = f"written through {Lc.name}+{Lp.name} directly into {Lp.tops[0]}"
+            if sole:
+                self.fused_away[act_blob] = why
+            self.fused_away[Lc.tops[0]] = why
             return hip.View(self._ptr(Lp.tops[0]), (Cc // self.cblk) * T * S, S, T * S, T)
         return None
 
@@ -845,6 +870,101 @@ class Engine:
                   lib.global_avgpool_fc_forward(x, w, bias, y, B, Cc, S, n_out, Cc, 0, False, s),
                   {"kernel": "eco::global_avgpool_fc_kernel", "flops": 2 * B * n_out * Cc,
                    "bytes": 4 * (B * Cc * S + n_out * Cc + B * n_out)})
+        return True
+
+    def _try_fuse_two_stream_tail(self, i, L, layers, absorbed) -> bool:
+        """ECO-Full's tail (models_ECO_Full/kinetics/deploy.prototxt:4607-4690) as two launches:
+
+            2-D stream: global_pool2D (AVE over the whole h x w plane of [B*T,C2,h,w]) -> dropout -> reshape
+                        [-1,1,T,C2] -> segment_consensus (AVE, kernel (T,1)) -> reshape [-1,C2]        \
+            3-D stream: global_pool (AVE over the whole d x h x w volume of [B,C3,...]) -> reshape -> dropout -> Concat -> fc
+
+        = fc over [mean_{t,h,w} x2d | mean_{d,h,w} x3d]: one pool+fc launch per stream on its columns of the fc
+        weights, the second accumulating into the logits.  Matched from the 2-D pool; every blob in between must
+        have no other consumer."""
+        spec = self.spec
+        g, b = L.geom, L.bottom_shapes[0]
+        if self.dt or len(b) != 4 or g["method"] != "AVE" or list(g["kernel"]) != list(b[2:]) or \
+                any(p != 0 for p in g["pad"]) or any(o != 1 for o in L.top_shapes[0][2:]):
+            return False
+        chain: List[int] = []
+
+        def only_next(blob: str, typ: str) -> Optional[int]:
+            """The single non-Dropout consumer of `blob` if it has type `typ` (in-place Dropouts are absorbed)."""
+            cs = self._consumers_of(blob)
+            drops = [c for c in cs if layers[c].type == "Dropout" and layers[c].inplace]
+            rest = [c for c in cs if c not in drops]
+            if len(rest) != 1 or layers[rest[0]].type != typ or blob in spec.outputs:
+                return None
+            chain.extend(drops)
+            return rest[0]
+
+        r1 = only_next(L.tops[0], "Reshape")
+        if r1 is None:
+            return False
+        shp = layers[r1].top_shapes[0]
+        if len(shp) != 4 or shp[1] != 1 or shp[3] != b[1] or shp[0] * shp[2] != b[0]:
+            return False
+        B, T, C2 = shp[0], shp[2], b[1]
+        p2 = only_next(layers[r1].tops[0], "Pooling")
+        if p2 is None:
+            return False
+        Lp2 = layers[p2]
+        if Lp2.geom["method"] != "AVE" or list(Lp2.geom["kernel"]) != [T, 1] or any(x != 0 for x in Lp2.geom["pad"]) or \
+                tuple(Lp2.top_shapes[0]) != (B, 1, 1, C2):
+            return False
+        r2 = only_next(Lp2.tops[0], "Reshape")
+        if r2 is None or tuple(layers[r2].top_shapes[0]) != (B, C2):
+            return False
+        cat = only_next(layers[r2].tops[0], "Concat")
+        if cat is None:
+            return False
+        Lcat = layers[cat]
+        srcs = [self._resolve(x) for x in Lcat.bottoms]
+        if Lcat.geom["axis"] != 1 or len(srcs) != 2 or srcs[0] != layers[r2].tops[0]:
+            return False
+        # the other operand: Reshape [B,C3] of a whole-volume AVE pool
+        prod = [k for k, Lk in enumerate(layers) if srcs[1] in Lk.tops and not Lk.inplace]
+        if len(prod) != 1 or layers[prod[0]].type != "Reshape":
+            return False
+        r3 = prod[0]
+        pp = [k for k, Lk in enumerate(layers) if self._resolve(layers[r3].bottoms[0]) in Lk.tops and not Lk.inplace]
+        if len(pp) != 1 or layers[pp[0]].type != "Pooling":
+            return False
+        p3 = pp[0]
+        Lp3 = layers[p3]
+        b3 = Lp3.bottom_shapes[0]
+        if Lp3.geom["method"] != "AVE" or list(Lp3.geom["kernel"]) != list(b3[2:]) or any(x != 0 for x in Lp3.geom["pad"]) or \
+                b3[0] != B or tuple(layers[r3].top_shapes[0]) != (B, b3[1]) or self._resolve(Lp3.bottoms[0]) not in self.tensors:
+            return False
+        C3 = b3[1]
+        if only_next(Lp3.tops[0], "Reshape") != r3 or only_next(layers[r3].tops[0], "Concat") != cat:
+            return False
+        fc = only_next(Lcat.tops[0], "InnerProduct")
+        if fc is None:
+            return False
+        Lf = layers[fc]
+        if Lf.geom["K"] != C2 + C3 or Lf.geom["M"] != B:
+            return False
+        if any(c <= i for c in (r1, p2, r2, cat, r3, p3, fc) if c != i and c < i):
+            return False
+        for c in chain + [r1, p2, r2, cat, r3, p3, fc]:
+            absorbed[c] = L.name
+        for c in (i, r1, p2, r2, cat, r3, p3):
+            for nm in layers[c].tops:
+                self.fused_away[nm] = f"only exists inside the fused two-stream tail {L.name}+{Lp3.name}+{Lf.name}"
+        self._materialize(Lf.tops[0], Lf.top_shapes[0], plain=True)
+        x2, x3, y = self._ptr(L.bottoms[0]), self._ptr(Lp3.bottoms[0]), self._ptr(Lf.tops[0])
+        w = self._pdev(Lf.name, "w")
+        bias = self._pdev(Lf.name, "bias") if Lf.geom["bias_term"] else None
+        S2, S3, n_out, wk = _prod(b[2:]), _prod(b3[2:]), Lf.geom["num_output"], C2 + C3
+        lib = self.lib
+        self._add(i, f"{Lp3.name}+{Lf.name} [3-D stream]", lambda s: lib.global_avgpool_fc_seg_forward(
+            x3, w, bias, y, B, 1, C3, S3, n_out, wk, C2, False, s),
+            {"kernel": "eco::global_avgpool_fc_kernel", "flops": 2 * B * n_out * C3, "bytes": 4 * (B * C3 * S3 + n_out * C3 + B * n_out)})
+        self._add(i, f"{L.name}+{Lp2.name}+{Lf.name} [2-D stream, accumulate]", lambda s: lib.global_avgpool_fc_seg_forward(
+            x2, w, None, y, B, T, C2, S2, n_out, wk, 0, True, s),
+            {"kernel": "eco::global_avgpool_fc_kernel", "flops": 2 * B * n_out * C2, "bytes": 4 * (B * T * C2 * S2 + n_out * C2 + 2 * B * n_out)})
         return True
 
     def _consumers_of(self, blob: str) -> List[int]:

@@ -21,7 +21,7 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 DT_BF16 = 1
 DT_F32X3 = 3
 
@@ -64,7 +64,7 @@ class View(C.Structure):
 class ConvEpilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("residual", View), ("raw", View),
                 ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p),
-                ("relu", C.c_int32), ("act", View)]
+                ("relu", C.c_int32), ("act", View), ("act2", View)]
 
 
 class PoolGeom(C.Structure):
@@ -170,6 +170,9 @@ _SIGNATURES = {
                                             C.c_int64, C.c_void_p]),
     "eco_global_avgpool_fc_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                                 C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    "eco_global_avgpool_fc_seg_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                                    C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
+                                                    C.c_void_p]),
     "eco_video_input_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_float, C.c_int32, C.c_void_p]),
     "eco_softmax_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
@@ -322,6 +325,10 @@ class EcoLib:
     def global_avgpool_fc_forward(self, x, w, bias, y, b, c, s, n_out, wk, c0=0, accumulate=False, stream=None) -> None:
         self._check(self._dll.eco_global_avgpool_fc_forward(x, w, bias, y, b, c, s, n_out, wk, c0,
                                                             int(accumulate), stream))
+
+    def global_avgpool_fc_seg_forward(self, x, w, bias, y, b, t, c, s, n_out, wk, c0=0, accumulate=False, stream=None) -> None:
+        self._check(self._dll.eco_global_avgpool_fc_seg_forward(x, w, bias, y, b, t, c, s, n_out, wk, c0,
+                                                                int(accumulate), stream))
 
     def video_input_forward(self, frames, y, num_frames, height, width, crop_h, crop_w, h_off, w_off, mean, scale=1.0,
                             mirror=False, stream=None) -> None:

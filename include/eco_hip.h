@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 9
+#define ECO_ABI_VERSION 10
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -116,8 +116,12 @@ typedef struct eco_view {
  *                                       shift=beta-mean*scale; bn_layer.cpp:93-207,
  *                                       same algebra as python/gen_bn_inference.py:121-134)
  *   act(img,c,sp) = relu ? max(a,0) : a   (layers/relu_layer.cpp:10-20)
- * Any of bias / residual.ptr / raw.ptr / act.ptr may be NULL (that step is skipped);
- * bn_scale==NULL means a = v.  At least one of raw.ptr / act.ptr must be non-NULL. */
+ *   act2(img,c,sp) = the same value       (a second destination of the activated output: the blob feeds both
+ *                                          a 2-D consumer and, through r2Dto3D + Permute, the 3-D trunk --
+ *                                          inception_3c_double_3x3_1_bn of ECO-Full,
+ *                                          models_ECO_Full/kinetics/deploy.prototxt:1835-1870)
+ * Any of bias / residual.ptr / raw.ptr / act.ptr / act2.ptr may be NULL (that step is skipped);
+ * bn_scale==NULL means a = v.  At least one of raw.ptr / act.ptr must be non-NULL; act2 needs act. */
 typedef struct eco_conv_epilogue {
   const float* bias;
   eco_view residual; /* read-only */
@@ -126,6 +130,7 @@ typedef struct eco_conv_epilogue {
   const float* bn_shift;
   int32_t relu;
   eco_view act;
+  eco_view act2;
 } eco_conv_epilogue;
 
 /* Validates `g` (fills nothing) and chooses the tiling for the calling thread's current device (its
@@ -222,6 +227,14 @@ int eco_inner_product_forward(const float* x, const float* w, const float* bias,
 int eco_global_avgpool_fc_forward(const float* x, const float* w, const float* bias, float* y,
                                   int64_t b, int64_t c, int64_t s, int64_t n_out, int64_t wk,
                                   int64_t c0, int accumulate, void* stream);
+/* The same with the clip's features spread over t consecutive images, x[b*t + f][c][s]: the mean runs over the
+ * t*s values of a channel.  That is ECO-Full's 2-D stream tail in one launch -- global_pool2D (AVE over the
+ * 7x7 plane) -> dropout -> reshape [-1,1,T,C] -> segment_consensus (AVE over T) -> reshape -> its columns of
+ * fc8N (models_ECO_Full/kinetics/deploy.prototxt:4607-4690); with accumulate it adds into the logits the 3-D
+ * stream's call left in y. */
+int eco_global_avgpool_fc_seg_forward(const float* x, const float* w, const float* bias, float* y,
+                                      int64_t b, int64_t t, int64_t c, int64_t s, int64_t n_out, int64_t wk,
+                                      int64_t c0, int accumulate, void* stream);
 /* GPU-side input stage = the VideoData TEST-phase output contract
  * (layers/video_data_layer.cpp:107-119, util/io.cpp:368-421 ReadSegmentRGBToDatum, DataTransformer::Transform
  * data_transformer.cpp:147-330): decoded frames arrive as uint8 H x W x 3 interleaved (OpenCV BGR order, channel
