@@ -587,6 +587,176 @@ __global__ __launch_bounds__(256, 2) void convb_dma_kernel(const ConvBArgs a, co
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Span form of the LDS-DMA kernel for stride-1 same-size (kd)x3x3 convolutions (the nine stride-1 trunk convs,
+// conv2_3x3 and the inception 3x3 convs: 85 % of ECO-Lite's flops).
+//
+// Measured on the per-tap kernel above: every layer, whatever its shape, ran at 9-11 TB/s of global -> LDS DMA
+// traffic -- 24 KB per stage of 32 k (128x256 / 256x128 tile), 27 stages per 32 input channels -- i.e. at the
+// rate the L1/L2 path delivers operands, ~36 % of the bf16 MFMA peak.  For a stride-1 same-size conv the nine
+// in-plane taps of a channel group read the SAME positions shifted by (y-1)*W + (x-1), so here a workgroup
+// stages, per group (32 channels, depth tap z), the span of BN + 2*(W+1) consecutive positions ONCE (20-24 KB)
+// and the nine taps read their B fragments from it at an LDS offset; zero padding inside the plane is a 9-bit
+// per-lane mask applied to the fragment (four v_cndmask), a whole plane outside the volume is a zero-page DMA.
+// Position-operand traffic drops ~7x, total DMA bytes per MFMA 2.3x; what remains is the weight stream
+// (BMP x 64 B per tap), which is why every plan of this kernel uses 256-position tiles.
+// Pipeline: weights per tap in three buffers exactly as above; the span of group g+1 is issued at the first tap of
+// group g (after its barrier) into the other span buffer and is retired, in order, by the wait of tap 2.
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, const uint4* zero_page, int span_pieces) {
+  constexpr int BM = 32 * TM * WM;
+  constexpr int BN = 32 * TN * WN;
+  constexpr int BMP = (BM + 63) / 64 * 64;
+  static_assert(WM * WN == 4 && BN == 256, "");
+  constexpr int A_PER_WAVE = kCbs * BMP / 64 / 4;
+  constexpr int T2 = 9;
+
+  ECO_DYNAMIC_LDS(lds_f);
+  const int SPAN = span_pieces * 64;
+  uint4* const Aw = (uint4*)lds_f;              // [3][kCbs][BMP]
+  uint4* const Bsp = Aw + 3 * kCbs * BMP;       // [2][kCbs][SPAN]
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int ntiles = a.nblk_m * a.nblk_n;
+  const int slice = (int)blockIdx.x / ntiles;
+  const int tile = xcd_remap((int)blockIdx.x - slice * ntiles, ntiles);
+  const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
+  const int m0 = mblk * BM, n0 = nblk * BN;
+  const int ngroups = (a.nstages / a.taps) * a.kd;          // (channel group, depth tap)
+  const int g_begin = (int)((long)slice * ngroups / a.ksplit);
+  const int g_end = (int)((long)(slice + 1) * ngroups / a.ksplit);
+  const int hw = a.Hi * a.Wi, halo = a.Wi + 1;
+
+  // ---- span elements staged by this lane: chunks `wave` and `wave + 4` of the span, element = chunk*64 + lane ----
+  const int nchunks = (span_pieces - wave + 3) / 4;          // 1 or 2 (span_pieces <= 8), wave-uniform
+  long sp_base[2];
+  int sp_d[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int v = n0 - halo + (wave + 4 * c) * 64 + lane;    // flattened (img, d, h, w) index of the centre tap
+    sp_base[c] = 0;
+    sp_d[c] = -(1 << 20);                                      // never a valid depth whatever z is added
+    if (v >= 0 && v < a.ntot) {
+      const int img = v / a.s_out, sp = v - img * a.s_out;
+      sp_base[c] = (long)img * a.img_stride_in + sp;
+      sp_d[c] = sp / hw;
+    }
+  }
+  const uint4* const xv = (const uint4*)a.x;
+  const long zoff = (long)(((intptr_t)zero_page - (intptr_t)xv) / 16);
+
+  // ---- in-plane tap masks of this lane's TN fragment positions: bit y*3 + x ----
+  unsigned fmask[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    fmask[j] = 0u;
+    const int n = n0 + (wn * TN + j) * 32 + l31;
+    if (n < a.ntot) {
+      const int r = (n % a.s_out) % hw, h = r / a.Wi, w = r - h * a.Wi;
+      unsigned mw_ = 0u;
+      for (int xx = 0; xx < 3; ++xx) mw_ |= (unsigned)((unsigned)(w - 1 + xx) < (unsigned)a.Wi) << xx;
+      for (int y = 0; y < 3; ++y)
+        if ((unsigned)(h - 1 + y) < (unsigned)a.Hi) fmask[j] |= mw_ << (3 * y);
+    }
+  }
+
+  auto issue_span = [&](int g, int sbuf) {   // group g = cg * kd + z
+    const int cg = g / a.kd, z = g - cg * a.kd;
+    const long shift = (long)(z - a.pd) * hw;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c < nchunks) {
+        long sel = -(long)((unsigned)(sp_d[c] + z - a.pd) < (unsigned)a.Di);
+        ECO_OPAQUE64(sel);
+#pragma unroll
+        for (int kb = 0; kb < kCbs; ++kb) {
+          const int cb = min(cg * kCbs + kb, a.cblocks - 1);
+          const long real = sp_base[c] + shift + (long)cb * a.cb_stride_in;
+          glds16(xv + (zoff ^ ((zoff ^ real) & sel)), Bsp + (sbuf * kCbs + kb) * SPAN + (wave + 4 * c) * 64);
+        }
+      }
+    }
+  };
+  auto issue_weights = [&](int g, int t2, int abuf) {
+    const int cg = g / a.kd, z = g - cg * a.kd;
+    const long stage = (long)cg * a.taps + z * T2 + t2;
+#pragma unroll
+    for (int q = 0; q < A_PER_WAVE; ++q) {
+      const int piece = wave + 4 * q;
+      const int row = piece / (BMP / 64), mc = piece % (BMP / 64);
+      glds16(a.wp + (stage * kCbs + row) * a.mpad + m0 + mc * 64 + lane, Aw + (abuf * kCbs + row) * BMP + mc * 64);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int total = (g_end - g_begin) * T2;   // flat tap stages of this slice
+  if (total > 0) {
+    issue_span(g_begin, 0);
+    issue_weights(g_begin, 0, 0);
+    if (total > 1) issue_weights(g_begin, 1, 1);
+    int abuf = 0;
+    for (int g = g_begin; g < g_end; ++g) {
+      const int sbuf = (g - g_begin) & 1;
+      const bool next_group = g + 1 < g_end;
+#pragma unroll 1
+      for (int t2 = 0; t2 < T2; ++t2) {
+        const int s = (g - g_begin) * T2 + t2;
+        // pieces of this wave that may still be in flight once this tap's weights have landed: the next tap's
+        // weights and, at tap 1, the span issued at tap 0
+        if (s + 1 >= total) wait_dma_all_but<0>();
+        else if (t2 == 1 && next_group) { if (nchunks == 2) wait_dma_all_but<A_PER_WAVE + 2 * kCbs>(); else wait_dma_all_but<A_PER_WAVE + kCbs>(); }
+        else wait_dma_all_but<A_PER_WAVE>();
+        wg_barrier_nodrain();
+        if (t2 == 0 && next_group) issue_span(g + 1, sbuf ^ 1);
+        if (s + 2 < total) {
+          const int t2n = t2 + 2 < T2 ? t2 + 2 : t2 + 2 - T2;
+          issue_weights(t2 + 2 < T2 ? g : g + 1, t2n, abuf == 0 ? 2 : abuf - 1);   // (abuf + 2) % 3
+        }
+        sched_fence();
+        const int y = t2 / 3, xx = t2 - 3 * y;
+        const int toff = halo + (y - 1) * a.Wi + (xx - 1);
+        unsigned okm[TN];   // all-ones where this tap is inside the plane (an AND per dword: no exec-masked reads)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) okm[j] = 0u - ((fmask[j] >> t2) & 1u);
+        const uint4* Ab = Aw + abuf * kCbs * BMP;
+        const uint4* Bb = Bsp + sbuf * kCbs * SPAN + toff;
+#pragma unroll
+        for (int ks = 0; ks < kCbs / 2; ++ks) {
+          uint4 af[TM], bf[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[i] = Ab[(2 * ks + half) * BMP + (wm * TM + i) * 32 + l31];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const uint4 q = Bb[(2 * ks + half) * SPAN + (wn * TN + j) * 32 + l31];
+            bf[j] = make_uint4(q.x & okm[j], q.y & okm[j], q.z & okm[j], q.w & okm[j]);
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
+        }
+        abuf = abuf == 2 ? 0 : abuf + 1;
+      }
+    }
+  }
+  if (a.ksplit > 1)
+    convb_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+  else
+    convb_epilogue<TM, TN, 1>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Stem input: fp32 N,3,H,W (the `data` blob, VideoData contract) -> zero-padded pixel-interleaved image
 //   P[f][h + 3][w + 3][4] (channel 3 = 0), rows of W + 8 pixels, H + 6 rows
 // in the path's storage type.  For conv1_7x7_s2 (stride 2, pad 3) the seven taps of kernel row ky of output
@@ -831,6 +1001,20 @@ extern "C" int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t
     else if (bm == 128 && ntot >= 8192) plan->bn = 256;
   }
   plan->dt = dt;
+  plan->span_pieces = 0;
+  if (ns == 1 && !is_stem(g)) {
+    // stride-1 same-size (kd)x3x3: the span kernel (256-position tiles; the span of BN + 2*(W+1) positions in at
+    // most eight 64-position DMA pieces)
+    bool span = g->kernel[1] == 3 && g->kernel[2] == 3 && g->pad[1] == 1 && g->pad[2] == 1 &&
+                (g->kernel[0] == 1 || g->kernel[0] == 3) && g->pad[0] == g->kernel[0] / 2;
+    for (int i = 0; i < 3; ++i) span = span && g->stride[i] == 1 && g->out[i] == g->in[i];
+    const int pieces = (int)ceil_div(256 + 2 * (g->in[2] + 1), 64);
+    if (span && pieces <= 8 && ntot >= 2048) {
+      plan->span_pieces = pieces;
+      if (bm == 256) plan->bm = bm = 128;   // the weight stream per MFMA depends on BN only: keep 256 positions
+      plan->bn = 256;
+    }
+  }
   plan->stem = is_stem(g) ? 1 : 0;
   plan->cblocks = plan->stem ? 4 : g->cin / 8;
   const int taps = plan->stem ? 7 : g->kernel[0] * g->kernel[1] * g->kernel[2];
@@ -848,6 +1032,7 @@ extern "C" int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t
     long sp = slots / tiles;
     if (sp > 8) sp = 8;
     if (sp > plan->nstages / 4) sp = plan->nstages / 4;
+    if (plan->span_pieces && sp > plan->nstages / 9) sp = plan->nstages / 9;   // the span kernel splits whole groups
     if (sp >= 2) {
       plan->ksplit = (int)sp;
       plan->ws_bytes = (int64_t)sp * g->cout * ntot * 4;
@@ -926,6 +1111,29 @@ static int launch_convb_dma(const ConvBArgs& a, hipStream_t stream) {
 }
 
 template <int TM, int TN, int WM, int WN>
+static int launch_convb_span(const ConvBArgs& a, int span_pieces, hipStream_t stream) {
+  constexpr int BM = 32 * TM * WM, BMP = (BM + 63) / 64 * 64;
+  const uint4* zp = device_zero_page();
+  if (!zp) return fail(ECO_ERR_RUNTIME, "convb: cannot allocate the zero page");
+  ECO_REQUIRE((((uintptr_t)a.x | (uintptr_t)a.wp) & 15) == 0, "convb: input and packed weights must be 16-byte aligned");
+  const int grid = a.nblk_m * a.nblk_n * a.ksplit;
+  const size_t lds = (size_t)(3 * kCbs * BMP + 2 * kCbs * span_pieces * 64) * 16;
+#ifndef ECO_EMU
+  if (lds > 64 * 1024) {
+    static thread_local bool raised = false;
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute((const void*)convb_span_kernel<TM, TN, WM, WN>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return fail(ECO_ERR_RUNTIME, "convb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+      raised = true;
+    }
+  }
+#endif
+  hipLaunchKernelGGL((convb_span_kernel<TM, TN, WM, WN>), dim3(grid), dim3(256), lds, stream, a, zp, span_pieces);
+  return check_launch("eco_convb_forward");
+}
+
+template <int TM, int TN, int WM, int WN>
 static int launch_convb(const ConvBArgs& a, int ns, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   const int grid = a.nblk_m * a.nblk_n * a.ksplit;
@@ -1000,6 +1208,21 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
   a.ws = (float*)workspace;
   hipStream_t s = (hipStream_t)stream;
   int rc;
+  if (plan->span_pieces) {
+    bool ok = ns == 1 && !plan->stem && plan->bn == 256 && g->kernel[1] == 3 && g->kernel[2] == 3 && g->pad[1] == 1 &&
+              g->pad[2] == 1 && (g->kernel[0] == 1 || g->kernel[0] == 3) && g->pad[0] == g->kernel[0] / 2 &&
+              plan->span_pieces * 64 >= 256 + 2 * (g->in[2] + 1) && plan->span_pieces <= 8 &&
+              plan->ksplit <= (plan->nstages / a.taps) * a.kd;
+    for (int i = 0; i < 3; ++i) ok = ok && g->stride[i] == 1 && g->out[i] == g->in[i];
+    ECO_REQUIRE(ok, "convb: the span kernel needs a bf16 stride-1 same-size (kd)x3x3 geometry");
+    switch (plan->bm) {
+      case 128: rc = launch_convb_span<4, 2, 1, 4>(a, plan->span_pieces, s); break;
+      case 96: rc = launch_convb_span<3, 2, 1, 4>(a, plan->span_pieces, s); break;
+      case 64: rc = launch_convb_span<2, 2, 1, 4>(a, plan->span_pieces, s); break;
+      case 32: rc = launch_convb_span<1, 2, 1, 4>(a, plan->span_pieces, s); break;
+      default: return fail(ECO_ERR_INVALID, "convb: unsupported span tile bm=%d", plan->bm);
+    }
+  } else
   switch (plan->bm) {
     case 256:
       ECO_REQUIRE(plan->bn == 128 && ns == 1, "convb: bad plan");

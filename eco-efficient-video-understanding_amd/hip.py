@@ -53,7 +53,7 @@ class ConvPlan(C.Structure):
 class ConvBPlan(C.Structure):
     _fields_ = [("bm", C.c_int32), ("bn", C.c_int32), ("dt", C.c_int32), ("stem", C.c_int32),
                 ("cblocks", C.c_int32), ("nstages", C.c_int32), ("mpad", C.c_int32), ("ksplit", C.c_int32),
-                ("wp_vecs", C.c_int64), ("ws_bytes", C.c_int64)]
+                ("span_pieces", C.c_int32), ("reserved", C.c_int32), ("wp_vecs", C.c_int64), ("ws_bytes", C.c_int64)]
 
 
 class View(C.Structure):
@@ -103,6 +103,9 @@ def conv_kernel_name(plan: ConvPlan) -> str:
 
 def convb_kernel_name(plan: "ConvBPlan") -> str:
     """Device kernel eco_convb_forward launches for this plan, as rocprofv3 prints it."""
+    if plan.dt == DT_BF16 and plan.span_pieces:
+        tm, tn, wm, wn = {128: (4, 2, 1, 4), 96: (3, 2, 1, 4), 64: (2, 2, 1, 4), 32: (1, 2, 1, 4)}[plan.bm]
+        return f"eco::convb_span_kernel<{tm}, {tn}, {wm}, {wn}>"
     if plan.dt == DT_BF16:   # LDS-DMA kernel
         tm, tn, wm, wn = {(256, 128): (4, 2, 2, 2), (128, 256): (4, 2, 1, 4)}.get((plan.bm, plan.bn)) or _CONV_TILES[(plan.bm, plan.bn)]
         return f"eco::convb_dma_kernel<{tm}, {tn}, {wm}, {wn}>"

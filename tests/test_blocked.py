@@ -202,6 +202,27 @@ def test_global_avgpool_fc_b(backend, dt):
     assert np.abs(backend.host(y, ref.shape) - ref).max() <= 1e-5 * np.abs(ref).max()
 
 
+SPANS = [  # n, cin, cout, in_sp, num_cu  (stride-1 same-size (kd)x3x3 with >= 2048 positions: bf16 takes the span kernel)
+    (2, 32, 64, (34, 34), 1),            # 2-D, one channel group, no split-K; last tile ragged
+    (1, 64, 128, (3, 26, 27), None),     # 3-D, two channel groups x three depth taps, split over groups
+    (1, 32, 96, (2, 33, 32), 1),         # bm = 96 (3x2 wave tiles), depth 2: both depth borders in one tile
+    (3, 40, 32, (28, 28), 1),            # cin = 40: zero-padded second channel group; three images per tile row
+]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("n,cin,cout,in_sp,num_cu", SPANS, ids=[f"s{i}" for i in range(len(SPANS))])
+def test_convb_span_kernel(backend, dt, n, cin, cout, in_sp, num_cu):
+    k = (3,) * len(in_sp)
+    plan = run_convb(backend, dt, n, cin, cout, in_sp, k, (1,) * len(in_sp), (1,) * len(in_sp), num_cu=num_cu, seed=3,
+                     residual=(cout == 128))
+    if dt == BF16:
+        assert plan.span_pieces == -(-(256 + 2 * (in_sp[-1] + 1)) // 64) and plan.bn == 256
+        assert (plan.ksplit > 1) == (num_cu is None)
+    else:
+        assert plan.span_pieces == 0
+
+
 def test_convb_rejects_unblocked_geometries(backend):
     g = hip.conv_geom(1, 20, 32, (4, 4), (1, 1), (1, 1), (0, 0), (4, 4))
     with pytest.raises(hip.EcoError, match="multiple of the 8-channel block"):
