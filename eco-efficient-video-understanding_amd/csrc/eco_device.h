@@ -75,7 +75,9 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return f32
 // own counting, and exactly one instruction is issued per call, whatever the lanes' addresses.
 __device__ __forceinline__ void glds16(const uint4* gptr, uint4* lds_wave_base) {
 #ifdef ECO_EMU
-  lds_wave_base[emu::tls_cur->lane] = emu::check_access(gptr, 16, false) ? *gptr : uint4{0u, 0u, 0u, 0u};
+  uint4 q = {0u, 0u, 0u, 0u};
+  if (emu::check_access(gptr, 16, false)) memcpy(&q, (const void*)gptr, 16);   // the source may be only 4-byte aligned
+  lds_wave_base[emu::tls_cur->lane] = q;
 #else
   const unsigned lds_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base;
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(gptr) : "memory", "m0");

@@ -1,0 +1,580 @@
+// eco_wgemm.hip -- the transformed-domain GEMMs of the Winograd F(4x4,3x3) route as a dedicated dense kernel.
+//
+// Round 1 ran the 36 point-convolutions M_p = U_p (*) V_p through the general gather kernel of eco_conv.hip
+// (per-position address decode, tap masks, 4-byte gathers, VGPR staging): 0.58-0.68 of the fp32 MFMA peak on the
+// 3-D trunk, 0.40-0.48 of their floor on the short-K 2-D layers -- 7.6 ms of an 18.1 ms step.  Between an input
+// transform and an output transform that this file owns as well, nothing forces that generality: the layouts of
+// V and M are free.  So
+//
+//   V[p][c/2][d'][r][c%2]     fp32, r = (b*TH + th)*TW + tw, d' = d + pd with an all-zero plane at either end
+//                             (kd = 3): channel PAIRS interleaved (one 8-byte LDS read feeds two MFMA k-steps),
+//                             positions depth-major, so that depth tap dz of channel pair cp is the SAME row
+//                             shifted by dz*NB positions -- a dense, contiguous operand with no padding logic
+//   U[p][mblock][stage][8][BMP][2]   stage = (16 input channels, depth tap); a stage's weights are one contiguous
+//                             block in HBM and in LDS
+//   M[p][slice][cout][d][r]   raw products, one row per output channel (lane = position: 128-byte stores)
+//
+// and the kernel is a plain batched GEMM: both operands go global -> LDS by LDS-DMA (16 bytes per lane, no VGPR
+// staging: the registers go to a 4x2 wave tile of 32x32 accumulators), three stage buffers with counted vmcnt
+// and a non-draining barrier exactly as eco_blocked.hip's bf16 kernels, k-pair fragments by ds_read_b64,
+// v_mfma_f32_32x32x2_f32.  Split-K slices are separate rows of M that the output transform sums while it reads
+// (no reduce launch).  Arithmetic is that of the round-1 route -- same products, fp32 accumulation; only the
+// summation order over (channel, depth tap) inside a point changes.
+//
+// Replaces cudnn_conv_layer.cu:15-65 / base_conv_layer.cpp:264-287 for the stride-1 3x3(x3) convolutions together
+// with eco_wino.hip's weight transform.
+#include <string.h>
+
+#include "eco_common.h"
+
+namespace eco {
+
+constexpr int kWgT = 6, kWgP = 36;   // F(4x4,3x3): 6x6 transform points
+constexpr int kWgKp = 8;             // k-pairs (16 reduction elements) per stage
+
+struct WGemmArgs {
+  const float* v;     // [P][cp][Q][2]
+  const float* u;     // [P][mblocks][nstages][8][bmp][2]
+  float* m;           // [P][ksplit][cout][ntot]
+  int cout, cp, kd, nstages, ksplit;
+  int Q, NB, ntot;    // row length / plane size / output positions (all in positions)
+  int mblocks, bmp, nblk_n;
+  long v_pstride, u_pstride, m_pstride;   // floats between points
+};
+
+// The three buffers of a stage: A [8][BMP][2], B [8][BN][2] floats.
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void wgemm_kernel(const WGemmArgs a) {
+  constexpr int BM = 32 * TM * WM;
+  constexpr int BN = 32 * TN * WN;
+  constexpr int BMP = (BM + 63) / 64 * 64;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(BN % 128 == 0, "");
+  constexpr int A_PER_WAVE = BMP / 64;            // 1 KB pieces of the weight block per wave (BMP/16 pieces over 4 waves)
+  constexpr int B_PER_WAVE = 2 * (BN / 128);      // 8 pair-rows x BN/128 pieces of 1 KB, two rows per wave
+  constexpr int P = A_PER_WAVE + B_PER_WAVE;
+  constexpr int A_VEC = kWgKp * BMP / 2;          // 16-byte vectors per stage buffer
+  constexpr int B_VEC = kWgKp * BN / 2;
+
+  ECO_DYNAMIC_LDS(lds_f);
+  uint4* const Aw = (uint4*)lds_f;                // [3][A_VEC]
+  uint4* const Bw = Aw + 3 * A_VEC;               // [3][B_VEC]
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int ntiles = a.mblocks * a.nblk_n;
+  const int slice = (int)blockIdx.x / ntiles;
+  const int tile = xcd_remap((int)blockIdx.x - slice * ntiles, ntiles);
+  const int mblk = tile % a.mblocks, nblk = tile / a.mblocks;
+  const int n0 = nblk * BN;
+  const int pt = (int)blockIdx.y;
+  const int s_begin = (int)((long)slice * a.nstages / a.ksplit);
+  const int s_end = (int)((long)(slice + 1) * a.nstages / a.ksplit);
+
+  const float* const vp = a.v + (long)pt * a.v_pstride;
+  const float* const up = a.u + (long)pt * a.u_pstride + (long)mblk * a.nstages * (kWgKp * BMP * 2);
+
+  int l_stage = s_begin;
+  auto issue_stage = [&](int buf) {
+    const int cg = l_stage / a.kd, dz = l_stage - cg * a.kd;
+    // weights: the stage's block is contiguous -- piece i of the wave = 64 lanes x 16 B
+#pragma unroll
+    for (int q = 0; q < A_PER_WAVE; ++q) {
+      const int piece = wave * A_PER_WAVE + q;
+      glds16((const uint4*)(up + (long)l_stage * (kWgKp * BMP * 2)) + piece * 64 + lane, Aw + buf * A_VEC + piece * 64);
+    }
+    // positions: wave w stages channel-pair rows 2w, 2w+1; a row is BN positions x 8 B = BN/128 pieces
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = 2 * wave + rr;
+      const float* src = vp + 2 * ((long)(cg * kWgKp + row) * a.Q + n0 + (long)dz * a.NB);
+#pragma unroll
+      for (int q = 0; q < BN / 128; ++q)
+        glds16((const uint4*)src + q * 64 + lane, Bw + buf * B_VEC + row * (BN / 2) + q * 64);
+    }
+    ++l_stage;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  int ia[TM], ib[TN];   // float2 index of this lane's fragments in pair-row `half` of a stage buffer
+#pragma unroll
+  for (int i = 0; i < TM; ++i) { ia[i] = half * BMP + (wm * TM + i) * 32 + l31; ECO_OPAQUE(ia[i]); }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { ib[j] = half * BN + (wn * TN + j) * 32 + l31; ECO_OPAQUE(ib[j]); }
+
+  auto compute = [&](int buf) {
+    const float2* Ab = (const float2*)(Aw + buf * A_VEC);
+    const float2* Bb = (const float2*)(Bw + buf * B_VEC);
+#pragma unroll
+    for (int t = 0; t < kWgKp / 2; ++t) {     // pair-rows 2t (lanes 0-31) and 2t+1 (lanes 32-63): four k per t
+      float2 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = Ab[2 * t * BMP + ia[i]];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bb[2 * t * BN + ib[j]];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(af[i].x, bf[j].x, acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(af[i].y, bf[j].y, acc[i][j]);
+    }
+  };
+
+  if (s_begin < s_end) {
+    issue_stage(0);
+    if (s_begin + 1 < s_end) issue_stage(1);
+    int buf = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+      if (s + 1 < s_end) wait_dma_all_but<P>(); else wait_dma_all_but<0>();
+      wg_barrier_nodrain();
+      if (s + 2 < s_end) issue_stage(buf == 0 ? 2 : buf - 1);   // (buf + 2) % 3: last read before this barrier
+      sched_fence();
+      compute(buf);
+      buf = buf == 2 ? 0 : buf + 1;
+    }
+  }
+  // raw store: M[p][slice][channel][position], lane = position (128 contiguous bytes per half-wave)
+  float* const mo = a.m + (long)pt * a.m_pstride + (long)slice * a.cout * a.ntot;
+  const int mw = mblk * BM + wm * TM * 32, nw = n0 + wn * TN * 32;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = nw + j * 32 + l31;
+    if (n >= a.ntot) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (ch < a.cout) st(mo + (long)ch * a.ntot + n, acc[i][j][r]);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Input transform into the pair-interleaved, depth-major, depth-padded layout.  One thread per (channel pair, padded
+// depth plane d', position r = (b, th, tw), channel parity): a 6x6 tile -> V = B^T d B, one float per transform
+// point; consecutive threads write consecutive floats (the parity is the fastest index of V).  The two padding
+// planes get zeros.  Transform constants: Lavin & Gray 2015, F(4x4,3x3), as in eco_wino.hip.
+struct WinoInPkArgs {
+  const float* x;
+  float* v;
+  int n, cin, D, H, W, TH, TW, pd;
+  int Q, NB;
+  long v_pstride;
+};
+
+__device__ __forceinline__ void wino_bt_d_b(const float (&d)[6][6], float (&v)[6][6]) {
+  constexpr float BT[6][6] = {{4, 0, -5, 0, 1, 0},  {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                              {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+  float t[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (BT[i][k] != 0.0f) acc += BT[i][k] * d[k][j];
+      t[i][j] = acc;
+    }
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (BT[j][k] != 0.0f) acc += t[i][k] * BT[j][k];
+      v[i][j] = acc;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void wino_input_pk_kernel(const WinoInPkArgs a) {
+  const int Dp = a.D + 2 * a.pd;
+  const long total = (long)(a.cin / 2) * Dp * a.NB * 2;     // one thread per (channel pair, plane, position, parity)
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int e = (int)(idx & 1);
+    const long pos = idx >> 1;
+    const int r = (int)(pos % a.NB);
+    const long t1 = pos / a.NB;
+    const int dp = (int)(t1 % Dp);
+    const int cp = (int)(t1 / Dp);
+    const int d = dp - a.pd;
+    float* out = a.v + idx;                                 // (cp*Q + dp*NB + r)*2 + e: consecutive lanes, consecutive floats
+    if ((unsigned)d >= (unsigned)a.D) {   // padding plane: zeros at every transform point
+#pragma unroll
+      for (int p = 0; p < kWgP; ++p) st(out + (long)p * a.v_pstride, 0.0f);
+      continue;
+    }
+    const int tw = r % a.TW, t2 = r / a.TW;
+    const int th = t2 % a.TH, b = t2 / a.TH;
+    const float* xp = a.x + (((long)b * a.cin + 2 * cp + e) * a.D + d) * a.H * a.W;
+    float dd[6][6], v[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int h = 4 * th - 1 + i;
+      const bool hok = (unsigned)h < (unsigned)a.H;
+      const float* rp = xp + (hok ? (long)h * a.W : 0l);
+      const int wl = 4 * tw - 1, wr = 4 * tw + 4;
+      const bool lok = hok && wl >= 0, rok = hok && wr < a.W;
+      dd[i][0] = lok ? ld(rp + (lok ? wl : 0)) : 0.0f;
+      dd[i][5] = rok ? ld(rp + (rok ? wr : 0)) : 0.0f;
+      if (VEC == 4) {
+        const bool ok = hok && 4 * tw < a.W;   // W % 4 == 0: the four columns are inside or outside together
+        const float4 q = ld((const float4*)(rp + (ok ? 4 * tw : 0)));
+        dd[i][1] = ok ? q.x : 0.0f; dd[i][2] = ok ? q.y : 0.0f; dd[i][3] = ok ? q.z : 0.0f; dd[i][4] = ok ? q.w : 0.0f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int w = 4 * tw + j;
+          const bool ok = hok && w < a.W;
+          dd[i][1 + j] = ok ? ld(rp + (ok ? w : 0)) : 0.0f;
+        }
+      }
+    }
+    wino_bt_d_b(dd, v);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) st(out + (long)(6 * i + j) * a.v_pstride, v[i][j]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Output transform from M[p][slice][cout][d][r]: y tile = A^T (sum over slices m) A, then the fused epilogue
+// (bias, Eltwise residual, raw store, folded BN, ReLU, both activated destinations; strided views).  One thread
+// per (b, channel, d, th, tw) as wino_output_kernel in eco_wino.hip.
+struct WinoOutDmArgs {
+  const float* m;
+  const float* bias;
+  const float* bn_scale;
+  const float* bn_shift;
+  eco_view residual, raw, act, act2;
+  int relu;
+  int n, cout, D, H, W, TH, TW;
+  int NB, ntot, ksplit;
+  long m_pstride;
+};
+
+template <int VEC>
+struct WgVec;
+template <>
+struct WgVec<1> { typedef float type; };
+template <>
+struct WgVec<2> { typedef float2 type; };
+template <>
+struct WgVec<4> { typedef float4 type; };
+
+template <int VEC>
+__global__ __launch_bounds__(256) void wino_output_dm_kernel(const WinoOutDmArgs a) {
+  constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+  typedef typename WgVec<VEC>::type vec_t;
+  const long tiles = (long)a.n * a.cout * a.D * a.TH * a.TW;
+  const int tpp = a.TH * a.TW;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < tiles; idx += (long)gridDim.x * 256) {
+    const int t = (int)(idx % tpp);
+    long r = idx / tpp;
+    const int d = (int)(r % a.D);
+    r /= a.D;
+    const int ch = (int)(r % a.cout);
+    const int img = (int)(r / a.cout);
+    const int th = t / a.TW, tw = t - th * a.TW;
+    const float* mp = a.m + (long)ch * a.ntot + (long)d * a.NB + (long)img * tpp + t;
+    float m[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float* q = mp + (long)(6 * i + j) * a.m_pstride;
+        float s = ld(q);
+        for (int sl = 1; sl < a.ksplit; ++sl) s += ld(q + (long)sl * a.cout * a.ntot);
+        m[i][j] = s;
+      }
+    float s4[4][6];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          if (AT[p][k] != 0.0f) acc += AT[p][k] * m[k][j];
+        s4[p][j] = acc;
+      }
+    const float b = a.bias ? ld(a.bias + ch) : 0.0f;
+    const float sc = a.bn_scale ? ld(a.bn_scale + ch) : 1.0f, sh = a.bn_scale ? ld(a.bn_shift + ch) : 0.0f;
+    const long o_res = a.residual.ptr ? view_base(a.residual, img, 0) + (long)ch * a.residual.stride_c : 0;
+    const long o_raw = a.raw.ptr ? view_base(a.raw, img, 0) + (long)ch * a.raw.stride_c : 0;
+    const long o_act = a.act.ptr ? view_base(a.act, img, 0) + (long)ch * a.act.stride_c : 0;
+    const long o_act2 = a.act2.ptr ? view_base(a.act2, img, 0) + (long)ch * a.act2.stride_c : 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int h = 4 * th + p;
+      if (h >= a.H) continue;
+#pragma unroll
+      for (int q0 = 0; q0 < 4; q0 += VEC) {
+        const int w0 = 4 * tw + q0;
+        if (w0 >= a.W) continue;  // W % VEC == 0: the VEC outputs are inside or outside together
+        float val[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float y = 0.0f;
+#pragma unroll
+          for (int k = 0; k < 6; ++k)
+            if (AT[q0 + e][k] != 0.0f) y += s4[p][k] * AT[q0 + e][k];
+          val[e] = y + b;
+        }
+        const int sp = (d * a.H + h) * a.W + w0;
+        if (a.residual.ptr) {
+          const vec_t rv = ld((const vec_t*)((const float*)a.residual.ptr + o_res + sp));
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) val[e] += ((const float*)&rv)[e];
+        }
+        if (a.raw.ptr) {
+          vec_t ov;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) ((float*)&ov)[e] = val[e];
+          st((vec_t*)(a.raw.ptr + o_raw + sp), ov);
+        }
+        if (a.act.ptr) {
+          vec_t ov;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            float o = val[e] * sc + sh;
+            if (a.relu) o = fmaxf(o, 0.0f);
+            ((float*)&ov)[e] = o;
+          }
+          st((vec_t*)(a.act.ptr + o_act + sp), ov);
+          if (a.act2.ptr) st((vec_t*)(a.act2.ptr + o_act2 + sp), ov);
+        }
+      }
+    }
+  }
+}
+
+static unsigned wg_grid(long total) {
+  long b = ceil_div(total, 256);
+  if (b > 1048576) b = 1048576;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+}  // namespace eco
+
+using namespace eco;
+
+static int wgemm_check_plan(const eco_wgemm_plan* p) {
+  ECO_REQUIRE(p != nullptr, "wgemm: null plan");
+  ECO_REQUIRE(p->points == kWgP, "wgemm: only F(4x4,3x3) (36 transform points) is supported, got %d", p->points);
+  ECO_REQUIRE(p->n > 0 && p->cin > 0 && p->cin % 16 == 0 && p->cout > 0 && p->d > 0 && p->th > 0 && p->tw > 0 &&
+                  (p->kd == 1 || p->kd == 3),
+              "wgemm: bad problem (n=%d cin=%d cout=%d d=%d tiles %dx%d kd=%d; cin must be a multiple of 16)", p->n, p->cin,
+              p->cout, p->d, p->th, p->tw, p->kd);
+  ECO_REQUIRE((p->bm == 128 || p->bm == 96 || p->bm == 64 || p->bm == 32) && (p->bn == 128 || p->bn == 256),
+              "wgemm: unsupported tile %dx%d", p->bm, p->bn);
+  ECO_REQUIRE(p->nstages == (p->cin / 16) * p->kd && p->ksplit >= 1 && p->ksplit <= p->nstages, "wgemm: bad plan");
+  return ECO_OK;
+}
+
+extern "C" int eco_wgemm_plan_create(int32_t n, int32_t cin, int32_t cout, int32_t d, int32_t th, int32_t tw, int32_t kd,
+                                     int32_t points, int32_t num_cu, eco_wgemm_plan* plan) {
+  clear_error();
+  ECO_REQUIRE(plan != nullptr && num_cu >= 0, "wgemm: bad argument");
+  if (num_cu == 0) num_cu = 256;
+  memset(plan, 0, sizeof(*plan));
+  plan->n = n; plan->cin = cin; plan->cout = cout; plan->d = d; plan->th = th; plan->tw = tw; plan->kd = kd;
+  plan->points = points;
+  int bm;
+  if (cout <= 32) bm = 32;
+  else if (cout <= 64) bm = 64;
+  else if (cout <= 96) bm = 96;
+  else {
+    bm = 128;
+    long best = ceil_div(cout, 128) * 128;
+    const int cands[2] = {96, 64};
+    for (int c : cands) {
+      const long padded = ceil_div(cout, c) * c;
+      if (padded < best) { best = padded; bm = c; }
+    }
+  }
+  plan->bm = bm;
+  plan->nstages = (cin / 16) * kd;
+  plan->ksplit = 1;
+  plan->bn = 256;
+  if (cin % 16 == 0 && cin > 0 && n > 0 && d > 0 && th > 0 && tw > 0) {
+    // Tile width and split-K by a small cost model: workgroups per round = 2 per CU; a workgroup costs its MFMA
+    // time at half a CU plus ~3 us of pipeline fill and store; pick the (bn, ksplit) with the fewest rounds x cost.
+    const long nb = (long)n * th * tw, ntot = nb * d;
+    const long mblocks = ceil_div(cout, bm);
+    const long slots = 2L * num_cu;
+    double best = 1e30;
+    int max_sp = plan->nstages / 4;
+    if (max_sp > 4) max_sp = 4;
+    if (max_sp < 1) max_sp = 1;
+    for (int bn = 256; bn >= 128; bn -= 128)
+      for (int sp = 1; sp <= max_sp; ++sp) {
+        const long wgs = mblocks * ceil_div(ntot, bn) * sp * points;
+        const double t_wg = 2.0 * bm * bn * 16.0 * (plan->nstages / (double)sp) * 2.0 / (157.3e12 / num_cu) + 3e-6 +
+                            (sp > 1 ? 1e-6 : 0.0);
+        const double t = (double)ceil_div(wgs, slots) * t_wg;
+        if (t < best * 0.97) { best = t; plan->bn = bn; plan->ksplit = sp; }
+      }
+  }
+  const long nb = (long)n * th * tw;
+  const int pd = kd / 2;
+  plan->mblocks = (int)ceil_div(cout, bm);
+  plan->bmp = (bm + 63) / 64 * 64;
+  plan->q = (int64_t)(d + 2 * pd) * nb;
+  plan->u_elems = (int64_t)points * plan->mblocks * plan->nstages * kWgKp * plan->bmp * 2;
+  // one tile of slack behind the last point: the last tile of a row reads up to bn positions past its end
+  plan->v_elems = ((int64_t)points * (cin / 2) * plan->q + 256 + 2 * nb) * 2;
+  plan->m_elems = (int64_t)points * plan->ksplit * cout * nb * d;
+  return wgemm_check_plan(plan);
+}
+
+extern "C" int eco_wgemm_pack_weights(const eco_wgemm_plan* plan, const float* u, float* up) {
+  clear_error();
+  if (int rc = wgemm_check_plan(plan)) return rc;
+  ECO_REQUIRE(u && up, "wgemm pack: null argument");
+  memset(up, 0, sizeof(float) * (size_t)plan->u_elems);
+  const int cin = plan->cin, cout = plan->cout, kd = plan->kd, bm = plan->bm, bmp = plan->bmp;
+  // u[p][co][ci][z] -> up[p][mblock][stage = (ci/16)*kd + z][(ci%16)/2][co - mblock*bm][ci%2]
+  for (int p = 0; p < plan->points; ++p)
+    for (int co = 0; co < cout; ++co) {
+      const int mb = co / bm, ml = co - mb * bm;
+      for (int ci = 0; ci < cin; ++ci)
+        for (int z = 0; z < kd; ++z) {
+          const long stage = (long)(ci / 16) * kd + z;
+          const long o = ((((long)p * plan->mblocks + mb) * plan->nstages + stage) * kWgKp + (ci % 16) / 2) * bmp * 2 +
+                         (long)ml * 2 + (ci & 1);
+          up[o] = u[(((long)p * cout + co) * cin + ci) * kd + z];
+        }
+    }
+  return ECO_OK;
+}
+
+extern "C" int eco_wino_input_pk_forward(const eco_wgemm_plan* plan, const float* x, float* v, int32_t h, int32_t w,
+                                         void* stream) {
+  clear_error();
+  if (int rc = wgemm_check_plan(plan)) return rc;
+  ECO_REQUIRE(x && v && h > 0 && w > 0, "winograd input transform: bad argument");
+  ECO_REQUIRE(plan->th == (h + 3) / 4 && plan->tw == (w + 3) / 4, "winograd input transform: plan is for %dx%d tiles", plan->th,
+              plan->tw);
+  WinoInPkArgs a;
+  a.x = x; a.v = v; a.n = plan->n; a.cin = plan->cin; a.D = plan->d; a.H = h; a.W = w; a.TH = plan->th; a.TW = plan->tw;
+  a.pd = plan->kd / 2;
+  a.NB = plan->n * plan->th * plan->tw;
+  a.Q = (int)plan->q;
+  a.v_pstride = (long)(plan->cin / 2) * plan->q * 2;
+  const long total = (long)(plan->cin / 2) * (plan->d + 2 * a.pd) * a.NB * 2;
+  const bool vec4 = w % 4 == 0 && ((uintptr_t)x & 15) == 0;
+  if (vec4) hipLaunchKernelGGL((wino_input_pk_kernel<4>), dim3(wg_grid(total)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((wino_input_pk_kernel<1>), dim3(wg_grid(total)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("eco_wino_input_pk_forward");
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_wgemm(const WGemmArgs& a, int points, hipStream_t stream) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, BMP = (BM + 63) / 64 * 64;
+  const size_t lds = (size_t)3 * kWgKp * (BMP + BN) * 8;
+#ifndef ECO_EMU
+  if (lds > 64 * 1024) {
+    static thread_local bool raised = false;
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute((const void*)wgemm_kernel<TM, TN, WM, WN>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return fail(ECO_ERR_RUNTIME, "wgemm: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+      raised = true;
+    }
+  }
+#endif
+  const int grid = a.mblocks * a.nblk_n * a.ksplit;
+  hipLaunchKernelGGL((wgemm_kernel<TM, TN, WM, WN>), dim3(grid, points), dim3(256), lds, stream, a);
+  return check_launch("eco_wgemm_forward");
+}
+
+extern "C" int eco_wgemm_forward(const eco_wgemm_plan* plan, const float* v, const float* up, float* m, void* stream) {
+  clear_error();
+  if (int rc = wgemm_check_plan(plan)) return rc;
+  ECO_REQUIRE(v && up && m, "wgemm: null argument");
+  ECO_REQUIRE((((uintptr_t)v | (uintptr_t)up) & 15) == 0, "wgemm: operands must be 16-byte aligned");
+  WGemmArgs a;
+  a.v = v; a.u = up; a.m = m;
+  a.cout = plan->cout; a.cp = plan->cin / 2; a.kd = plan->kd; a.nstages = plan->nstages; a.ksplit = plan->ksplit;
+  a.NB = plan->n * plan->th * plan->tw;
+  a.Q = (int)plan->q;
+  a.ntot = a.NB * plan->d;
+  a.mblocks = plan->mblocks; a.bmp = plan->bmp;
+  a.nblk_n = (int)ceil_div(a.ntot, plan->bn);
+  a.v_pstride = (long)a.cp * plan->q * 2;
+  a.u_pstride = (long)plan->mblocks * plan->nstages * kWgKp * plan->bmp * 2;
+  a.m_pstride = (long)plan->ksplit * plan->cout * a.ntot;
+  hipStream_t s = (hipStream_t)stream;
+  if (plan->bn == 256) {
+    switch (plan->bm) {
+      case 128: return launch_wgemm<4, 2, 1, 4>(a, plan->points, s);
+      case 96: return launch_wgemm<3, 2, 1, 4>(a, plan->points, s);
+      case 64: return launch_wgemm<2, 2, 1, 4>(a, plan->points, s);
+      case 32: return launch_wgemm<1, 2, 1, 4>(a, plan->points, s);
+    }
+  } else {
+    switch (plan->bm) {
+      case 128: return launch_wgemm<2, 2, 2, 2>(a, plan->points, s);
+      case 96: return launch_wgemm<3, 1, 1, 4>(a, plan->points, s);
+      case 64: return launch_wgemm<2, 1, 1, 4>(a, plan->points, s);
+      case 32: return launch_wgemm<1, 1, 1, 4>(a, plan->points, s);
+    }
+  }
+  return fail(ECO_ERR_INVALID, "wgemm: unsupported tile %dx%d", plan->bm, plan->bn);
+}
+
+extern "C" int eco_wino_output_dm_forward(const eco_wgemm_plan* plan, const float* m, int32_t h, int32_t w,
+                                          const eco_conv_epilogue* ep, void* stream) {
+  clear_error();
+  if (int rc = wgemm_check_plan(plan)) return rc;
+  ECO_REQUIRE(m && ep && h > 0 && w > 0, "winograd output transform: bad argument");
+  ECO_REQUIRE(plan->th == (h + 3) / 4 && plan->tw == (w + 3) / 4, "winograd output transform: plan is for %dx%d tiles",
+              plan->th, plan->tw);
+  ECO_REQUIRE(ep->raw.ptr || ep->act.ptr, "winograd output transform: at least one of raw/act outputs is required");
+  ECO_REQUIRE(!ep->bn_scale == !ep->bn_shift, "winograd output transform: bn_scale and bn_shift must be given together");
+  ECO_REQUIRE(!ep->act2.ptr || ep->act.ptr, "winograd output transform: act2 needs act");
+  const eco_view* views[4] = {&ep->residual, &ep->raw, &ep->act, &ep->act2};
+  for (const eco_view* v : views)
+    ECO_REQUIRE(!v->ptr || (v->t >= 1 && v->stride_c >= 1), "winograd output transform: view needs t >= 1 and stride_c >= 1");
+  WinoOutDmArgs a;
+  a.m = m; a.bias = ep->bias; a.bn_scale = ep->bn_scale; a.bn_shift = ep->bn_shift;
+  a.residual = ep->residual; a.raw = ep->raw; a.act = ep->act; a.act2 = ep->act2; a.relu = ep->relu;
+  a.n = plan->n; a.cout = plan->cout; a.D = plan->d; a.H = h; a.W = w; a.TH = plan->th; a.TW = plan->tw;
+  a.NB = plan->n * plan->th * plan->tw;
+  a.ntot = a.NB * plan->d;
+  a.ksplit = plan->ksplit;
+  a.m_pstride = (long)plan->ksplit * plan->cout * a.ntot;
+  int vec = 4;
+  auto limit = [&](const eco_view& v) {
+    if (!v.ptr) return;
+    while (vec > 1 && (((uintptr_t)v.ptr % (4 * vec)) || v.stride_b % vec || v.stride_t % vec || v.stride_c % vec)) vec /= 2;
+  };
+  while (vec > 1 && w % vec) vec /= 2;
+  limit(a.residual); limit(a.raw); limit(a.act); limit(a.act2);
+  const long tiles = (long)a.n * a.cout * a.D * a.TH * a.TW;
+  const dim3 grid(wg_grid(tiles)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (vec == 4) hipLaunchKernelGGL((wino_output_dm_kernel<4>), grid, block, 0, s, a);
+  else if (vec == 2) hipLaunchKernelGGL((wino_output_dm_kernel<2>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((wino_output_dm_kernel<1>), grid, block, 0, s, a);
+  return check_launch("eco_wino_output_dm_forward");
+}

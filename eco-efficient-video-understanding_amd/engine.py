@@ -135,6 +135,7 @@ class Engine:
         if winograd not in (False, True, 2, 4):
             raise ValueError("winograd must be False, True, 2 or 4")
         self.winograd = winograd
+        self.wgemm = True          # F(4x4,3x3) GEMMs on the dedicated dense kernel (False: round-1 gather-kernel route)
         self.num_cu = num_cu       # None = the device's 256 CUs (tests shrink it to reach split-K paths)
         self.params: Dict[str, List[np.ndarray]] = {}
         self._param_dev: Dict[str, dict] = {}    # layer name -> device-side state
@@ -204,7 +205,14 @@ class Engine:
                 if L.geom["bias_term"]:
                     self.alloc.upload(st["bias"], blobs[1])
                 wn = st.get("wino")
-                if wn is not None:  # u[p] = (G g G^T)[p], each point packed for the (kd,1,1) gather kernel
+                if wn is not None and wn.get("kind") == "wgemm":   # u[p] = (G g G^T)[p] packed for the dense GEMM kernel
+                    cout, cin, kd = L.geom["cout"], L.geom["cin"], wn["kd"]
+                    u = np.empty((36, cout, cin, kd), np.float32)
+                    self.lib.wino_weight_transform(w.ctypes.data, cout, cin, kd, 4, u.ctypes.data)
+                    up = np.empty(wn["plan"].u_elems, np.float32)
+                    self.lib.wgemm_pack_weights(wn["plan"], u.ctypes.data, up.ctypes.data)
+                    self.alloc.upload(wn["up"], up)
+                elif wn is not None:  # u[p] = (G g G^T)[p], each point packed for the (kd,1,1) gather kernel
                     cout, cin, kd = L.geom["cout"], L.geom["cin"], wn["kd"]
                     P = wn["points"]
                     u = np.empty((P, cout, cin, kd), np.float32)
@@ -284,7 +292,7 @@ class Engine:
         ws_bytes = max([st["plan"].ws_bytes for st in self._param_dev.values() if "plan" in st] +
                        [st["bplan"].ws_bytes for st in self._param_dev.values() if "bplan" in st] +
                        [st["wino"]["points"] * st["wino"]["plan"].ws_bytes for st in self._param_dev.values()
-                        if "wino" in st] + [0])
+                        if "wino" in st and st["wino"]["kind"] == "gather"] + [0])
         for key in ("v_elems", "m_elems"):
             need = max([st["wino"][key] for st in self._param_dev.values() if "wino" in st] + [0])
             if need > getattr(self, "_wino_" + key, 0):
@@ -485,12 +493,22 @@ class Engine:
         M = self.winograd if self.winograd in (2, 4) else 4
         T = M + 2
         TH, TW = -(-H // M), -(-W // M)
+        old = st.get("wino")
+        if M == 4 and self.wgemm:
+            # F(4x4,3x3) on the dedicated dense GEMM (csrc/eco_wgemm.hip): pair-interleaved depth-major V, LDS-DMA staging
+            plan = self.lib.wgemm_plan(n, g["cin"], g["cout"], D, TH, TW, kd, self.num_cu)
+            wn = dict(kind="wgemm", plan=plan, M=4, points=36, TH=TH, TW=TW, kd=kd, v_elems=plan.v_elems, m_elems=plan.m_elems)
+            if old is not None and old.get("kind") == "wgemm" and old["plan"].u_elems == plan.u_elems:
+                wn["up"] = old["up"]
+            else:
+                wn["up"] = self.alloc.empty(plan.u_elems, np.float32)
+            st["wino"] = wn
+            return
         gw = hip.conv_geom(n, g["cin"], g["cout"], (D, TH, TW), (kd, 1, 1), (1, 1, 1), (kd // 2, 0, 0), (D, TH, TW))
         plan = self.lib.conv_plan(gw, self.num_cu, batch=T * T)   # the T*T points share one launch
-        old = st.get("wino")
-        wn = dict(geom=gw, plan=plan, M=M, points=T * T, TH=TH, TW=TW, kd=kd,
+        wn = dict(kind="gather", geom=gw, plan=plan, M=M, points=T * T, TH=TH, TW=TW, kd=kd,
                   v_elems=T * T * n * g["cin"] * D * TH * TW, m_elems=T * T * n * g["cout"] * D * TH * TW)
-        if old is not None and (old["points"], old["plan"].wp_elems, old["plan"].ktab_elems) == \
+        if old is not None and old.get("kind") == "gather" and (old["points"], old["plan"].wp_elems, old["plan"].ktab_elems) == \
                 (T * T, plan.wp_elems, plan.ktab_elems):
             wn["wp"], wn["ktab"] = old["wp"], old["ktab"]
         else:
@@ -501,12 +519,31 @@ class Engine:
     def _emit_wino_conv(self, i: int, L: LayerSpec, ep: "hip.ConvEpilogue", label: str, nbytes: int) -> None:
         st = self._param_dev[L.name]
         wn = st["wino"]
-        gw, plan, M, P = wn["geom"], wn["plan"], wn["M"], wn["points"]
         lib = self.lib
         n, D, H, W, kd = self._wino_dims(L)
         cin, cout = L.geom["cin"], L.geom["cout"]
         x = self._ptr(L.bottoms[0])
         v, m = self.alloc.ptr(self._wino_buf_v_elems), self.alloc.ptr(self._wino_buf_m_elems)
+        if wn["kind"] == "wgemm":
+            plan, up = wn["plan"], self.alloc.ptr(wn["up"])
+            self._keep.append((plan, ep))
+            tiles = n * D * wn["TH"] * wn["TW"]                     # positions per transform point
+            v_bytes = 4 * 36 * cin * (D + 2 * (kd // 2)) * n * wn["TH"] * wn["TW"]
+            m_bytes = 4 * 36 * plan.ksplit * cout * tiles
+            tag = "F(4x4,3x3)"
+            self._add(i, f"{label} [winograd {tag} input transform]", lambda s, plan=plan, x=x, v=v, H=H, W=W:
+                      lib.wino_input_pk_forward(plan, x, v, H, W, s),
+                      {"kernel": "eco::wino_input_pk_kernel", "flops": 0, "bytes": 4 * n * cin * D * H * W + v_bytes})
+            self._add(i, f"{label} [36 transformed-domain GEMMs, K = {cin * kd}]", lambda s, plan=plan, v=v, up=up, m=m:
+                      lib.wgemm_forward(plan, v, up, m, s),
+                      {"kernel": hip.wgemm_kernel_name(plan), "flops": 2 * 36 * tiles * cout * cin * kd,
+                       "bytes": v_bytes + 4 * 36 * cout * cin * kd + m_bytes})
+            self._add(i, f"{label} [winograd {tag} output transform]", lambda s, plan=plan, m=m, H=H, W=W, ep=ep:
+                      lib.wino_output_dm_forward(plan, m, H, W, ep, s),
+                      {"kernel": "eco::wino_output_dm_kernel", "flops": 0,
+                       "bytes": m_bytes + nbytes - 4 * (n * cin * D * H * W + 9 * kd * cin * cout)})
+            return
+        gw, plan, M, P = wn["geom"], wn["plan"], wn["M"], wn["points"]
         wp, kt = self.alloc.ptr(wn["wp"]), self.alloc.ptr(wn["ktab"])
         ws = self.alloc.ptr(self._ws) if plan.ws_bytes else None
         tin, tout = wn["v_elems"] // P, wn["m_elems"] // P

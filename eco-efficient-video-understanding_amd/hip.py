@@ -21,7 +21,7 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 DT_BF16 = 1
 DT_F32X3 = 3
 
@@ -54,6 +54,13 @@ class ConvBPlan(C.Structure):
     _fields_ = [("bm", C.c_int32), ("bn", C.c_int32), ("dt", C.c_int32), ("stem", C.c_int32),
                 ("cblocks", C.c_int32), ("nstages", C.c_int32), ("mpad", C.c_int32), ("ksplit", C.c_int32),
                 ("span_pieces", C.c_int32), ("reserved", C.c_int32), ("wp_vecs", C.c_int64), ("ws_bytes", C.c_int64)]
+
+
+class WGemmPlan(C.Structure):
+    _fields_ = [("n", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("d", C.c_int32), ("th", C.c_int32),
+                ("tw", C.c_int32), ("kd", C.c_int32), ("points", C.c_int32), ("bm", C.c_int32), ("bn", C.c_int32),
+                ("nstages", C.c_int32), ("ksplit", C.c_int32), ("mblocks", C.c_int32), ("bmp", C.c_int32),
+                ("q", C.c_int64), ("u_elems", C.c_int64), ("v_elems", C.c_int64), ("m_elems", C.c_int64)]
 
 
 class View(C.Structure):
@@ -99,6 +106,12 @@ def conv_kernel_name(plan: ConvPlan) -> str:
     if plan.mode == 2:
         return f"eco::conv_span_kernel<{tm}, {tn}, {wm}, {wn}>"
     return f"eco::conv_mfma_kernel<{tm}, {tn}, {wm}, {wn}, {plan.kc}, {plan.mode}>"
+
+
+def wgemm_kernel_name(plan: "WGemmPlan") -> str:
+    tm, tn, wm, wn = {(128, 256): (4, 2, 1, 4), (96, 256): (3, 2, 1, 4), (64, 256): (2, 2, 1, 4), (32, 256): (1, 2, 1, 4),
+                      (128, 128): (2, 2, 2, 2), (96, 128): (3, 1, 1, 4), (64, 128): (2, 1, 1, 4), (32, 128): (1, 1, 1, 4)}[(plan.bm, plan.bn)]
+    return f"eco::wgemm_kernel<{tm}, {tn}, {wm}, {wn}>"
 
 
 def convb_kernel_name(plan: "ConvBPlan") -> str:
@@ -183,6 +196,12 @@ _SIGNATURES = {
                                        C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "eco_softmax_loss_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                            C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "eco_wgemm_plan_create": (C.c_int, [C.c_int32] * 9 + [C.POINTER(WGemmPlan)]),
+    "eco_wgemm_pack_weights": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p]),
+    "eco_wino_input_pk_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "eco_wgemm_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eco_wino_output_dm_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_int32, C.c_int32,
+                                             C.POINTER(ConvEpilogue), C.c_void_p]),
     "eco_convb_plan_create": (C.c_int, [C.POINTER(ConvGeom), C.c_int32, C.c_int32, C.POINTER(ConvBPlan)]),
     "eco_convb_pack_weights": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvBPlan), C.c_void_p, C.c_void_p]),
     "eco_convb_forward": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvBPlan), C.c_void_p, C.c_void_p,
@@ -276,6 +295,25 @@ class EcoLib:
     def wino_output_forward(self, m: int, n: int, cout: int, d: int, h: int, w: int, tile_m: int, ep: ConvEpilogue,
                             stream=None) -> None:
         self._check(self._dll.eco_wino_output_forward(m, n, cout, d, h, w, tile_m, C.byref(ep), stream))
+
+    # -- Winograd F(4x4,3x3) on the dedicated transformed-domain GEMM (csrc/eco_wgemm.hip) --
+    def wgemm_plan(self, n, cin, cout, d, th, tw, kd, num_cu: Optional[int] = None) -> "WGemmPlan":
+        p = WGemmPlan()
+        self._check(self._dll.eco_wgemm_plan_create(n, cin, cout, d, th, tw, kd, 36, 0 if num_cu is None else int(num_cu),
+                                                    C.byref(p)))
+        return p
+
+    def wgemm_pack_weights(self, p: "WGemmPlan", u_host: int, up_host: int) -> None:
+        self._check(self._dll.eco_wgemm_pack_weights(C.byref(p), u_host, up_host))
+
+    def wino_input_pk_forward(self, p: "WGemmPlan", x: int, v: int, h: int, w: int, stream=None) -> None:
+        self._check(self._dll.eco_wino_input_pk_forward(C.byref(p), x, v, h, w, stream))
+
+    def wgemm_forward(self, p: "WGemmPlan", v: int, up: int, m: int, stream=None) -> None:
+        self._check(self._dll.eco_wgemm_forward(C.byref(p), v, up, m, stream))
+
+    def wino_output_dm_forward(self, p: "WGemmPlan", m: int, h: int, w: int, ep: ConvEpilogue, stream=None) -> None:
+        self._check(self._dll.eco_wino_output_dm_forward(C.byref(p), m, h, w, C.byref(ep), stream))
 
     # -- channel-blocked bf16-MFMA path (csrc/eco_blocked.hip) ------------------
     def convb_plan(self, g: ConvGeom, dt: int, num_cu: Optional[int] = None) -> "ConvBPlan":

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 10
+#define ECO_ABI_VERSION 11
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -261,6 +261,37 @@ int eco_accuracy_forward(const float* x, const float* label, float* out, int64_t
 int eco_softmax_loss_forward(const float* x, const float* label, float* out, int64_t outer, int64_t c,
                              int64_t inner, int32_t normalize, int32_t has_ignore_label,
                              int32_t ignore_label, void* stream);
+
+/* ---- Winograd F(4x4,3x3) route on a dedicated transformed-domain GEMM (csrc/eco_wgemm.hip) -------------------
+ *
+ * The same three steps as the eco_wino_* / eco_conv_forward_batched route above for tile_m = 4, with layouts chosen
+ * for a dense GEMM kernel (operands staged by LDS-DMA, no address decode, no tap masks):
+ *   v[p][cin/2][d + 2*(kd/2)][r][2]   channel pairs interleaved, positions r = (b*TH + th)*TW + tw depth-major,
+ *                                     one all-zero plane at either end of the depth axis when kd = 3
+ *   up = eco_wgemm_pack_weights(u)    u = eco_wino_weight_transform(w, tile_m = 4) -> [p][mblock][stage][8][bmp][2]
+ *   m[p][slice][cout][d][r]           raw products; split-K slices are summed by the output transform
+ *   eco_wino_input_pk_forward(x -> v); eco_wgemm_forward(v, up -> m); eco_wino_output_dm_forward(m -> y, epilogue)
+ * Same results as eco_conv_forward up to fp32 rounding (cudnn_conv_layer.cu:15-65 leaves the algorithm to cuDNN). */
+typedef struct eco_wgemm_plan {
+  int32_t n, cin, cout, d, th, tw; /* clips/images, channels, depth, tiles per plane (ceil(H/4), ceil(W/4))   */
+  int32_t kd;                      /* 1 (2-D 3x3) or 3 (3x3x3, depth taps direct)                             */
+  int32_t points;                  /* 36                                                                      */
+  int32_t bm, bn;                  /* block tile: output channels x positions                                 */
+  int32_t nstages;                 /* (cin/16) * kd stages of 16 reduction elements                           */
+  int32_t ksplit;                  /* split-K slices (rows of m)                                              */
+  int32_t mblocks, bmp;            /* ceil(cout/bm); bm rounded up to 64 (rows of a packed weight block)      */
+  int64_t q;                       /* positions per channel-pair row of v: (d + 2*(kd/2)) * n*th*tw           */
+  int64_t u_elems, v_elems, m_elems; /* floats in up / v (with read slack) / m                                */
+} eco_wgemm_plan;
+/* cin % 16 == 0.  num_cu = 0 plans for 256 compute units. */
+int eco_wgemm_plan_create(int32_t n, int32_t cin, int32_t cout, int32_t d, int32_t th, int32_t tw, int32_t kd,
+                          int32_t points, int32_t num_cu, eco_wgemm_plan* plan);
+/* HOST function: u[p][cout][cin][kd] (eco_wino_weight_transform) -> up (plan->u_elems floats). */
+int eco_wgemm_pack_weights(const eco_wgemm_plan* plan, const float* u, float* up);
+int eco_wino_input_pk_forward(const eco_wgemm_plan* plan, const float* x, float* v, int32_t h, int32_t w, void* stream);
+int eco_wgemm_forward(const eco_wgemm_plan* plan, const float* v, const float* up, float* m, void* stream);
+int eco_wino_output_dm_forward(const eco_wgemm_plan* plan, const float* m, int32_t h, int32_t w,
+                               const eco_conv_epilogue* ep, void* stream);
 
 /* ---- channel-blocked ("NC8") path on the bf16 matrix cores (csrc/eco_blocked.hip) -------------------------
  *
