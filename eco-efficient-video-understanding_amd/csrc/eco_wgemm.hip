@@ -420,7 +420,6 @@ extern "C" int eco_wgemm_plan_create(int32_t n, int32_t cin, int32_t cout, int32
     // time at half a CU plus ~3 us of pipeline fill and store; pick the (bn, ksplit) with the fewest rounds x cost.
     const long nb = (long)n * th * tw, ntot = nb * d;
     const long mblocks = ceil_div(cout, bm);
-    const long slots = 2L * num_cu;
     double best = 1e30;
     int max_sp = plan->nstages / 4;
     if (max_sp > 4) max_sp = 4;
@@ -428,9 +427,16 @@ extern "C" int eco_wgemm_plan_create(int32_t n, int32_t cin, int32_t cout, int32
     for (int bn = 256; bn >= 128; bn -= 128)
       for (int sp = 1; sp <= max_sp; ++sp) {
         const long wgs = mblocks * ceil_div(ntot, bn) * sp * points;
-        const double t_wg = 2.0 * bm * bn * 16.0 * (plan->nstages / (double)sp) * 2.0 / (157.3e12 / num_cu) + 3e-6 +
-                            (sp > 1 ? 1e-6 : 0.0);
-        const double t = (double)ceil_div(wgs, slots) * t_wg;
+        const long lds = 3L * kWgKp * ((bm + 63) / 64 * 64 + bn) * 8;          // three stage buffers
+        long occ = 160 * 1024 / lds;                                         // workgroups resident per CU (LDS-bound)
+        if (occ > 4) occ = 4;
+        const long slots = occ * num_cu;
+        const double t_wg = 2.0 * bm * bn * 16.0 * (plan->nstages / (double)sp) * occ / (157.3e12 / num_cu) + 3e-6;
+        // every extra slice is one more write of M here and one more read in the output transform (~4 TB/s each,
+        // measured on the transforms): without this term res4 (1152 tiles on 512 slots) took three slices and the
+        // output transform gave back what the GEMM had gained
+        const double t_slices = (sp - 1) * 2.0 * (double)points * cout * ntot * 4.0 / 4e12;
+        const double t = (double)ceil_div(wgs, slots) * t_wg + t_slices;
         if (t < best * 0.97) { best = t; plan->bn = bn; plan->ksplit = sp; }
       }
   }
