@@ -857,6 +857,108 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : TM * TN <= 6 ? 3 : 2)) voi
     conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 1x1 stride-1 convolutions (ECO_CONV_MODE_POINT: the *_1x1, *_reduce and *_pool_proj layers of the inception
+// blocks: K = 192-576, cout 32-192 over 401 408 positions) as a plain GEMM staged by LDS-DMA.
+//
+// Y[m, n] = sum_c Wp[c, m] * X[img(n), c, sp(n)]: row c of the position operand is the channel's own plane,
+// contiguous inside an image, so a stage of 16 channels is 16 rows of BN consecutive positions that go
+// global -> LDS as 16-byte pieces (four positions per lane; a plane size that is a multiple of 4 keeps a lane's
+// four positions inside one image) -- no address decode per element, no tap mask, no VGPR staging, no ds_write.
+// These layers sit near the HBM ridge (89-140 flop/B): what they need is bytes in flight, which three stage
+// buffers of DMA give (two stages of 16-24 KB per workgroup outstanding while the third is multiplied).  The
+// gather kernel ran them at 0.45-0.50 of their floor.  Same packed weights (CTAP order = channel order for a
+// single tap), same epilogue and views as conv_mfma_kernel.
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_point_kernel(const ConvKernelArgs a) {
+  constexpr int KC = 16;
+  constexpr int BM = 32 * TM * WM;
+  constexpr int BN = 32 * TN * WN;
+  constexpr int BMP = (BM + 63) / 64 * 64;
+  static_assert(WM * WN == 4 && BN == 256, "");
+  constexpr int A_PER_WAVE = BMP / 64;   // 16 rows x BMP floats = BMP/16 pieces of 1 KB
+  constexpr int B_PER_WAVE = 4;          // 16 rows x 256 positions: one piece per row
+  constexpr int P = A_PER_WAVE + B_PER_WAVE;
+
+  ECO_DYNAMIC_LDS(lds);
+  float* const As = lds;                        // [3][KC][BMP]
+  float* const Bs = lds + 3 * KC * BMP;         // [3][KC][BN]
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int tile = xcd_remap((int)blockIdx.x, a.nblk_m * a.nblk_n);
+  const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
+  const int m0 = mblk * BM, n0 = nblk * BN;
+  const int nstages = a.cin / KC;
+
+  // this lane's four positions n0 + 4*lane .. +3 (one image: s_out % 4 == 0)
+  long lane_base;
+  {
+    const int n = n0 + 4 * lane;
+    const int nn = n < a.ntot ? n : 0;          // past the end: any valid address (those columns are never stored)
+    const int img = nn / a.s_out, sp = nn - img * a.s_out;
+    lane_base = (long)img * a.img_stride_in + sp;
+  }
+  int l_stage = 0;
+  auto issue_stage = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < A_PER_WAVE; ++q) {
+      const int i = (wave * A_PER_WAVE + q) * 64 + lane;           // float4 index in the [KC][BMP] tile
+      const int row = i / (BMP / 4), c4 = i - row * (BMP / 4);
+      glds16((const uint4*)(a.wp + (long)(l_stage * KC + row) * a.mpad + m0 + c4 * 4),
+             (uint4*)(As + buf * KC * BMP) + (wave * A_PER_WAVE + q) * 64);
+    }
+#pragma unroll
+    for (int q = 0; q < B_PER_WAVE; ++q) {
+      const int row = wave * B_PER_WAVE + q;
+      glds16((const uint4*)(a.x + lane_base + (long)(l_stage * KC + row) * a.s_in), (uint4*)(Bs + (buf * KC + row) * BN));
+    }
+    ++l_stage;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto compute = [&](int buf) {
+    const float* Ab = As + buf * KC * BMP + half * BMP + wm * TM * 32 + l31;
+    const float* Bb = Bs + buf * KC * BN + half * BN + wn * TN * 32 + l31;
+#pragma unroll
+    for (int kk = 0; kk < KC / 2; ++kk) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = Ab[2 * kk * BMP + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bb[2 * kk * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(af[i], bf[j], acc[i][j]);
+    }
+  };
+
+  issue_stage(0);
+  if (nstages > 1) issue_stage(1);
+  int buf = 0;
+  for (int s = 0; s < nstages; ++s) {
+    if (s + 1 < nstages) wait_dma_all_but<P>(); else wait_dma_all_but<0>();
+    wg_barrier_nodrain();
+    if (s + 2 < nstages) issue_stage(buf == 0 ? 2 : buf - 1);
+    sched_fence();
+    compute(buf);
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+  conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+}
+
 static int validate_geom(const eco_conv_geom* g) {
   ECO_REQUIRE(g != nullptr, "conv: null geometry");
   ECO_REQUIRE(g->n > 0 && g->cin > 0 && g->cout > 0, "conv: n/cin/cout must be positive (n=%d cin=%d cout=%d)",
@@ -977,6 +1079,13 @@ extern "C" int eco_conv_plan_create_batched(const eco_conv_geom* g, int32_t num_
     for (int i = 0; i < 3; ++i) span = span && g->stride[i] == 1 && g->out[i] == g->in[i];
     span = span && plan->bn + 2 * (g->in[2] + 1) <= 512;  // two span columns per thread
     if (span) plan->mode = ECO_CONV_MODE_SPAN;
+    // 1x1 stride-1 unpadded convolutions over planes whose size is a multiple of 4, with enough positions to
+    // fill 256-wide tiles: the LDS-DMA GEMM kernel (single launches only; the gather kernel keeps the batched form)
+    bool point = plan->mode == ECO_CONV_MODE_CTAP && batch == 1;
+    for (int i = 0; i < 3; ++i) point = point && g->kernel[i] == 1 && g->stride[i] == 1 && g->pad[i] == 0;
+    const long s_out_ = (long)g->out[0] * g->out[1] * g->out[2];
+    point = point && s_out_ % 4 == 0 && (long)g->n * s_out_ >= 4L * num_cu * 256;
+    if (point) { plan->mode = ECO_CONV_MODE_POINT; plan->bn = 256; }
   }
   plan->k = g->cin * g->kernel[0] * g->kernel[1] * g->kernel[2];
   plan->kpad = (int)(ceil_div(plan->k, plan->kc) * plan->kc);
@@ -996,7 +1105,7 @@ extern "C" int eco_conv_plan_create_batched(const eco_conv_geom* g, int32_t num_
   plan->ksplit = 1;
   plan->split_tiles = 0;
   plan->ws_bytes = 0;
-  {
+  if (plan->mode != ECO_CONV_MODE_POINT) {
     const long s_out = (long)g->out[0] * g->out[1] * g->out[2];
     const long ntot = (long)g->n * s_out;
     const long mblocks = ceil_div(g->cout, bm);
@@ -1067,7 +1176,8 @@ extern "C" int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan
   const int K = g->cin * taps;
   ECO_REQUIRE(plan->k == K && plan->kpad >= K && plan->mpad >= g->cout, "conv pack: plan does not match geometry");
   ECO_REQUIRE(plan->mode == ECO_CONV_MODE_TABLE ||
-                  ((plan->mode == ECO_CONV_MODE_CTAP || plan->mode == ECO_CONV_MODE_SPAN) && g->cin % plan->kc == 0),
+                  ((plan->mode == ECO_CONV_MODE_CTAP || plan->mode == ECO_CONV_MODE_SPAN || plan->mode == ECO_CONV_MODE_POINT) &&
+                   g->cin % plan->kc == 0),
               "conv pack: bad plan mode");
   const long s_in = (long)g->in[0] * g->in[1] * g->in[2];
   memset(wp, 0, sizeof(float) * (size_t)plan->wp_elems);
@@ -1096,6 +1206,25 @@ extern "C" int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan
     for (int m = 0; m < g->cout; ++m) row[(long)m * mstep] = w[(long)m * K + wk];
   }
   return ECO_OK;
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_conv_point(const ConvKernelArgs& a, hipStream_t stream) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, BMP = (BM + 63) / 64 * 64;
+  const size_t lds_bytes = sizeof(float) * 3 * 16 * (size_t)(BMP + BN);
+#ifndef ECO_EMU
+  if (lds_bytes > 64 * 1024) {
+    static thread_local bool raised = false;
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute((const void*)conv_point_kernel<TM, TN, WM, WN>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return fail(ECO_ERR_RUNTIME, "conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+      raised = true;
+    }
+  }
+#endif
+  hipLaunchKernelGGL((conv_point_kernel<TM, TN, WM, WN>), dim3(a.nblk_m * a.nblk_n), dim3(256), lds_bytes, stream, a);
+  return check_launch("eco_conv_forward");
 }
 
 template <int TM, int TN, int WM, int WN, int KC>
@@ -1158,8 +1287,17 @@ static int conv_forward_impl(const eco_conv_geom* g, const eco_conv_plan* plan, 
   a.nblk_n = (int)ceil_div(a.ntot, plan->bn);
   ECO_REQUIRE((long)a.nblk_m * plan->bm <= plan->mpad, "conv: plan mpad too small for bm");
   ECO_REQUIRE(plan->mode == ECO_CONV_MODE_TABLE ||
-                  ((plan->mode == ECO_CONV_MODE_CTAP || plan->mode == ECO_CONV_MODE_SPAN) && g->cin % plan->kc == 0),
+                  ((plan->mode == ECO_CONV_MODE_CTAP || plan->mode == ECO_CONV_MODE_SPAN || plan->mode == ECO_CONV_MODE_POINT) &&
+                   g->cin % plan->kc == 0),
               "conv: bad plan mode");
+  if (plan->mode == ECO_CONV_MODE_POINT) {
+    bool ok = plan->bn == 256 && plan->ksplit == 1 && batch == 1 && a.s_out % 4 == 0 && ((uintptr_t)x & 15) == 0 &&
+              ((uintptr_t)wp & 15) == 0 && plan->mpad % 4 == 0;
+    for (int i = 0; i < 3; ++i) ok = ok && g->kernel[i] == 1 && g->stride[i] == 1 && g->pad[i] == 0;
+    ECO_REQUIRE(ok, "conv: the point kernel needs a 1x1 stride-1 unpadded geometry with a plane size that is a multiple of 4 "
+                    "and 16-byte aligned operands");
+    ECO_REQUIRE((long)(a.nblk_m - 1) * plan->bm + (plan->bm + 63) / 64 * 64 <= plan->mpad, "conv: plan mpad too small for the point kernel");
+  }
   if (plan->mode == ECO_CONV_MODE_SPAN) {
     bool ok = g->kernel[1] == 3 && g->kernel[2] == 3 && g->pad[1] == 1 && g->pad[2] == 1 &&
               (g->kernel[0] == 1 || g->kernel[0] == 3) && g->pad[0] == g->kernel[0] / 2 &&
@@ -1192,6 +1330,15 @@ static int conv_forward_impl(const eco_conv_geom* g, const eco_conv_plan* plan, 
   host_split_layout(g, mode, plan->bn, plan->ksplit, &a.col_long0, &a.col_long1, &a.ns_short, &a.ns_long);
   int rc = ECO_OK;
   hipStream_t s = (hipStream_t)stream;
+  if (mode == ECO_CONV_MODE_POINT) {
+    switch (plan->bm) {
+      case 128: return launch_conv_point<4, 2, 1, 4>(a, s);
+      case 96: return launch_conv_point<3, 2, 1, 4>(a, s);
+      case 64: return launch_conv_point<2, 2, 1, 4>(a, s);
+      case 32: return launch_conv_point<1, 2, 1, 4>(a, s);
+      default: return fail(ECO_ERR_INVALID, "conv: unsupported point-kernel tile bm=%d", plan->bm);
+    }
+  }
   switch (plan->bm) {
     case 128:
       ECO_REQUIRE(plan->bn == 128 || plan->bn == 256, "conv: bad plan");

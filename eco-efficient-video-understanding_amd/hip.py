@@ -102,6 +102,9 @@ _CONV_TILES = {(128, 128): (2, 2, 2, 2), (128, 256): (2, 4, 2, 2), (96, 256): (3
 
 def conv_kernel_name(plan: ConvPlan) -> str:
     """Name of the device kernel eco_conv_forward launches for this plan, as rocprofv3 prints it."""
+    if plan.mode == 3:
+        tm, tn, wm, wn = {128: (4, 2, 1, 4), 96: (3, 2, 1, 4), 64: (2, 2, 1, 4), 32: (1, 2, 1, 4)}[plan.bm]
+        return f"eco::conv_point_kernel<{tm}, {tn}, {wm}, {wn}>"
     tm, tn, wm, wn = _CONV_TILES[(plan.bm, plan.bn)]
     if plan.mode == 2:
         return f"eco::conv_span_kernel<{tm}, {tn}, {wm}, {wn}>"

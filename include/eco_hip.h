@@ -45,6 +45,7 @@ extern "C" {
 #define ECO_CONV_MODE_TABLE 0 /* k = c*taps + tap, per-k gather table (any cin)            */
 #define ECO_CONV_MODE_CTAP 1  /* k = (c/kc*taps + tap)*kc + c%kc, one tap per stage (cin%kc==0) */
 #define ECO_CONV_MODE_SPAN 2  /* CTAP order; stride-1 same-size (kd)x3x3 convs stage input spans in LDS */
+#define ECO_CONV_MODE_POINT 3 /* CTAP order; 1x1 stride-1 convs as a GEMM staged by LDS-DMA              */
 
 #define ECO_POOL_MAX 0
 #define ECO_POOL_AVE 1

@@ -508,3 +508,32 @@ def test_batched_conv_equals_separate_launches(backend):
     for b in range(nb):
         ref = orc.convolution(xs[b], wsn[b], None, (3, 1, 1), (1, 1, 1), (1, 0, 0))
         assert relerr(got[b], ref) < TOL
+
+
+# 1x1 stride-1 convolutions on the LDS-DMA GEMM kernel (ECO_CONV_MODE_POINT): reached at emulator sizes by planning for
+# a one-CU device (the rule wants >= 4 * num_cu tiles of 256 positions)
+POINT = [  # n, cin, cout, in_sp
+    (3, 32, 64, (20, 20)),       # bm 64; 1200 positions: last tile ragged, tiles straddle images
+    (2, 48, 96, (24, 24)),       # bm 96 (weight rows padded to 128 in LDS), three stages
+    (5, 16, 160, (16, 16)),      # two M-blocks of 96, the second ragged; one stage
+    (2, 64, 32, (3, 16, 16)),    # 3-D blob, bm 32
+    (9, 32, 128, (12, 12)),      # bm 128 (4x2 wave tiles)
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,insp", POINT, ids=[f"p{i}" for i in range(len(POINT))])
+@pytest.mark.parametrize("mode", ["plain", "fused", "concat"])
+def test_conv_point_kernel(backend, n, cin, cout, insp, mode):
+    one = (1,) * len(insp)
+    plan = run_conv(backend, n, cin, cout, insp, one, one, (0,) * len(insp), mode=mode, seed=9, num_cu=1)
+    assert plan.mode == 3 and plan.bn == 256 and plan.ksplit == 1
+
+
+def test_conv_point_kernel_eligibility(backend):
+    lib = backend.lib
+    # default device: the inception 1x1 layers of the benchmark qualify, a single clip's 7x7 layer does not
+    assert lib.conv_plan(hip.conv_geom(512, 192, 64, (28, 28), (1, 1), (1, 1), (0, 0), (28, 28))).mode == 3
+    assert lib.conv_plan(hip.conv_geom(16, 1024, 352, (7, 7), (1, 1), (1, 1), (0, 0), (7, 7))).mode == 1
+    # plane size not a multiple of 4 (a lane's four positions would straddle images), strided 1x1: gather kernel
+    assert lib.conv_plan(hip.conv_geom(64, 32, 64, (7, 7), (1, 1), (1, 1), (0, 0), (7, 7)), 1).mode == 1
+    assert lib.conv_plan(hip.conv_geom(64, 32, 64, (8, 8), (1, 1), (2, 2), (0, 0), (4, 4)), 1).mode == 1
