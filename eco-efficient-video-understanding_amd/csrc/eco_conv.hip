@@ -890,33 +890,26 @@ __global__ __launch_bounds__(256, 2) void conv_point_kernel(const ConvKernelArgs
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, l31 = lane & 31;
 
-  // A workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... as ONE continuous stage stream (the grid is
-  // sized to the resident slots): with 12-36 stages per tile the pipeline fill and the epilogue of every tile would
-  // otherwise be exposed; here the first stages of the next tile are in flight under the last stages and the
-  // stores of the current one.  (Stores share vmcnt with the DMA pieces and may retire out of order with them;
-  // the counted wait stays sufficient because DMA pieces retire in order among themselves.)
-  const int ntiles = a.nblk_m * a.nblk_n;
+  const int tile = xcd_remap((int)blockIdx.x, a.nblk_m * a.nblk_n);
+  const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
+  const int m0 = mblk * BM, n0 = nblk * BN;
   const int nstages = a.cin / KC;
-  const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
 
-  // the tile whose stages are being issued: this lane's four positions n0 + 4*lane .. +3 (one image: s_out % 4 == 0)
-  int l_tile = (int)blockIdx.x, l_stage = 0, l_m0 = 0;
-  long lane_base = 0;
-  auto enter_tile = [&]() {
-    const int t = l_tile < ntiles ? l_tile : ntiles - 1;
-    l_m0 = (t % a.nblk_m) * BM;
-    const int n = (t / a.nblk_m) * BN + 4 * lane;
+  // this lane's four positions n0 + 4*lane .. +3 (one image: s_out % 4 == 0)
+  long lane_base;
+  {
+    const int n = n0 + 4 * lane;
     const int nn = n < a.ntot ? n : 0;          // past the end: any valid address (those columns are never stored)
     const int img = nn / a.s_out, sp = nn - img * a.s_out;
     lane_base = (long)img * a.img_stride_in + sp;
-  };
-  enter_tile();
+  }
+  int l_stage = 0;
   auto issue_stage = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < A_PER_WAVE; ++q) {
       const int i = (wave * A_PER_WAVE + q) * 64 + lane;           // float4 index in the [KC][BMP] tile
       const int row = i / (BMP / 4), c4 = i - row * (BMP / 4);
-      glds16((const uint4*)(a.wp + (long)(l_stage * KC + row) * a.mpad + l_m0 + c4 * 4),
+      glds16((const uint4*)(a.wp + (long)(l_stage * KC + row) * a.mpad + m0 + c4 * 4),
              (uint4*)(As + buf * KC * BMP) + (wave * A_PER_WAVE + q) * 64);
     }
 #pragma unroll
@@ -924,7 +917,7 @@ __global__ __launch_bounds__(256, 2) void conv_point_kernel(const ConvKernelArgs
       const int row = wave * B_PER_WAVE + q;
       glds16((const uint4*)(a.x + lane_base + (long)(l_stage * KC + row) * a.s_in), (uint4*)(Bs + (buf * KC + row) * BN));
     }
-    if (++l_stage == nstages) { l_stage = 0; l_tile += (int)gridDim.x; enter_tile(); }
+    ++l_stage;
   };
 
   f32x16 acc[TM][TN];
@@ -952,32 +945,18 @@ __global__ __launch_bounds__(256, 2) void conv_point_kernel(const ConvKernelArgs
     }
   };
 
-  const int total = my_tiles * nstages;
-  if (total > 0) {
-    issue_stage(0);
-    if (total > 1) issue_stage(1);
-    int buf = 0, s_in_tile = 0, tile = (int)blockIdx.x;
-    for (int f = 0; f < total; ++f) {
-      if (f + 1 < total) wait_dma_all_but<P>(); else wait_dma_all_but<0>();
-      wg_barrier_nodrain();
-      if (f + 2 < total) issue_stage(buf == 0 ? 2 : buf - 1);
-      sched_fence();
-      compute(buf);
-      buf = buf == 2 ? 0 : buf + 1;
-      if (++s_in_tile == nstages) {
-        const int m0 = (tile % a.nblk_m) * BM, n0 = (tile / a.nblk_m) * BN;
-        conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-        s_in_tile = 0;
-        tile += (int)gridDim.x;
-      }
-    }
+  issue_stage(0);
+  if (nstages > 1) issue_stage(1);
+  int buf = 0;
+  for (int s = 0; s < nstages; ++s) {
+    if (s + 1 < nstages) wait_dma_all_but<P>(); else wait_dma_all_but<0>();
+    wg_barrier_nodrain();
+    if (s + 2 < nstages) issue_stage(buf == 0 ? 2 : buf - 1);
+    sched_fence();
+    compute(buf);
+    buf = buf == 2 ? 0 : buf + 1;
   }
+  conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
 }
 
 static int validate_geom(const eco_conv_geom* g) {
@@ -1092,7 +1071,6 @@ extern "C" int eco_conv_plan_create_batched(const eco_conv_geom* g, int32_t num_
     if (batch > 1 && g->cout >= 256) plan->bn = 256;
   }
   plan->kc = 16;
-  plan->reserved = 0;
   plan->mode = (g->cin % plan->kc == 0) ? ECO_CONV_MODE_CTAP : ECO_CONV_MODE_TABLE;
   {
     // stride-1, same-size (kd) x 3 x 3 convolutions stage input *spans* instead of per-tap gathers
@@ -1107,7 +1085,7 @@ extern "C" int eco_conv_plan_create_batched(const eco_conv_geom* g, int32_t num_
     for (int i = 0; i < 3; ++i) point = point && g->kernel[i] == 1 && g->stride[i] == 1 && g->pad[i] == 0;
     const long s_out_ = (long)g->out[0] * g->out[1] * g->out[2];
     point = point && s_out_ % 4 == 0 && (long)g->n * s_out_ >= 4L * num_cu * 256;
-    if (point) { plan->mode = ECO_CONV_MODE_POINT; plan->bn = 256; plan->reserved = 2 * num_cu; }   // resident workgroup slots
+    if (point) { plan->mode = ECO_CONV_MODE_POINT; plan->bn = 256; }
   }
   plan->k = g->cin * g->kernel[0] * g->kernel[1] * g->kernel[2];
   plan->kpad = (int)(ceil_div(plan->k, plan->kc) * plan->kc);
@@ -1245,12 +1223,7 @@ static int launch_conv_point(const ConvKernelArgs& a, hipStream_t stream) {
     }
   }
 #endif
-  // persistent over tiles: as many workgroups as the device keeps resident (LDS-bound: 2 per CU; the plan's
-  // figure), at most one per tile
-  int grid = a.batch;   // the point kernel has no batched form: the field carries the plan's slot count
-  if (grid < 1) grid = 2 * current_device_num_cu();
-  if (grid > a.nblk_m * a.nblk_n) grid = a.nblk_m * a.nblk_n;
-  hipLaunchKernelGGL((conv_point_kernel<TM, TN, WM, WN>), dim3(grid), dim3(256), lds_bytes, stream, a);
+  hipLaunchKernelGGL((conv_point_kernel<TM, TN, WM, WN>), dim3(a.nblk_m * a.nblk_n), dim3(256), lds_bytes, stream, a);
   return check_launch("eco_conv_forward");
 }
 
@@ -1358,7 +1331,6 @@ static int conv_forward_impl(const eco_conv_geom* g, const eco_conv_plan* plan, 
   int rc = ECO_OK;
   hipStream_t s = (hipStream_t)stream;
   if (mode == ECO_CONV_MODE_POINT) {
-    a.batch = plan->reserved;
     switch (plan->bm) {
       case 128: return launch_conv_point<4, 2, 1, 4>(a, s);
       case 96: return launch_conv_point<3, 2, 1, 4>(a, s);

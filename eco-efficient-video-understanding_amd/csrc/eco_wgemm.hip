@@ -40,7 +40,6 @@ struct WGemmArgs {
   int Q, NB, ntot;    // row length / plane size / output positions (all in positions)
   int mblocks, bmp, nblk_n;
   long v_pstride, u_pstride, m_pstride;   // floats between points
-  int points_in_wg;   // 1: blockIdx.y is the transform point; 36: the workgroup walks all points of its tile
 };
 
 // The three buffers of a stage: A [8][BMP][2], B [8][BN][2] floats.
@@ -72,20 +71,15 @@ __global__ __launch_bounds__(256, 2) void wgemm_kernel(const WGemmArgs a) {
   const int tile = xcd_remap((int)blockIdx.x - slice * ntiles, ntiles);
   const int mblk = tile % a.mblocks, nblk = tile / a.mblocks;
   const int n0 = nblk * BN;
+  const int pt = (int)blockIdx.y;
   const int s_begin = (int)((long)slice * a.nstages / a.ksplit);
   const int s_end = (int)((long)(slice + 1) * a.nstages / a.ksplit);
-  // Short reductions (the 2-D layers: 4-6 stages per point) would spend their time filling and draining the DMA
-  // pipeline once per tile; there one workgroup keeps its (M-block, N-tile) and walks the 36 transform points as
-  // ONE continuous stage stream: the first stages of point p+1 are in flight under the last stages and the stores
-  // of point p.  (The stores share vmcnt with the DMA pieces and may retire out of order with them; the counted
-  // wait stays sufficient because DMA pieces retire in order among themselves -- it can only over-wait.)
-  const int npts = a.points_in_wg;
-  const int pt0 = npts == 1 ? (int)blockIdx.y : 0;
 
-  int l_stage = s_begin, l_pt = pt0;
+  const float* const vp = a.v + (long)pt * a.v_pstride;
+  const float* const up = a.u + (long)pt * a.u_pstride + (long)mblk * a.nstages * (kWgKp * BMP * 2);
+
+  int l_stage = s_begin;
   auto issue_stage = [&](int buf) {
-    const float* const vp = a.v + (long)l_pt * a.v_pstride;
-    const float* const up = a.u + (long)l_pt * a.u_pstride + (long)mblk * a.nstages * (kWgKp * BMP * 2);
     const int cg = l_stage / a.kd, dz = l_stage - cg * a.kd;
     // weights: the stage's block is contiguous -- piece i of the wave = 64 lanes x 16 B
 #pragma unroll
@@ -102,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void wgemm_kernel(const WGemmArgs a) {
       for (int q = 0; q < BN / 128; ++q)
         glds16((const uint4*)src + q * 64 + lane, Bw + buf * B_VEC + row * (BN / 2) + q * 64);
     }
-    if (++l_stage == s_end) { l_stage = s_begin; ++l_pt; }
+    ++l_stage;
   };
 
   f32x16 acc[TM][TN];
@@ -140,39 +134,33 @@ __global__ __launch_bounds__(256, 2) void wgemm_kernel(const WGemmArgs a) {
     }
   };
 
-  const int nst = s_end - s_begin;
-  const int total = npts * nst;
-  const int mw = mblk * BM + wm * TM * 32, nw = n0 + wn * TN * 32;
-  if (total > 0) {
+  if (s_begin < s_end) {
     issue_stage(0);
-    if (total > 1) issue_stage(1);
-    int buf = 0, s_in_pt = 0, pt = pt0;
-    for (int f = 0; f < total; ++f) {
-      if (f + 1 < total) wait_dma_all_but<P>(); else wait_dma_all_but<0>();
+    if (s_begin + 1 < s_end) issue_stage(1);
+    int buf = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+      if (s + 1 < s_end) wait_dma_all_but<P>(); else wait_dma_all_but<0>();
       wg_barrier_nodrain();
-      if (f + 2 < total) issue_stage(buf == 0 ? 2 : buf - 1);   // (buf + 2) % 3: last read before this barrier
+      if (s + 2 < s_end) issue_stage(buf == 0 ? 2 : buf - 1);   // (buf + 2) % 3: last read before this barrier
       sched_fence();
       compute(buf);
       buf = buf == 2 ? 0 : buf + 1;
-      if (++s_in_pt == nst) {
-        // raw store: M[p][slice][channel][position], lane = position (128 contiguous bytes per half-wave)
-        float* const mo = a.m + (long)pt * a.m_pstride + (long)slice * a.cout * a.ntot;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int n = nw + j * 32 + l31;
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int ch = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-              if (n < a.ntot && ch < a.cout) st(mo + (long)ch * a.ntot + n, acc[i][j][r]);
-              acc[i][j][r] = 0.0f;
-            }
-        }
-        s_in_pt = 0;
-        ++pt;
-      }
     }
+  }
+  // raw store: M[p][slice][channel][position], lane = position (128 contiguous bytes per half-wave)
+  float* const mo = a.m + (long)pt * a.m_pstride + (long)slice * a.cout * a.ntot;
+  const int mw = mblk * BM + wm * TM * 32, nw = n0 + wn * TN * 32;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = nw + j * 32 + l31;
+    if (n >= a.ntot) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (ch < a.cout) st(mo + (long)ch * a.ntot + n, acc[i][j][r]);
+      }
   }
 }
 
@@ -454,10 +442,6 @@ extern "C" int eco_wgemm_plan_create(int32_t n, int32_t cin, int32_t cout, int32
   }
   const long nb = (long)n * th * tw;
   const int pd = kd / 2;
-  // short reductions with enough tiles to fill the device on their own: one workgroup per tile walks the 36 points
-  // as one continuous stage stream (see wgemm_kernel)
-  plan->walk_points = (plan->nstages / plan->ksplit <= 12 &&
-                       ceil_div(cout, bm) * ceil_div(nb * d, plan->bn) * plan->ksplit >= 2L * num_cu) ? 1 : 0;
   plan->mblocks = (int)ceil_div(cout, bm);
   plan->bmp = (bm + 63) / 64 * 64;
   plan->q = (int64_t)(d + 2 * pd) * nb;
@@ -525,7 +509,7 @@ static int launch_wgemm(const WGemmArgs& a, int points, hipStream_t stream) {
   }
 #endif
   const int grid = a.mblocks * a.nblk_n * a.ksplit;
-  hipLaunchKernelGGL((wgemm_kernel<TM, TN, WM, WN>), dim3(grid, a.points_in_wg == 1 ? points : 1), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((wgemm_kernel<TM, TN, WM, WN>), dim3(grid, points), dim3(256), lds, stream, a);
   return check_launch("eco_wgemm_forward");
 }
 
@@ -545,7 +529,6 @@ extern "C" int eco_wgemm_forward(const eco_wgemm_plan* plan, const float* v, con
   a.v_pstride = (long)a.cp * plan->q * 2;
   a.u_pstride = (long)plan->mblocks * plan->nstages * kWgKp * plan->bmp * 2;
   a.m_pstride = (long)plan->ksplit * plan->cout * a.ntot;
-  a.points_in_wg = plan->walk_points ? plan->points : 1;
   hipStream_t s = (hipStream_t)stream;
   if (plan->bn == 256) {
     switch (plan->bm) {

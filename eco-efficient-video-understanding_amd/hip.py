@@ -60,7 +60,7 @@ class WGemmPlan(C.Structure):
     _fields_ = [("n", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("d", C.c_int32), ("th", C.c_int32),
                 ("tw", C.c_int32), ("kd", C.c_int32), ("points", C.c_int32), ("bm", C.c_int32), ("bn", C.c_int32),
                 ("nstages", C.c_int32), ("ksplit", C.c_int32), ("mblocks", C.c_int32), ("bmp", C.c_int32),
-                ("walk_points", C.c_int32), ("reserved", C.c_int32), ("q", C.c_int64), ("u_elems", C.c_int64), ("v_elems", C.c_int64), ("m_elems", C.c_int64)]
+                ("q", C.c_int64), ("u_elems", C.c_int64), ("v_elems", C.c_int64), ("m_elems", C.c_int64)]
 
 
 class View(C.Structure):

@@ -92,7 +92,7 @@ typedef struct eco_conv_plan {
   int32_t ksplit;     /* >1: the last split_tiles output tiles have their reduction cut into ksplit slices */
   int64_t ws_bytes;   /* bytes of device scratch eco_conv_forward needs for this plan (0 if none) */
   int32_t split_tiles; /* 0 (no split-K), all tiles (few-tile layers) or the tail of a many-tile launch */
-  int32_t reserved;    /* ECO_CONV_MODE_POINT: resident workgroup slots the persistent launch is sized to     */
+  int32_t reserved;
 } eco_conv_plan;
 
 /* Strided view of an N,C,[D,]H,W output (or residual) tensor.  Element
@@ -281,7 +281,6 @@ typedef struct eco_wgemm_plan {
   int32_t nstages;                 /* (cin/16) * kd stages of 16 reduction elements                           */
   int32_t ksplit;                  /* split-K slices (rows of m)                                              */
   int32_t mblocks, bmp;            /* ceil(cout/bm); bm rounded up to 64 (rows of a packed weight block)      */
-  int32_t walk_points, reserved;   /* 1: one workgroup per tile walks all points (short reductions)           */
   int64_t q;                       /* positions per channel-pair row of v: (d + 2*(kd/2)) * n*th*tw           */
   int64_t u_elems, v_elems, m_elems; /* floats in up / v (with read slack) / m                                */
 } eco_wgemm_plan;
