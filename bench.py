@@ -272,23 +272,27 @@ def cpu_baseline(args, gen, N, frames, params, logits):
             refs.append(eco_oracle.forward(specs, params, {"data": x1}, conv_impl=conv_impl)[out_name])
             t_cpu += time.perf_counter() - t1
             done += k
-            if not args.cpu_clips and t_cpu >= budget_s:
+            if not args.cpu_clips and budget_s > 0 and t_cpu >= budget_s:
                 break
         return done, t_cpu, np.concatenate(refs, 0)
 
     variants = {}
     max_clips = args.cpu_clips or 8
+    blas_threads = min(cores, 64)   # SciPy's OpenBLAS is built for at most 64 threads
     if have_ref:
-        eco_ref.set_blas_threads(cores)
+        eco_ref.set_blas_threads(blas_threads)
         d, t, ref = run(lambda *a: eco_ref.convolution(*a, image_threads=1), 10.0, max_clips)
-        variants["caffe_cost"] = dict(clips_per_s=round(d / t, 4), clips=d, seconds=round(t, 2), blas_threads=cores,
+        variants["caffe_cost"] = dict(clips_per_s=round(d / t, 4), clips=d, seconds=round(t, 2), blas_threads=blas_threads,
                                       kind="reference im2col (compiled from util/im2col.cpp) + OpenBLAS sgemm, images in sequence")
-        d2, t2, _ = run(lambda *a: eco_ref.convolution(*a, image_threads=cores), 8.0, max_clips, clips_at_once=min(8, max_clips))
+        # throughput form: a whole GPU batch of clips at once, its images spread over the cores (the 3-D trunk has
+        # one "image" per clip, so fewer clips would leave most cores idle there)
+        par = args.cpu_clips or min(32, len(frames) // N)
+        d2, t2, _ = run(lambda *a: eco_ref.convolution(*a, image_threads=cores), 0.0, par, clips_at_once=par)
         variants["image_parallel"] = dict(clips_per_s=round(d2 / t2, 4), clips=d2, seconds=round(t2, 2), blas_threads=1,
-                                          image_threads=cores, kind="same arithmetic, images spread over the cores")
+                                          image_threads=cores, kind="same arithmetic, one batch of clips at once, images spread over the cores")
     else:  # oracle/_ref not shipped: the NumPy restatement (np.matmul = OpenBLAS sgemm)
         d, t, ref = run(None, 10.0, max_clips)
-        variants["caffe_cost"] = dict(clips_per_s=round(d / t, 4), clips=d, seconds=round(t, 2), blas_threads=cores,
+        variants["caffe_cost"] = dict(clips_per_s=round(d / t, 4), clips=d, seconds=round(t, 2), blas_threads=blas_threads,
                                       kind="NumPy restatement (im2col_nd + np.matmul), images in sequence")
     torch.set_num_threads(cores)
     d3, t3, _ = run(torch_conv, 6.0, max_clips, clips_at_once=min(4, max_clips))
@@ -299,7 +303,7 @@ def cpu_baseline(args, gen, N, frames, params, logits):
     cpu = {"value": cc["clips_per_s"], "unit": "clips/sec", "cores": cores,
            "kind": "reference" if have_ref else "port",
            "sample": f"{cc['clips']} clip(s) of the same workload (num_segments={N}; the first clips of rank 0's batch), "
-                     f"{cc['seconds']} s; conv = {cc['kind']} with {cores} BLAS threads, other layers NumPy "
+                     f"{cc['seconds']} s; conv = {cc['kind']} with {blas_threads} BLAS threads, other layers NumPy "
                      f"(oracle/eco_oracle.py); caffe_3d itself cannot be built here (DESIGN.md section 4)",
            "gflops": round(cc["clips_per_s"] * flops_clip / 1e9, 1), "variants": variants}
     done = cc["clips"]

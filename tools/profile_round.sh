@@ -12,6 +12,13 @@ rocprofv3 --pmc FETCH_SIZE -d $PWD/$OUT/pmc_fetch -o bench --output-format csv -
 rocprofv3 --pmc WRITE_SIZE -d $PWD/$OUT/pmc_write -o bench --output-format csv -- $B --steps 2 --warmup 1 > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA -d $PWD/$OUT/pmc_sq -o bench --output-format csv -- $B --steps 2 --warmup 1 > $OUT/pmc_sq.log 2>&1
 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
+# the other BASELINE configurations: configs[4] (bf16, N=32) with its kernel trace, configs[3] (ECO-Full)
+rocprofv3 --kernel-trace --stats -d $PWD/$OUT/trace_bf16 -o bench --output-format csv -- $B --segments 32 --dtype bf16 --steps 10 --warmup 3 > $OUT/trace_bf16.log 2>&1
+python bench.py --segments 32 --dtype bf16 > $OUT/bench_line_bf16.json 2> $OUT/bench_line_bf16.err
+python bench.py --variant full > $OUT/bench_line_full.json 2> $OUT/bench_line_full.err
+python tools/eco_time.py --iterations 5 > $OUT/eco_time.txt 2>&1
+python tools/eco_time.py --iterations 5 --segments 32 --dtype bf16 > $OUT/eco_time_bf16.txt 2>&1
+python tools/eco_time.py --iterations 5 --variant full > $OUT/eco_time_full.txt 2>&1
 find $OUT -name "*.csv" | head -20
 # keep only what the summariser reads (the merge back is capped at 64 MiB)
 find $OUT -name "*agent_info*" -delete

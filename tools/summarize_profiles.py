@@ -34,6 +34,21 @@ def main():
             f.write("%s,%s,%.3f,%.1f,%.1f,%.1f,%s\n" % (short(r["Name"]).replace(",", ";"), r["Calls"],
                     float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3,
                     float(r["MaxNs"]) / 1e3, r["Percentage"]))
+    bf = os.path.join(src, "trace_bf16", "bench_kernel_stats.csv")
+    if os.path.exists(bf):
+        with open(os.path.join(out_dir, f"{tag}_bf16_kernel_stats.csv"), "w") as f:
+            f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --segments 32 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline\n")
+            f.write("kernel,calls,total_ms,avg_us,min_us,max_us,percent\n")
+            for r in csv.DictReader(open(bf)):
+                f.write("%s,%s,%.3f,%.1f,%.1f,%.1f,%s\n" % (short(r["Name"]).replace(",", ";"), r["Calls"],
+                        float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3,
+                        float(r["MaxNs"]) / 1e3, r["Percentage"]))
+    for nm in ("bench_line.json", "bench_line_bf16.json", "bench_line_full.json", "eco_time.txt", "eco_time_bf16.txt",
+               "eco_time_full.txt"):
+        p = os.path.join(src, nm)
+        if os.path.exists(p) and os.path.getsize(p):
+            with open(p) as fi, open(os.path.join(out_dir, f"{tag}_{nm}"), "w") as fo:
+                fo.write("".join(l for l in fi if "amdgpu.ids" not in l))
     traffic = collections.defaultdict(dict)
     for nm, key in (("pmc_fetch", "fetch_kib"), ("pmc_write", "write_kib")):
         p = os.path.join(src, nm, "bench_counter_collection.csv")
