@@ -71,3 +71,26 @@ def test_shard_range():
     # single process: gather is the identity, no process group needed
     t = torch.arange(6.0).reshape(2, 3)
     assert eco_dist.all_gather_logits(t) is t
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N>1 path end to end on a 1-GPU box: two ranks launched exactly as the driver launches them
+    (torch.distributed.run, one process per rank), both on cuda:0 over gloo (ECO_BENCH_DEVICE / ECO_BENCH_BACKEND
+    exist for this test only; RCCL refuses two ranks on one device).  One JSON line from rank 0 with the whole-job
+    aggregate, the rank count the communicator reports, and weak scaling."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ECO_BENCH_DEVICE="0", ECO_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--clips-per-gpu", "2", "--segments", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 4
+    assert line["config"]["collective_ranks"] == 2 and line["config"]["collective_backend"] == "gloo"
+    assert line["value"] > 0 and line["cpu_baseline"] is None and "step_frac" in line["roofline"]
