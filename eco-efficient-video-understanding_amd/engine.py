@@ -136,6 +136,7 @@ class Engine:
             raise ValueError("winograd must be False, True, 2 or 4")
         self.winograd = winograd
         self.wgemm = True          # F(4x4,3x3) GEMMs on the dedicated dense kernel (False: round-1 gather-kernel route)
+        self.stem = True           # conv1 + BN + ReLU + pool1 as one launch (False: conv kernel + pooling kernel)
         self.num_cu = num_cu       # None = the device's 256 CUs (tests shrink it to reach split-K paths)
         self.params: Dict[str, List[np.ndarray]] = {}
         self._param_dev: Dict[str, dict] = {}    # layer name -> device-side state
@@ -204,6 +205,12 @@ class Engine:
                 self.alloc.upload(st["ktab"], kt)
                 if L.geom["bias_term"]:
                     self.alloc.upload(st["bias"], blobs[1])
+                if "stem_wp" in st:   # conv1 + pool1 as one launch (csrc/eco_stem.hip)
+                    swp = np.empty(74 * L.geom["cout"] * 2, np.float32)
+                    sko = np.empty(148, np.int32)
+                    self.lib.stem_pack_weights(w.ctypes.data, L.geom["cout"], swp.ctypes.data, sko.ctypes.data)
+                    self.alloc.upload(st["stem_wp"], swp)
+                    self.alloc.upload(st["stem_koff"], sko)
                 wn = st.get("wino")
                 if wn is not None and wn.get("kind") == "wgemm":   # u[p] = (G g G^T)[p] packed for the dense GEMM kernel
                     cout, cin, kd = L.geom["cout"], L.geom["cin"], wn["kd"]
@@ -275,6 +282,9 @@ class Engine:
                         st["bias"] = self.alloc.empty(g["cout"], np.float32)
                 st["geom"], st["plan"] = geom, plan
                 st.pop("wino", None) if not self._wino_eligible(L) else self._plan_wino(L, st)
+                if self._stem_geometry(L) and "stem_wp" not in st:
+                    st["stem_wp"] = self.alloc.empty(74 * g["cout"] * 2, np.float32)
+                    st["stem_koff"] = self.alloc.empty(148, np.int32)
                 self._dirty_params.add(L.name)  # the gather table depends on the input dims
             elif L.type == "BN" and st.get("size") != L.geom["channels"]:
                 st["scale"] = self.alloc.empty(L.geom["channels"], np.float32)
@@ -568,6 +578,41 @@ class Engine:
                   {"kernel": f"eco::wino_output_kernel<{M}>", "flops": 0,
                    "bytes": 4 * P * tout + nbytes - 4 * (n * cin * D * H * W + 9 * kd * cin * cout)})
 
+    # -- the stem: conv1_7x7_s2 + BN + ReLU + pool1_3x3_s2 as one launch (csrc/eco_stem.hip) --
+    def _stem_geometry(self, L: LayerSpec) -> bool:
+        g = L.geom
+        return (self.fuse and not self.dt and self.stem and len(L.bottom_shapes[0]) == 4 and g["cin"] == 3 and
+                g["cout"] in (32, 64) and list(g["kernel"]) == [7, 7] and list(g["stride"]) == [2, 2] and
+                list(g["pad"]) == [3, 3] and min(L.top_shapes[0][2:]) >= 3)
+
+    def _try_fuse_stem(self, i, L, ep, act_blob, label, layers, consumers, outputs, absorbed) -> bool:
+        """conv (stem geometry) + BN + ReLU whose activated blob feeds only a MAX 3x3 stride-2 unpadded Pooling:
+        one launch writes the pooled blob; the conv's own output is never stored."""
+        if act_blob is None or act_blob in outputs or ep.raw.ptr or ep.residual.ptr or not self._stem_geometry(L):
+            return False
+        cs = [c for c in consumers.get(act_blob, []) if absorbed.get(c) != L.name]
+        if len(cs) != 1 or layers[cs[0]].type != "Pooling":
+            return False
+        Lp = layers[cs[0]]
+        gp = Lp.geom
+        if gp["method"] != "MAX" or list(gp["kernel"]) != [3, 3] or list(gp["stride"]) != [2, 2] or any(gp["pad"]):
+            return False
+        st = self._param_dev[L.name]
+        n, _, H, W = L.bottom_shapes[0]
+        cout = L.geom["cout"]
+        self._materialize(Lp.tops[0], Lp.top_shapes[0])
+        absorbed[cs[0]] = L.name
+        self.fused_away[act_blob] = f"only exists inside the fused stem launch {L.name}+{Lp.name}"
+        x, y = self._ptr(L.bottoms[0]), self._ptr(Lp.tops[0])
+        wp, ko = self.alloc.ptr(st["stem_wp"]), self.alloc.ptr(st["stem_koff"])
+        bias, sc, sh, relu = ep.bias, ep.bn_scale, ep.bn_shift, ep.relu
+        lib = self.lib
+        n_conv = _prod(L.top_shapes[0])
+        self._add(i, f"{label}+{Lp.name}", lambda s: lib.stem_forward(x, wp, ko, bias, sc, sh, relu, y, n, H, W, cout, s),
+                  {"kernel": "eco::stem_kernel", "flops": 2 * n_conv * 147,
+                   "bytes": 4 * (_prod(L.bottom_shapes[0]) + 147 * cout + _prod(Lp.top_shapes[0]))})
+        return True
+
     # -- blocked bf16-MFMA path (csrc/eco_blocked.hip) --------------------------------
     def _plan_blocked_conv(self, L: LayerSpec, st: dict, geom) -> None:
         g = L.geom
@@ -784,6 +829,9 @@ class Engine:
             ep.raw = self._view(value, cout, S)
         else:
             self.fused_away[value] = f"only exists inside the fused epilogue of {L.name}"
+        # 3b. the stem: conv1 + BN + ReLU + pool1 as one launch
+        if self._try_fuse_stem(i, L, ep, act_blob, label, layers, consumers, outputs, absorbed):
+            return
         # 4. activated output and its destination
         if act_blob is not None:
             dest = self._act_destination(act_blob, L, layers, consumers, outputs, absorbed, concat_skip)

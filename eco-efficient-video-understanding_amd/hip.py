@@ -21,7 +21,7 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 DT_BF16 = 1
 DT_F32X3 = 3
 
@@ -199,6 +199,9 @@ _SIGNATURES = {
                                        C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "eco_softmax_loss_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                            C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "eco_stem_pack_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "eco_stem_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                   C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "eco_wgemm_plan_create": (C.c_int, [C.c_int32] * 9 + [C.POINTER(WGemmPlan)]),
     "eco_wgemm_pack_weights": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p]),
     "eco_wino_input_pk_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
@@ -298,6 +301,13 @@ class EcoLib:
     def wino_output_forward(self, m: int, n: int, cout: int, d: int, h: int, w: int, tile_m: int, ep: ConvEpilogue,
                             stream=None) -> None:
         self._check(self._dll.eco_wino_output_forward(m, n, cout, d, h, w, tile_m, C.byref(ep), stream))
+
+    # -- the stem as one launch (csrc/eco_stem.hip) -----------------------------------
+    def stem_pack_weights(self, w_host: int, cout: int, wp_host: int, koff_host: int) -> None:
+        self._check(self._dll.eco_stem_pack_weights(w_host, cout, wp_host, koff_host))
+
+    def stem_forward(self, x, wp, koff, bias, bn_scale, bn_shift, relu, y, n, h, w, cout, stream=None) -> None:
+        self._check(self._dll.eco_stem_forward(x, wp, koff, bias, bn_scale, bn_shift, int(relu), y, n, h, w, cout, stream))
 
     # -- Winograd F(4x4,3x3) on the dedicated transformed-domain GEMM (csrc/eco_wgemm.hip) --
     def wgemm_plan(self, n, cin, cout, d, th, tw, kd, num_cu: Optional[int] = None) -> "WGemmPlan":

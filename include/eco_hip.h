@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 11
+#define ECO_ABI_VERSION 12
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -262,6 +262,17 @@ int eco_accuracy_forward(const float* x, const float* label, float* out, int64_t
 int eco_softmax_loss_forward(const float* x, const float* label, float* out, int64_t outer, int64_t c,
                              int64_t inner, int32_t normalize, int32_t has_ignore_label,
                              int32_t ignore_label, void* stream);
+
+/* ---- the BN-Inception stem as one launch (csrc/eco_stem.hip) ------------------------------------------------
+ * conv1_7x7_s2 (3 -> cout in {32, 64}, 7x7, stride 2, pad 3) + bias + folded BN + ReLU + pool1_3x3_s2 (MAX 3x3,
+ * stride 2, ceil rule): models_ECO_Lite/kinetics/deploy.prototxt:8-77; conv_layer.cpp:28-43, bn_layer.cpp:93-207,
+ * relu_layer.cpp:10-20, pooling_layer.cpp:131-147,199-237.  x: [n,3,h,w] fp32 -> y: [n,cout,PH,PW] with
+ * HO = (h-1)/2+1, PH = ceil((HO-3)/2)+1 (same for w); conv1's own output is never written. */
+/* HOST: w[cout][3][7][7] -> wp[74][cout][2] (k-pair interleaved, k = c*49 + ky*7 + kx) and koff[148] (upload both). */
+int eco_stem_pack_weights(const float* w, int32_t cout, float* wp, int32_t* koff);
+int eco_stem_forward(const float* x, const float* wp, const int32_t* koff, const float* bias, const float* bn_scale,
+                     const float* bn_shift, int32_t relu, float* y, int32_t n, int32_t h, int32_t w, int32_t cout,
+                     void* stream);
 
 /* ---- Winograd F(4x4,3x3) route on a dedicated transformed-domain GEMM (csrc/eco_wgemm.hip) -------------------
  *
