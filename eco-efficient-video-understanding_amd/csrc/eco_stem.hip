@@ -7,16 +7,20 @@
 //
 // As separate launches the stem cost 2.05 ms of the 17.3 ms step: conv1 is a K = 147 reduction per output (ten
 // 16-row stages of per-element gathers in the table-mode kernel: 0.46 of its floor) whose 1.64 GB output is written,
-// then read again by the pool.  Here a workgroup owns an 8 x 14 patch of POOLED outputs of one frame:
-//   * the 39 x 63 x 3 input patch it depends on (zero padded) and the whole packed weight block (74 k-pairs x cout)
-//     are loaded into LDS once -- no stage loop, no gathers from global memory inside the reduction;
+// then read again by the pool.  Here a workgroup (persistent, two per CU) walks 8 x 14 patches of POOLED outputs:
+//   * the whole packed weight block (74 k-pairs x cout) sits in LDS for the workgroup's lifetime, and the 39 x 63 x 3
+//     input patch a pooled patch depends on (zero padded) is loaded into LDS once -- the next patch's words are in
+//     flight in registers under the current reduction; no stage loop, no gathers from global memory inside it;
 //   * the 17 x 29 conv outputs under the patch (one halo row / column, 10 % extra work) are computed as a
 //     cout x 512 x 148 GEMM on v_mfma_f32_32x32x2_f32: wave w owns 128 of the 512 position columns, all channels;
 //     the B fragment of k = (c, ky, kx) for conv position (r, q) is the LDS word patch[c][2r + ky][2q + kx], i.e.
-//     a per-lane base plus a per-k offset that is wave-uniform per half (two scalars per k-pair from a table);
-//   * bias, folded BN and ReLU are applied to the accumulators, which go through LDS (reusing the operand space,
-//     32 channels at a time) so that the 3x3 stride-2 windows can be taken across lanes; only the pooled
+//     a per-lane base plus a per-k offset that every lane advances itself (k = 2*kp + half walks (c, ky, kx));
+//   * bias, folded BN and ReLU are applied to the accumulators, which go through LDS (reusing the patch's space,
+//     16 channels at a time) so that the 3x3 stride-2 windows can be taken across lanes; only the pooled
 //     cout x 8 x 14 values are stored.  conv1's output never exists in HBM.
+// Measured (512 frames of 224 x 224, warm): 1.35 ms = 65 % of the fp32-MFMA peak on the executed 139 GFLOP; the
+// first cut took 2.1 ms with its operand loads in rolled loops (one memory round trip each) and a table lookup in
+// front of every fragment read.
 // fp32 arithmetic: the same products as the reference's sgemm, summed per output in k order by the MFMA chain.
 #include <float.h>
 #include <string.h>
@@ -34,47 +38,80 @@ constexpr int kStemK = 147, kStemKP = 74;                // k = (c, ky, kx); k-p
 struct StemArgs {
   const float* x;        // [n][3][H][W]
   const float* wp;       // [74][cout][2] packed weights (k-pair interleaved), zero for k = 147
-  const int* koff;       // [148] LDS word offset of k in the input patch: c*IR*IQ + ky*IQ + kx
   const float* bias;
   const float* bn_scale;
   const float* bn_shift;
   float* y;              // [n][cout][PHo][PWo]
   int n, H, W, cout, Ho, Wo, PHo, PWo;   // conv / pooled output sizes
   int relu, tiles_h, tiles_w;
+  int total;             // patches (n * tiles_h * tiles_w); a workgroup takes patch blockIdx.x, + gridDim.x, ...
 };
 
 // TMC = cout / 32 (1 or 2 m-tiles; every wave holds all channels of its 128 columns)
 template <int TMC>
 __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
   constexpr int COUT = 32 * TMC;
-  constexpr int IN_WORDS = 3 * kStemIR * kStemIQ;        // 7371
+  constexpr int IN_ROWS = 3 * kStemIR;                   // 117 patch rows of 63 words
+  constexpr int IN_WORDS = IN_ROWS * kStemIQ;            // 7371
   constexpr int W_WORDS = kStemKP * COUT * 2;
+  constexpr int STAGE_CH = 16;                           // channels pooled per pass
   constexpr int STAGE_LD = kStemNPos + 3;                // 496: staging row of one channel
+  constexpr int XS_WORDS = STAGE_CH * STAGE_LD;          // 7936 >= IN_WORDS: the patch and the stage share it
+  static_assert(XS_WORDS >= IN_WORDS, "stage must cover the patch");
+  constexpr int XU = (IN_ROWS + 3) / 4, WU = (W_WORDS / 4 + 255) / 256;
   ECO_DYNAMIC_LDS(lds);
   float* const Xs = lds;                                 // [3][39][63]
-  float* const Ws = lds + ((IN_WORDS + 3) & ~3);         // [74][COUT][2]
-  float* const Ss = lds;                                 // staging [32][STAGE_LD] (after the reduction)
+  float* const Ss = lds;                                 // staging [16][STAGE_LD] (after the reduction)
+  float* const Ws = lds + XS_WORDS;                      // [74][COUT][2], resident for the workgroup's lifetime
+  float* const Es = Ws + W_WORDS;                        // epilogue constants [3][COUT]: bias, BN scale, BN shift
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   const int wave = uniform(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-
   const int tpf = a.tiles_h * a.tiles_w;
-  const int f = (int)blockIdx.x / tpf, t = (int)blockIdx.x - f * tpf;
-  const int by = t / a.tiles_w, bx = t - by * a.tiles_w;
-  const int r0 = 2 * kStemPH * by, q0 = 2 * kStemPW * bx;        // first conv row / column of the patch
-  const int ih0 = 2 * r0 - 3, iw0 = 2 * q0 - 3;                  // first input row / column
 
-  // ---- operands into LDS ----
-  for (int i = tid; i < IN_WORDS; i += 256) {
-    const int q = i % kStemIQ, rr = (i / kStemIQ) % kStemIR, c = i / (kStemIQ * kStemIR);
-    const int h = ih0 + rr, w = iw0 + q;
-    const bool ok = (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
-    Xs[i] = ok ? ld(a.x + (((long)f * 3 + c) * a.H + (ok ? h : 0)) * a.W + (ok ? w : 0)) : 0.0f;
+  // ---- once per workgroup: the packed weights and the epilogue's per-channel constants ----
+  {
+    float4 wv[WU];
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+      const int i = tid + 256 * u;
+      wv[u] = i < W_WORDS / 4 ? ld((const float4*)a.wp + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < 3 * COUT) {
+      const int which = tid / COUT, ch = tid - which * COUT;
+      const float* src = which == 0 ? a.bias : which == 1 ? a.bn_scale : a.bn_shift;
+      Es[tid] = src ? ld(src + ch) : (which == 1 ? 1.0f : 0.0f);
+    }
+#pragma unroll
+    for (int u = 0; u < WU; ++u)
+      if (tid + 256 * u < W_WORDS / 4) ((float4*)Ws)[tid + 256 * u] = wv[u];
   }
-  for (int i = tid; i < W_WORDS / 4; i += 256) ((float4*)Ws)[i] = ld((const float4*)a.wp + i);
-  __syncthreads();
+
+  // A wave takes whole patch rows (lane = column): the row arithmetic is scalar, a lane's address is base + lane,
+  // and every load is in flight before the first one is waited for.
+  float xv[XU];
+  auto load_patch = [&](int patch) {
+    const int f = patch / tpf, t = patch - f * tpf;
+    const int by = t / a.tiles_w, bx = t - by * a.tiles_w;
+    const int ih0 = 4 * kStemPH * by - 3, iw0 = 4 * kStemPW * bx - 3;     // first input row / column
+    const float* xf = a.x + (long)f * 3 * a.H * a.W;
+    const int w = iw0 + lane;
+    const bool wok = lane < kStemIQ && (unsigned)w < (unsigned)a.W;
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const int row = wave + 4 * u;                      // (c, rr), wave-uniform
+      const int c = row / kStemIR, h = ih0 + row - c * kStemIR;
+      const bool ok = wok && row < IN_ROWS && (unsigned)h < (unsigned)a.H;
+      xv[u] = ok ? ld(xf + ((long)c * a.H + h) * a.W + w) : 0.0f;
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int u = 0; u < XU; ++u)
+      if (lane < kStemIQ && wave + 4 * u < IN_ROWS) Xs[(wave + 4 * u) * kStemIQ + lane] = xv[u];
+  };
 
   // ---- this lane's four position columns: conv position p = wave*128 + j*32 + l31 -> patch word 2r*IQ + 2q ----
   int pbase[4];
@@ -85,62 +122,120 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
     const int r = p / kStemCQ, q = p - r * kStemCQ;
     pbase[j] = 2 * r * kStemIQ + 2 * q;
   }
-  f32x16 acc[TMC][4];
-#pragma unroll
-  for (int i = 0; i < TMC; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
+  const bool last_col_ok = wave * 128 + 96 + l31 < kStemNPos;   // only wave 3's j = 3 has padding columns
   const float* wl = Ws + 2 * l31 + half;                  // A[m = l31 (+32 i)][k = 2 kp + half]
-#pragma unroll 2
-  for (int kp = 0; kp < kStemKP; ++kp) {
-    const int k0 = ld(a.koff + 2 * kp), k1 = ld(a.koff + 2 * kp + 1);   // wave-uniform: scalar loads
-    const int ko = half ? k1 : k0;
-    float af[TMC], bf[4];
-#pragma unroll
-    for (int i = 0; i < TMC; ++i) af[i] = wl[(kp * COUT + 32 * i) * 2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bf[j] = Xs[pbase[j] + ko];
+  // pooling threads: 14 x 8 pooled positions x 2 channel phases = 224 of the 256
+  const int pw = tid % kStemPW, ph = (tid / kStemPW) % kStemPH, clo = tid / (kStemPW * kStemPH);
+  const float* const sp0 = Ss + clo * STAGE_LD + 2 * ph * kStemCQ + 2 * pw;
+  float* const sw0 = Ss + 4 * half * STAGE_LD + wave * 128 + l31;
+  const long ych = (long)a.PHo * a.PWo;
+
+  int patch = (int)blockIdx.x;
+  load_patch(patch);
+  store_patch();
+  __syncthreads();
+
+  while (true) {
+    const int next = patch + (int)gridDim.x;
+    if (next < a.total) load_patch(next);                 // in flight under the reduction below
+
+    f32x16 acc[TMC][4];
 #pragma unroll
     for (int i = 0; i < TMC; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = mfma_32x32x2(af[i], bf[j], acc[i][j]);
-  }
-  __syncthreads();   // every wave is done with Xs / Ws: the space becomes the pooling stage
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // ---- per 32 channels: epilogue into the stage, 3x3 stride-2 max over it, pooled store ----
+    // patch word offset of this lane's k = 2*kp + half = (c, ky, kx), advanced by two taps per step with plain
+    // VALU (a per-step table lookup -- scalar or LDS -- would put a memory latency in front of every fragment read;
+    // the first cut did).  k = 147 (the zero-weight padding row) re-reads the window's first tap: a word of this
+    // position's own receptive field.  Step kp + 1's fragments are read before step kp's products issue.
+    // (The bases are made opaque per patch: as loop invariants the compiler would hoist all 74 x 4 fragment
+    // addresses out of the patch loop and spill them.)
+    int ko = half, kx = half, ky = 0;
 #pragma unroll
-  for (int i = 0; i < TMC; ++i) {
+    for (int j = 0; j < 4; ++j) ECO_OPAQUE(pbase[j]);
+    ECO_OPAQUE(ko);
+    ECO_OPAQUE(kx);
+    float af[2][TMC], bf[2][4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int cl = (r & 3) + 8 * (r >> 2) + 4 * half, ch = 32 * i + cl;
-      const float b = a.bias ? ld(a.bias + ch) : 0.0f;
-      const float sc = a.bn_scale ? ld(a.bn_scale + ch) : 1.0f, sh = a.bn_scale ? ld(a.bn_shift + ch) : 0.0f;
+    for (int i = 0; i < TMC; ++i) af[0][i] = wl[(32 * i) * 2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int p = wave * 128 + j * 32 + l31;
-        float v = (acc[i][j][r] + b) * sc + sh;
-        if (a.relu) v = fmaxf(v, 0.0f);
-        if (p < kStemNPos) Ss[cl * STAGE_LD + p] = v;
+    for (int j = 0; j < 4; ++j) bf[0][j] = Xs[pbase[j] + ko];
+#pragma unroll
+    for (int kp = 0; kp < kStemKP; ++kp) {
+      const int cur = kp & 1;
+      if (kp + 1 < kStemKP) {
+        kx += 2; ko += 2;
+        if (kx >= 7) {
+          kx -= 7; ko += kStemIQ - 7;
+          if (++ky == 7) { ky = 0; ko += (kStemIR - 7) * kStemIQ; }
+        }
+#pragma unroll
+        for (int i = 0; i < TMC; ++i) af[cur ^ 1][i] = wl[((kp + 1) * COUT + 32 * i) * 2];
+        const int koe = (kp + 1 == kStemKP - 1 && half) ? 0 : ko;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[cur ^ 1][j] = Xs[pbase[j] + koe];
+      }
+#pragma unroll
+      for (int i = 0; i < TMC; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_32x32x2(af[cur][i], bf[cur][j], acc[i][j]);
+    }
+    __syncthreads();   // every wave is done with Xs: the space becomes the pooling stage
+
+    // ---- per 16 channels: epilogue into the stage, 3x3 stride-2 max over it, pooled store.  A thread's nine window
+    // offsets are fixed per patch (taps outside the conv image -- the MAX window is clipped to it,
+    // pooling_layer.cpp:207-212 -- re-read tap (0,0), which a stored output always has); its channel advances by
+    // two per step: immediate offsets only. ----
+    const int f = patch / tpf, t = patch - f * tpf;
+    const int by = t / a.tiles_w, bx = t - by * a.tiles_w;
+    const int r0 = 2 * kStemPH * by, q0 = 2 * kStemPW * bx;          // first conv row / column of the patch
+    const int gph = kStemPH * by + ph, gpw = kStemPW * bx + pw;
+    const bool pool_thread = clo < 2 && gph < a.PHo && gpw < a.PWo;
+    int woff[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+        woff[dy * 3 + dx] = (r0 + 2 * ph + dy < a.Ho && q0 + 2 * pw + dx < a.Wo) ? dy * kStemCQ + dx : 0;
+    float* const yp0 = a.y + (((long)f * a.cout + clo) * a.PHo + gph) * a.PWo + gpw;
+#pragma unroll
+    for (int i = 0; i < TMC; ++i) {
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int r = 8 * rh + rr;
+          const int cl0 = (rr & 3) + 8 * (rr >> 2);        // + 4*half: this lane's channel within the 16
+          const int ch = 32 * i + 16 * rh + cl0 + 4 * half;
+          const float b = Es[ch], sc = Es[COUT + ch], sh = Es[2 * COUT + ch];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = (acc[i][j][r] + b) * sc + sh;
+            if (a.relu) v = fmaxf(v, 0.0f);
+            if (j < 3 || last_col_ok) sw0[cl0 * STAGE_LD + j * 32] = v;
+          }
+        }
+        __syncthreads();
+        if (pool_thread) {
+#pragma unroll
+          for (int u = 0; u < STAGE_CH / 2; ++u) {
+            const float* sp = sp0 + 2 * u * STAGE_LD;
+            float m = sp[woff[0]];
+#pragma unroll
+            for (int k = 1; k < 9; ++k) m = fmaxf(m, sp[woff[k]]);
+            st(yp0 + (32 * i + 16 * rh + 2 * u) * ych, m);
+          }
+        }
+        __syncthreads();
       }
     }
+    if (next >= a.total) break;
+    store_patch();
     __syncthreads();
-    for (int o = tid; o < 32 * kStemPH * kStemPW; o += 256) {
-      const int pw = o % kStemPW, ph = (o / kStemPW) % kStemPH, cl = o / (kStemPW * kStemPH);
-      const int gph = kStemPH * by + ph, gpw = kStemPW * bx + pw;
-      if (gph >= a.PHo || gpw >= a.PWo) continue;
-      const float* sp = Ss + cl * STAGE_LD + 2 * ph * kStemCQ + 2 * pw;
-      float m = -FLT_MAX;
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx)   // MAX clips its window to the conv image (pooling_layer.cpp:207-212)
-          if (r0 + 2 * ph + dy < a.Ho && q0 + 2 * pw + dx < a.Wo) m = fmaxf(m, sp[dy * kStemCQ + dx]);
-      st(a.y + (((long)f * a.cout + 32 * i + cl) * a.PHo + gph) * a.PWo + gpw, m);
-    }
-    if (i + 1 < TMC) __syncthreads();
+    patch = next;
   }
 }
 
@@ -157,40 +252,48 @@ static int stem_dims(int h, int w, int* ho, int* wo, int* pho, int* pwo) {
   return *ho >= 3 && *wo >= 3;
 }
 
-extern "C" int eco_stem_pack_weights(const float* w, int32_t cout, float* wp, int32_t* koff) {
+extern "C" int eco_stem_pack_weights(const float* w, int32_t cout, float* wp) {
   clear_error();
-  ECO_REQUIRE(w && wp && koff && (cout == 32 || cout == 64), "stem: weights for 32 or 64 output channels (got %d)", cout);
+  ECO_REQUIRE(w && wp && (cout == 32 || cout == 64), "stem: weights for 32 or 64 output channels (got %d)", cout);
   memset(wp, 0, sizeof(float) * (size_t)kStemKP * cout * 2);
-  for (int k = 0; k < 2 * kStemKP; ++k) {
-    const int kk = k < kStemK ? k : 0;                 // the padding row multiplies zero weights: any in-range word
-    const int c = kk / 49, ky = (kk % 49) / 7, kx = kk % 7;
-    koff[k] = c * kStemIR * kStemIQ + ky * kStemIQ + kx;
-    if (k < kStemK)
-      for (int m = 0; m < cout; ++m) wp[((long)(k / 2) * cout + m) * 2 + (k & 1)] = w[(long)m * kStemK + k];
-  }
+  for (int k = 0; k < kStemK; ++k)
+    for (int m = 0; m < cout; ++m) wp[((long)(k / 2) * cout + m) * 2 + (k & 1)] = w[(long)m * kStemK + k];
   return ECO_OK;
 }
 
-extern "C" int eco_stem_forward(const float* x, const float* wp, const int32_t* koff, const float* bias,
-                                const float* bn_scale, const float* bn_shift, int32_t relu, float* y, int32_t n,
-                                int32_t h, int32_t w, int32_t cout, void* stream) {
+// Compute units of the current device (two workgroups fit on each: 70 KB of LDS, <= 256 VGPRs).
+static int stem_num_cu() {
+#ifdef ECO_EMU
+  return 256;
+#else
+  int dev = 0, cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) return 256;
+  return cu;
+#endif
+}
+
+extern "C" int eco_stem_forward(const float* x, const float* wp, const float* bias, const float* bn_scale,
+                                const float* bn_shift, int32_t relu, float* y, int32_t n, int32_t h, int32_t w,
+                                int32_t cout, int32_t max_workgroups, void* stream) {
   clear_error();
-  ECO_REQUIRE(x && wp && koff && y && n > 0 && h > 0 && w > 0, "stem: bad argument");
+  ECO_REQUIRE(x && wp && y && n > 0 && h > 0 && w > 0 && max_workgroups >= 0, "stem: bad argument");
   ECO_REQUIRE(cout == 32 || cout == 64, "stem: 32 or 64 output channels (got %d)", cout);
   ECO_REQUIRE(!bn_scale == !bn_shift, "stem: bn_scale and bn_shift must be given together");
   ECO_REQUIRE(((uintptr_t)wp & 15) == 0, "stem: packed weights must be 16-byte aligned");
   StemArgs a;
-  a.x = x; a.wp = wp; a.koff = koff; a.bias = bias; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.y = y;
+  a.x = x; a.wp = wp; a.bias = bias; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.y = y;
   a.n = n; a.H = h; a.W = w; a.cout = cout; a.relu = relu;
   ECO_REQUIRE(stem_dims(h, w, &a.Ho, &a.Wo, &a.PHo, &a.PWo), "stem: image %dx%d too small for conv 7x7/2 + pool 3x3/2", h, w);
   a.tiles_h = (int)ceil_div(a.PHo, kStemPH);
   a.tiles_w = (int)ceil_div(a.PWo, kStemPW);
-  const long grid = (long)n * a.tiles_h * a.tiles_w;
-  ECO_REQUIRE(grid < 2147483647l, "stem: too many patches for one launch");
-  const int in_words = (3 * kStemIR * kStemIQ + 3) & ~3;
-  size_t lds = sizeof(float) * (size_t)(in_words + kStemKP * cout * 2);
-  const size_t stage = sizeof(float) * 32 * (kStemNPos + 3);
-  if (stage > lds) lds = stage;
+  const long total = (long)n * a.tiles_h * a.tiles_w;
+  ECO_REQUIRE(total < 2147483647l, "stem: too many patches for one launch");
+  a.total = (int)total;
+  // persistent workgroups, two per CU: the weights are loaded once per workgroup, not once per patch
+  const long cap = max_workgroups ? max_workgroups : 2l * stem_num_cu();
+  const long grid = total < cap ? total : cap;
+  const size_t lds = sizeof(float) * (size_t)(16 * (kStemNPos + 3) + kStemKP * cout * 2 + 3 * cout);
   hipStream_t s = (hipStream_t)stream;
 #ifndef ECO_EMU
   {

@@ -207,10 +207,8 @@ class Engine:
                     self.alloc.upload(st["bias"], blobs[1])
                 if "stem_wp" in st:   # conv1 + pool1 as one launch (csrc/eco_stem.hip)
                     swp = np.empty(74 * L.geom["cout"] * 2, np.float32)
-                    sko = np.empty(148, np.int32)
-                    self.lib.stem_pack_weights(w.ctypes.data, L.geom["cout"], swp.ctypes.data, sko.ctypes.data)
+                    self.lib.stem_pack_weights(w.ctypes.data, L.geom["cout"], swp.ctypes.data)
                     self.alloc.upload(st["stem_wp"], swp)
-                    self.alloc.upload(st["stem_koff"], sko)
                 wn = st.get("wino")
                 if wn is not None and wn.get("kind") == "wgemm":   # u[p] = (G g G^T)[p] packed for the dense GEMM kernel
                     cout, cin, kd = L.geom["cout"], L.geom["cin"], wn["kd"]
@@ -284,7 +282,6 @@ class Engine:
                 st.pop("wino", None) if not self._wino_eligible(L) else self._plan_wino(L, st)
                 if self._stem_geometry(L) and "stem_wp" not in st:
                     st["stem_wp"] = self.alloc.empty(74 * g["cout"] * 2, np.float32)
-                    st["stem_koff"] = self.alloc.empty(148, np.int32)
                 self._dirty_params.add(L.name)  # the gather table depends on the input dims
             elif L.type == "BN" and st.get("size") != L.geom["channels"]:
                 st["scale"] = self.alloc.empty(L.geom["channels"], np.float32)
@@ -604,11 +601,11 @@ class Engine:
         absorbed[cs[0]] = L.name
         self.fused_away[act_blob] = f"only exists inside the fused stem launch {L.name}+{Lp.name}"
         x, y = self._ptr(L.bottoms[0]), self._ptr(Lp.tops[0])
-        wp, ko = self.alloc.ptr(st["stem_wp"]), self.alloc.ptr(st["stem_koff"])
+        wp = self.alloc.ptr(st["stem_wp"])
         bias, sc, sh, relu = ep.bias, ep.bn_scale, ep.bn_shift, ep.relu
         lib = self.lib
         n_conv = _prod(L.top_shapes[0])
-        self._add(i, f"{label}+{Lp.name}", lambda s: lib.stem_forward(x, wp, ko, bias, sc, sh, relu, y, n, H, W, cout, s),
+        self._add(i, f"{label}+{Lp.name}", lambda s: lib.stem_forward(x, wp, bias, sc, sh, relu, y, n, H, W, cout, s),
                   {"kernel": "eco::stem_kernel", "flops": 2 * n_conv * 147,
                    "bytes": 4 * (_prod(L.bottom_shapes[0]) + 147 * cout + _prod(Lp.top_shapes[0]))})
         return True

@@ -199,9 +199,9 @@ _SIGNATURES = {
                                        C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "eco_softmax_loss_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                            C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
-    "eco_stem_pack_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
-    "eco_stem_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
-                                   C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "eco_stem_pack_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "eco_stem_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                   C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "eco_wgemm_plan_create": (C.c_int, [C.c_int32] * 9 + [C.POINTER(WGemmPlan)]),
     "eco_wgemm_pack_weights": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p]),
     "eco_wino_input_pk_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
@@ -303,11 +303,13 @@ class EcoLib:
         self._check(self._dll.eco_wino_output_forward(m, n, cout, d, h, w, tile_m, C.byref(ep), stream))
 
     # -- the stem as one launch (csrc/eco_stem.hip) -----------------------------------
-    def stem_pack_weights(self, w_host: int, cout: int, wp_host: int, koff_host: int) -> None:
-        self._check(self._dll.eco_stem_pack_weights(w_host, cout, wp_host, koff_host))
+    def stem_pack_weights(self, w_host: int, cout: int, wp_host: int) -> None:
+        self._check(self._dll.eco_stem_pack_weights(w_host, cout, wp_host))
 
-    def stem_forward(self, x, wp, koff, bias, bn_scale, bn_shift, relu, y, n, h, w, cout, stream=None) -> None:
-        self._check(self._dll.eco_stem_forward(x, wp, koff, bias, bn_scale, bn_shift, int(relu), y, n, h, w, cout, stream))
+    def stem_forward(self, x, wp, bias, bn_scale, bn_shift, relu, y, n, h, w, cout, stream=None,
+                     max_workgroups: int = 0) -> None:
+        self._check(self._dll.eco_stem_forward(x, wp, bias, bn_scale, bn_shift, int(relu), y, n, h, w, cout,
+                                               max_workgroups, stream))
 
     # -- Winograd F(4x4,3x3) on the dedicated transformed-domain GEMM (csrc/eco_wgemm.hip) --
     def wgemm_plan(self, n, cin, cout, d, th, tw, kd, num_cu: Optional[int] = None) -> "WGemmPlan":

@@ -9,9 +9,11 @@ from eco_amd.netspec import NetSpec
 from tests.test_net import make_net, relerr
 
 
-@pytest.mark.parametrize("n,H,W,cout,bn", [(2, 64, 64, 64, True), (1, 75, 52, 32, True), (3, 40, 36, 64, False),
-                                           (1, 224, 224, 64, True)])
-def test_stem_matches_layer_sequence(backend, n, H, W, cout, bn):
+# max_wg: cap on the persistent workgroups (0 = two per CU); small caps make one workgroup walk several patches
+@pytest.mark.parametrize("n,H,W,cout,bn,max_wg", [(2, 64, 64, 64, True, 0), (2, 64, 64, 64, True, 3),
+                                                  (1, 75, 52, 32, True, 1), (3, 40, 36, 64, False, 2),
+                                                  (1, 224, 224, 64, True, 0), (2, 224, 224, 64, True, 5)])
+def test_stem_matches_layer_sequence(backend, n, H, W, cout, bn, max_wg):
     if H == 224 and backend.kind == "emu":
         pytest.skip("full-size frame: GPU only")
     rng = np.random.default_rng(H + cout)
@@ -25,18 +27,17 @@ def test_stem_matches_layer_sequence(backend, n, H, W, cout, bn):
     v = np.maximum(v, 0)
     ref = orc.pooling(v, "MAX", (3, 3), (2, 2), (0, 0))
     lib = backend.lib
-    wp, ko = np.empty(74 * cout * 2, np.float32), np.empty(148, np.int32)
-    lib.stem_pack_weights(w.ctypes.data, cout, wp.ctypes.data, ko.ctypes.data)
+    wp = np.empty(74 * cout * 2, np.float32)
+    lib.stem_pack_weights(w.ctypes.data, cout, wp.ctypes.data)
     y = backend.empty(ref.shape)
-    lib.stem_forward(backend.ptr(backend.dev(x)), backend.ptr(backend.dev(wp)), backend.ptr(backend.dev(ko)),
-                     backend.ptr(backend.dev(b)), backend.ptr(backend.dev(sc)) if bn else None,
-                     backend.ptr(backend.dev(sh)) if bn else None, 1, backend.ptr(y), n, H, W, cout)
+    lib.stem_forward(backend.ptr(backend.dev(x)), backend.ptr(backend.dev(wp)), backend.ptr(backend.dev(b)), backend.ptr(backend.dev(sc)) if bn else None,
+                     backend.ptr(backend.dev(sh)) if bn else None, 1, backend.ptr(y), n, H, W, cout, max_workgroups=max_wg)
     assert relerr(backend.host(y, ref.shape), ref) < 2e-5
 
 
 def test_stem_rejects_other_widths(backend):
     with pytest.raises(hip.EcoError, match="32 or 64"):
-        backend.lib.stem_pack_weights(0, 48, 0, 0)
+        backend.lib.stem_pack_weights(0, 48, 0)
 
 
 def test_engine_fuses_the_stem(backend):
