@@ -1164,6 +1164,7 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
   ECO_REQUIRE(ep->raw.ptr || ep->act.ptr, "convb: at least one of raw/act outputs is required");
   ECO_REQUIRE(!ep->bn_scale == !ep->bn_shift, "convb: bn_scale and bn_shift must be given together");
   ECO_REQUIRE(!ep->act2.ptr || ep->act.ptr, "convb: act2 needs act");
+  ECO_REQUIRE(ep->nseg == 0, "convb: segmented (sibling) launches exist for the fp32 direct kernels only");
   const eco_view* views[4] = {&ep->residual, &ep->raw, &ep->act, &ep->act2};
   for (const eco_view* v : views)
     ECO_REQUIRE(!v->ptr || (v->t >= 1 && v->stride_c >= 1), "convb: view needs t >= 1 and stride_c >= 1");

@@ -40,6 +40,10 @@ struct ConvKernelArgs {
   const float* bn_scale;
   const float* bn_shift;
   eco_view residual, raw, act, act2;
+  // sibling convs run as one (eco_conv_epilogue::nseg): 32-row tiles at or above seg_begin[s] write through
+  // seg_act[s], whose ptr the host moved back by seg_begin[s] channels so that the global channel indexes it
+  int nseg, seg_begin[2];
+  eco_view seg_act[2];
   int relu;
   int cin, cout, mpad, kpad;
   int Di, Hi, Wi, Do, Ho, Wo;
@@ -142,6 +146,7 @@ template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw,
                                               int half, int l31) {
   long e_res[TN], e_raw[TN], e_act[TN], e_act2[TN];
+  int e_img[TN], e_sp[TN];
   bool e_ok[TN];
   const bool has_bias = a.bias != nullptr, has_bn = a.bn_scale != nullptr, has_res = a.residual.ptr != nullptr;
   const bool has_raw = a.raw.ptr != nullptr, has_act = a.act.ptr != nullptr, has_act2 = has_act && a.act2.ptr != nullptr;
@@ -156,9 +161,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&
     e_raw[j] = has_raw ? view_base(a.raw, img, sp) : 0;
     e_act[j] = has_act ? view_base(a.act, img, sp) : 0;
     e_act2[j] = has_act2 ? view_base(a.act2, img, sp) : 0;
+    e_img[j] = img; e_sp[j] = sp;
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    // the destination of this 32-row tile (wave-uniform): `act`, or a sibling's own tensor
+    float* aptr = a.act.ptr;
+    long astride_c = a.act.stride_c;
+    const int mt = mw + i * 32;
+    if (a.nseg > 0 && mt >= a.seg_begin[0]) {
+      const eco_view& sv = a.seg_act[(a.nseg > 1 && mt >= a.seg_begin[1]) ? 1 : 0];
+      aptr = sv.ptr; astride_c = sv.stride_c;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) e_act[j] = (long)e_img[j] * sv.stride_b + e_sp[j];
+    }   // (tiles ascend: once past seg_begin[0] a wave never returns to `act`, whose offsets e_act held so far)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int chg = mw + i * 32 + 8 * g + 4 * half;  // first of this group's 4 consecutive channels
@@ -196,7 +212,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&
             float y = v[q] * ps[q] + ph[q];
             if (a.relu) y = fmaxf(y, 0.0f);
             if (chg + q < a.cout) {
-              st(a.act.ptr + e_act[j] + (long)(chg + q) * a.act.stride_c, y);
+              st(aptr + e_act[j] + (long)(chg + q) * astride_c, y);
               if (has_act2) st(a.act2.ptr + e_act2[j] + (long)(chg + q) * a.act2.stride_c, y);
             }
           }
@@ -1271,6 +1287,24 @@ static int conv_forward_impl(const eco_conv_geom* g, const eco_conv_plan* plan, 
   a.x = x; a.wp = wp; a.ktab = ktab;
   a.bias = ep->bias; a.bn_scale = ep->bn_scale; a.bn_shift = ep->bn_shift;
   a.residual = ep->residual; a.raw = ep->raw; a.act = ep->act; a.act2 = ep->act2; a.relu = ep->relu;
+  a.nseg = ep->nseg; a.seg_begin[0] = a.seg_begin[1] = 0;
+  a.seg_act[0] = a.seg_act[1] = eco_view{nullptr, 0, 0, 0, 1};
+  if (ep->nseg) {
+    ECO_REQUIRE(ep->nseg >= 1 && ep->nseg <= 2, "conv: 1 or 2 extra output segments (got %d)", ep->nseg);
+    ECO_REQUIRE(ep->act.ptr && ep->act.t == 1 && !ep->raw.ptr && !ep->residual.ptr && !ep->act2.ptr && batch == 1,
+                "conv: a segmented launch takes plain act destinations only (no raw / residual / act2 / batch)");
+    ECO_REQUIRE(plan->ksplit == 1, "conv: a segmented launch cannot use a split-K plan");
+    int prev = 0;
+    for (int s = 0; s < ep->nseg; ++s) {
+      const eco_view& v = ep->seg_act[s];
+      ECO_REQUIRE(v.ptr && v.t == 1 && v.stride_c >= 1, "conv: segment %d needs a plain destination view", s + 1);
+      ECO_REQUIRE(ep->seg_begin[s] > prev && ep->seg_begin[s] < g->cout && ep->seg_begin[s] % 32 == 0,
+                  "conv: segment boundary %d must be a multiple of 32 inside (%d, %d)", ep->seg_begin[s], prev, g->cout);
+      prev = a.seg_begin[s] = ep->seg_begin[s];
+      a.seg_act[s] = v;
+      a.seg_act[s].ptr = v.ptr - (long)ep->seg_begin[s] * v.stride_c;
+    }
+  }
   a.cin = g->cin; a.cout = g->cout; a.mpad = plan->mpad; a.kpad = plan->kpad;
   a.Di = g->in[0]; a.Hi = g->in[1]; a.Wi = g->in[2];
   a.Do = g->out[0]; a.Ho = g->out[1]; a.Wo = g->out[2];

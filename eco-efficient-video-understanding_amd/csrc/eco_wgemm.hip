@@ -29,7 +29,7 @@
 
 namespace eco {
 
-constexpr int kWgT = 6, kWgP = 36;   // F(4x4,3x3): 6x6 transform points
+constexpr int kWgP = 36;   // F(4x4,3x3): 6x6 transform points
 constexpr int kWgKp = 8;             // k-pairs (16 reduction elements) per stage
 
 struct WGemmArgs {
@@ -257,8 +257,7 @@ __global__ __launch_bounds__(256) void wino_input_pk_kernel(const WinoInPkArgs a
 
 // ------------------------------------------------------------------------------------------------------------------
 // Output transform from M[p][slice][cout][d][r]: y tile = A^T (sum over slices m) A, then the fused epilogue
-// (bias, Eltwise residual, raw store, folded BN, ReLU, both activated destinations; strided views).  One thread
-// per (b, channel, d, th, tw) as wino_output_kernel in eco_wino.hip.
+// (bias, Eltwise residual, raw store, folded BN, ReLU, both activated destinations; strided views).
 struct WinoOutDmArgs {
   const float* m;
   const float* bias;
@@ -280,29 +279,32 @@ struct WgVec<2> { typedef float2 type; };
 template <>
 struct WgVec<4> { typedef float4 type; };
 
+// A thread takes one tile column r of one (channel, depth) row of M, in M's own order (ch, d, r): every point's load
+// is contiguous across the wave (256 B per point) and the stores are runs of one H x W plane per (img, ch, d).
+// (The (img, ch, d, t) order -- stores contiguous over the whole tensor, M read in runs of TH*TW floats: 196 / 64 /
+// 16 bytes in res3 / 4 / 5 -- was 9 % slower over the step's 17 transforms; 2 or 4 columns per thread with vector
+// loads of M were slower again: 72 / 144 live tile values.)
 template <int VEC>
 __global__ __launch_bounds__(256) void wino_output_dm_kernel(const WinoOutDmArgs a) {
   constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
   typedef typename WgVec<VEC>::type vec_t;
-  const long tiles = (long)a.n * a.cout * a.D * a.TH * a.TW;
+  const long total = (long)a.cout * a.ntot;
   const int tpp = a.TH * a.TW;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < tiles; idx += (long)gridDim.x * 256) {
-    const int t = (int)(idx % tpp);
-    long r = idx / tpp;
-    const int d = (int)(r % a.D);
-    r /= a.D;
-    const int ch = (int)(r % a.cout);
-    const int img = (int)(r / a.cout);
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+    const int ch = (int)(q / a.ntot);
+    const int rem = (int)(q - (long)ch * a.ntot);
+    const int d = rem / a.NB, r = rem - d * a.NB;
+    const int img = r / tpp, t = r - img * tpp;
     const int th = t / a.TW, tw = t - th * a.TW;
-    const float* mp = a.m + (long)ch * a.ntot + (long)d * a.NB + (long)img * tpp + t;
+    const float* mp = a.m + q;
     float m[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        const float* q = mp + (long)(6 * i + j) * a.m_pstride;
-        float s = ld(q);
-        for (int sl = 1; sl < a.ksplit; ++sl) s += ld(q + (long)sl * a.cout * a.ntot);
+        const float* qq = mp + (long)(6 * i + j) * a.m_pstride;
+        float s = ld(qq);
+        for (int sl = 1; sl < a.ksplit; ++sl) s += ld(qq + (long)sl * a.cout * a.ntot);
         m[i][j] = s;
       }
     float s4[4][6];
@@ -558,6 +560,7 @@ extern "C" int eco_wino_output_dm_forward(const eco_wgemm_plan* plan, const floa
   ECO_REQUIRE(ep->raw.ptr || ep->act.ptr, "winograd output transform: at least one of raw/act outputs is required");
   ECO_REQUIRE(!ep->bn_scale == !ep->bn_shift, "winograd output transform: bn_scale and bn_shift must be given together");
   ECO_REQUIRE(!ep->act2.ptr || ep->act.ptr, "winograd output transform: act2 needs act");
+  ECO_REQUIRE(ep->nseg == 0, "winograd output transform: segmented (sibling) launches exist for the direct kernels only");
   const eco_view* views[4] = {&ep->residual, &ep->raw, &ep->act, &ep->act2};
   for (const eco_view* v : views)
     ECO_REQUIRE(!v->ptr || (v->t >= 1 && v->stride_c >= 1), "winograd output transform: view needs t >= 1 and stride_c >= 1");

@@ -137,9 +137,13 @@ class Engine:
         self.winograd = winograd
         self.wgemm = True          # F(4x4,3x3) GEMMs on the dedicated dense kernel (False: round-1 gather-kernel route)
         self.stem = True           # conv1 + BN + ReLU + pool1 as one launch (False: conv kernel + pooling kernel)
+        self.siblings = True       # 1x1 convs reading the same bottom as one launch (fp32 path)
         self.num_cu = num_cu       # None = the device's 256 CUs (tests shrink it to reach split-K paths)
         self.params: Dict[str, List[np.ndarray]] = {}
         self._param_dev: Dict[str, dict] = {}    # layer name -> device-side state
+        self._group_dev: Dict[str, dict] = {}    # sibling-conv group -> device-side state (concatenated members)
+        self._groups: Dict[str, dict] = {}
+        self._dirty_groups: set = set()
         self._dirty_params: set = set()
         self.tensors: Dict[str, _Tensor] = {}
         self.fused_away: Dict[str, str] = {}     # blob -> reason
@@ -179,9 +183,10 @@ class Engine:
 
     def _sync_params(self) -> None:
         """(Re)upload parameters whose host copy changed; repack conv weights."""
-        if not self._dirty_params:
+        if not self._dirty_params and not self._dirty_groups:
             return
         self.generation += 1
+        self._sync_groups(set(self._dirty_params))
         for name in list(self._dirty_params):
             L = self.spec.layer(name)
             st = self._param_dev.setdefault(name, {})
@@ -251,6 +256,8 @@ class Engine:
         self.fused_away = {}
         self.ops = []
         self._keep = []
+        self._groups = {}
+        self._dirty_groups = set()
         self.generation += 1
         # device-side parameter storage (sizes depend on geometry)
         for L in spec.layers:
@@ -769,7 +776,10 @@ class Engine:
             if i in absorbed:
                 continue
             if L.type == "Convolution":
-                self._fuse_conv(i, L, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed, concat_skip)
+                if not self._try_fuse_siblings(i, L, layers, consumers, outputs, sole_consumer, bn_relu_after,
+                                               absorbed, concat_skip):
+                    self._fuse_conv(i, L, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed,
+                                    concat_skip)
             elif L.type == "Pooling" and (self._try_fuse_tail(i, L, layers, sole_consumer, absorbed) or
                                           self._try_fuse_two_stream_tail(i, L, layers, absorbed)):
                 pass
@@ -781,6 +791,14 @@ class Engine:
                 self._emit_unfused(i, L)
 
     def _fuse_conv(self, i, L, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed, concat_skip) -> None:
+        ep, label = self._conv_epilogue(i, L, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed,
+                                        concat_skip)
+        if ep is not None:
+            self._emit_conv(i, L, ep, label)
+
+    def _conv_epilogue(self, i, L, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed, concat_skip):
+        """Decide what the conv's epilogue absorbs and where its outputs go: (epilogue, label), or (None, label) when
+        the whole group was emitted here already (the stem)."""
         cout = L.geom["cout"]
         S = _prod(L.top_shapes[0][2:])
         ep = hip.ConvEpilogue()
@@ -828,7 +846,7 @@ class Engine:
             self.fused_away[value] = f"only exists inside the fused epilogue of {L.name}"
         # 3b. the stem: conv1 + BN + ReLU + pool1 as one launch
         if self._try_fuse_stem(i, L, ep, act_blob, label, layers, consumers, outputs, absorbed):
-            return
+            return None, label
         # 4. activated output and its destination
         if act_blob is not None:
             dest = self._act_destination(act_blob, L, layers, consumers, outputs, absorbed, concat_skip)
@@ -844,7 +862,136 @@ class Engine:
                                             if v == L.name and layers[c].type in ("Reshape", "Permute"))
             else:
                 ep.act = dest
-        self._emit_conv(i, L, ep, label)
+        return ep, label
+
+    # -- sibling convolutions: one launch for the 1x1 convs that read the same bottom ----------------------------
+    def _try_fuse_siblings(self, i, L, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed,
+                           concat_skip) -> bool:
+        """The 1x1 / 3x3_reduce / double_3x3_reduce convs of an Inception block (models_ECO_Lite/kinetics/
+        deploy.prototxt:130-330) read the same blob: concatenated along the output channel they are one GEMM that
+        reads the input once, each member's 32-row tiles writing to its own destination (eco_conv_epilogue::nseg).
+        Members: 1x1 stride-1 unpadded convs whose value is only seen through a fused BN + ReLU."""
+        if self.dt or not self.siblings:
+            return False
+
+        def point(Lc) -> bool:
+            g = Lc.geom
+            return all(k == 1 for k in g["kernel"]) and all(s == 1 for s in g["stride"]) and \
+                all(q == 0 for q in g["pad"]) and g["cout"] % 32 == 0 and g.get("group", 1) == 1
+
+        def simple(Lc) -> bool:
+            value = Lc.tops[0]
+            br = bn_relu_after(value)
+            if br is None or br[0] in absorbed or sole_consumer(value, "Eltwise") is not None or value in outputs:
+                return False
+            return all(c == br[0] for c in consumers.get(value, []))
+
+        src = self._resolve(L.bottoms[0])
+        if not (point(L) and simple(L)):
+            return False
+        members = [i]
+        for j in consumers.get(src, []):
+            Lj = layers[j]
+            if j <= i or j in absorbed or Lj.type != "Convolution" or len(members) == 3:
+                continue
+            if point(Lj) and simple(Lj) and Lj.geom["bias_term"] == L.geom["bias_term"] and \
+                    Lj.bottom_shapes[0] == L.bottom_shapes[0] and \
+                    not any(layers[k].inplace and self._resolve(layers[k].bottoms[0]) == src for k in range(i, j)):
+                members.append(j)
+        if len(members) < 2:
+            return False
+        geom = hip.conv_geom(L.bottom_shapes[0][0], L.geom["cin"], sum(layers[j].geom["cout"] for j in members),
+                             L.bottom_shapes[0][2:], L.geom["kernel"], L.geom["stride"], L.geom["pad"],
+                             L.top_shapes[0][2:])
+        plan = self.lib.conv_plan(geom, self.num_cu)
+        if plan.ksplit != 1:
+            return False
+        bns = [layers[bn_relu_after(layers[j].tops[0])[0]].name for j in members]
+        eps, labels = [], []
+        for j in members:
+            ep, label = self._conv_epilogue(j, layers[j], layers, consumers, outputs, sole_consumer, bn_relu_after,
+                                            absorbed, concat_skip)
+            eps.append(ep)
+            labels.append(label)
+            if j != i:
+                absorbed[j] = L.name
+        ok = [bool(ep.act.ptr) and ep.act.t == 1 and not ep.raw.ptr and not ep.act2.ptr and not ep.residual.ptr
+              for ep in eps]
+        fuse = [k for k in range(len(members)) if ok[k]]
+        if len(fuse) < 2:
+            fuse = []
+        for k, j in enumerate(members):
+            if k not in fuse:       # a destination the segmented epilogue cannot express (e.g. through Permute)
+                self._emit_conv(i, layers[j], eps[k], labels[k])
+        if fuse:
+            if len(fuse) != len(members):
+                geom = hip.conv_geom(L.bottom_shapes[0][0], L.geom["cin"],
+                                     sum(layers[members[k]].geom["cout"] for k in fuse), L.bottom_shapes[0][2:],
+                                     L.geom["kernel"], L.geom["stride"], L.geom["pad"], L.top_shapes[0][2:])
+                plan = self.lib.conv_plan(geom, self.num_cu)
+            self._emit_sibling_conv(i, [layers[members[k]] for k in fuse], [bns[k] for k in fuse],
+                                    [eps[k] for k in fuse], [labels[k] for k in fuse], geom, plan)
+        return True
+
+    def _emit_sibling_conv(self, i, Ls, bns, eps, labels, geom, plan) -> None:
+        key = "|".join(Lc.name for Lc in Ls)
+        couts = [Lc.geom["cout"] for Lc in Ls]
+        ctot = sum(couts)
+        st = self._group_dev.setdefault(key, {})
+        old = st.get("plan")
+        if old is None or (old.wp_elems, old.ktab_elems, st.get("ctot")) != (plan.wp_elems, plan.ktab_elems, ctot):
+            st["wp"] = self.alloc.empty(plan.wp_elems, np.float32)
+            st["ktab"] = self.alloc.empty(plan.ktab_elems, np.int32)
+            for k in ("bias", "scale", "shift"):
+                st[k] = self.alloc.empty(ctot, np.float32)
+            st["ctot"] = ctot
+        st["geom"], st["plan"] = geom, plan
+        bias_term = bool(Ls[0].geom["bias_term"])
+        self._groups[key] = {"convs": [Lc.name for Lc in Ls], "bns": list(bns), "bias_term": bias_term, "st": st}
+        self._dirty_groups.add(key)
+        ep = hip.ConvEpilogue()
+        ep.bias = self.alloc.ptr(st["bias"]) if bias_term else None
+        ep.bn_scale, ep.bn_shift, ep.relu = self.alloc.ptr(st["scale"]), self.alloc.ptr(st["shift"]), 1
+        ep.residual, ep.raw, ep.act2 = hip.null_view(), hip.null_view(), hip.null_view()
+        ep.act = eps[0].act
+        ep.nseg = len(Ls) - 1
+        begin = 0
+        for s in range(1, len(Ls)):
+            begin += couts[s - 1]
+            ep.seg_begin[s - 1] = begin
+            ep.seg_act[s - 1] = eps[s].act
+        x = self._ptr(Ls[0].bottoms[0])
+        wp, kt = self.alloc.ptr(st["wp"]), self.alloc.ptr(st["ktab"])
+        self._keep.append((geom, plan, ep))
+        lib = self.lib
+        n_in, cin = _prod(Ls[0].bottom_shapes[0]), Ls[0].geom["cin"]
+        n_out = sum(_prod(Lc.top_shapes[0]) for Lc in Ls)
+        meta = {"kernel": hip.conv_kernel_name(plan), "flops": 2 * n_out * cin,
+                "bytes": 4 * (n_in + cin * ctot + n_out), "siblings": len(Ls)}
+        self._add(i, " | ".join(labels), lambda s, g=geom, plan=plan, x=x, wp=wp, kt=kt, ep=ep:
+                  lib.conv_forward(g, plan, x, wp, kt, ep, None, s), meta)
+
+    def _sync_groups(self, dirty) -> None:
+        """Repack the concatenated weights / bias / folded BN vectors of sibling groups with a changed member."""
+        for key, grp in self._groups.items():
+            if key not in self._dirty_groups and not (dirty & set(grp["convs"] + grp["bns"])):
+                continue
+            st = grp["st"]
+            g, plan = st["geom"], st["plan"]
+            w = np.ascontiguousarray(np.concatenate(
+                [np.asarray(self.params[n][0], np.float32).reshape(-1, g.cin) for n in grp["convs"]], 0))
+            wp = np.empty(plan.wp_elems, np.float32)
+            kt = np.empty(plan.ktab_elems, np.int32)
+            self.lib.conv_pack_weights(g, plan, w.ctypes.data, wp.ctypes.data, kt.ctypes.data)
+            self.alloc.upload(st["wp"], wp)
+            self.alloc.upload(st["ktab"], kt)
+            if grp["bias_term"]:
+                self.alloc.upload(st["bias"], np.concatenate([np.asarray(self.params[n][1], np.float32).ravel()
+                                                              for n in grp["convs"]]))
+            folded = [fold_bn(self.params[n], bn_eps(self.spec.layer(n))) for n in grp["bns"]]
+            self.alloc.upload(st["scale"], np.concatenate([a for a, _ in folded]).astype(np.float32))
+            self.alloc.upload(st["shift"], np.concatenate([b for _, b in folded]).astype(np.float32))
+            self._dirty_groups.discard(key)
 
     def _act_destination(self, act_blob, L, layers, consumers, outputs, absorbed, concat_skip):
         """Strided destination for a fused conv's activated output, or None for a dense tensor."""

@@ -21,7 +21,7 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 DT_BF16 = 1
 DT_F32X3 = 3
 
@@ -71,7 +71,8 @@ class View(C.Structure):
 class ConvEpilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("residual", View), ("raw", View),
                 ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p),
-                ("relu", C.c_int32), ("act", View), ("act2", View)]
+                ("relu", C.c_int32), ("act", View), ("act2", View),
+                ("nseg", C.c_int32), ("seg_begin", C.c_int32 * 2), ("seg_act", View * 2)]
 
 
 class PoolGeom(C.Structure):

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 12
+#define ECO_ABI_VERSION 13
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -122,7 +122,14 @@ typedef struct eco_view {
  *                                          inception_3c_double_3x3_1_bn of ECO-Full,
  *                                          models_ECO_Full/kinetics/deploy.prototxt:1835-1870)
  * Any of bias / residual.ptr / raw.ptr / act.ptr / act2.ptr may be NULL (that step is skipped);
- * bn_scale==NULL means a = v.  At least one of raw.ptr / act.ptr must be non-NULL; act2 needs act. */
+ * bn_scale==NULL means a = v.  At least one of raw.ptr / act.ptr must be non-NULL; act2 needs act.
+ *
+ * Sibling convolutions: the 1x1 / 3x3_reduce / double_3x3_reduce convs of an Inception block read the same
+ * bottom (models_ECO_Lite/kinetics/deploy.prototxt:130-330) and can run as ONE conv whose weights, bias and
+ * folded BN vectors are the members' concatenated along the output channel: nseg = members - 1 (0 = plain).
+ * Channels [0, seg_begin[0]) go to `act` as usual; channels [seg_begin[s], seg_begin[s+1] or cout) go to
+ * seg_act[s] at channel (c - seg_begin[s]).  Boundaries are multiples of 32; segmented launches take act only
+ * (no residual / raw / act2), plain views (t = 1), and the fp32 direct kernels without split-K. */
 typedef struct eco_conv_epilogue {
   const float* bias;
   eco_view residual; /* read-only */
@@ -132,6 +139,9 @@ typedef struct eco_conv_epilogue {
   int32_t relu;
   eco_view act;
   eco_view act2;
+  int32_t nseg;
+  int32_t seg_begin[2];
+  eco_view seg_act[2];
 } eco_conv_epilogue;
 
 /* Validates `g` (fills nothing) and chooses the tiling for the calling thread's current device (its
