@@ -55,6 +55,8 @@ def main() -> None:
                          "operands split exactly into 3 bf16 terms on the bf16 MFMA (fp32 accumulation in all three)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-winograd", action="store_true", help="evaluate every convolution directly (A/B runs)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one hipGraph (launch-bound small batches: --clips-per-gpu 1 online latency)")
     ap.add_argument("--cpu-clips", type=int, default=0, help="clips per CPU-baseline variant (0 = auto, bounded by time)")
     ap.add_argument("--profile-iters", type=int, default=3)
     args = ap.parse_args()
@@ -102,7 +104,7 @@ def main() -> None:
     gathered = torch.empty(world * B, n_cls, device=dev, dtype=logits.dtype) if world > 1 else None
 
     def step() -> None:
-        net.forward_device()
+        net.forward_device(graph=args.graph)
         if world > 1:
             eco_dist.all_gather_logits(logits, out=gathered)
 
@@ -220,6 +222,7 @@ def main() -> None:
                                "224x224 frames resident in HBM" % (name, N, B, args.dtype, cfg),
                    "baseline_config": cfg, "global_batch": world * B, "num_segments": N,
                    "parallelism": f"clip-batch dp{world}", "launches_per_step": len(prof),
+                   "submission": "hipGraph replay" if args.graph else "one C-ABI call per launch",
                    "collective": "none" if world == 1 else "RCCL all-gather of logits",
                    "collective_ranks": ranks_seen, "collective_backend": "none" if world == 1 else backend,
                    "device": f"cuda:{dev_index} {dev_info['name']}, {dev_info['num_cu']} CUs"},

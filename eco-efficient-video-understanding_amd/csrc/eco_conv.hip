@@ -42,7 +42,7 @@ struct ConvKernelArgs {
   eco_view residual, raw, act, act2;
   // sibling convs run as one (eco_conv_epilogue::nseg): 32-row tiles at or above seg_begin[s] write through
   // seg_act[s], whose ptr the host moved back by seg_begin[s] channels so that the global channel indexes it
-  int nseg, seg_begin[2];
+  int nseg, seg_begin[2], seg_relu[2];
   eco_view seg_act[2];
   int relu;
   int cin, cout, mpad, kpad;
@@ -168,10 +168,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&
     // the destination of this 32-row tile (wave-uniform): `act`, or a sibling's own tensor
     float* aptr = a.act.ptr;
     long astride_c = a.act.stride_c;
+    int relu = a.relu;
     const int mt = mw + i * 32;
     if (a.nseg > 0 && mt >= a.seg_begin[0]) {
-      const eco_view& sv = a.seg_act[(a.nseg > 1 && mt >= a.seg_begin[1]) ? 1 : 0];
-      aptr = sv.ptr; astride_c = sv.stride_c;
+      const int sidx = (a.nseg > 1 && mt >= a.seg_begin[1]) ? 1 : 0;
+      const eco_view& sv = a.seg_act[sidx];
+      aptr = sv.ptr; astride_c = sv.stride_c; relu = a.seg_relu[sidx];
 #pragma unroll
       for (int j = 0; j < TN; ++j) e_act[j] = (long)e_img[j] * sv.stride_b + e_sp[j];
     }   // (tiles ascend: once past seg_begin[0] a wave never returns to `act`, whose offsets e_act held so far)
@@ -210,7 +212,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float y = v[q] * ps[q] + ph[q];
-            if (a.relu) y = fmaxf(y, 0.0f);
+            if (relu) y = fmaxf(y, 0.0f);
             if (chg + q < a.cout) {
               st(aptr + e_act[j] + (long)(chg + q) * astride_c, y);
               if (has_act2) st(a.act2.ptr + e_act2[j] + (long)(chg + q) * a.act2.stride_c, y);
@@ -290,13 +292,19 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKerne
     }
     if (a.act.ptr) {
       const float sc = a.bn_scale ? ld(a.bn_scale + ch) : 1.0f, sh = a.bn_scale ? ld(a.bn_shift + ch) : 0.0f;
+      eco_view av = a.act;       // sibling launches: the channel's own destination (ptr already moved back)
+      int relu = a.relu;
+      if (a.nseg > 0 && ch >= a.seg_begin[0]) {
+        const int sidx = (a.nseg > 1 && ch >= a.seg_begin[1]) ? 1 : 0;
+        av = a.seg_act[sidx]; relu = a.seg_relu[sidx];
+      }
       float y[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         y[e] = v[e] * sc + sh;
-        if (a.relu) y[e] = fmaxf(y[e], 0.0f);
+        if (relu) y[e] = fmaxf(y[e], 0.0f);
       }
-      float* o = a.act.ptr + view_base(a.act, img, sp) + (long)ch * a.act.stride_c;
+      float* o = av.ptr + view_base(av, img, sp) + (long)ch * av.stride_c;
       if (VEC == 4) st((float4*)o, make_float4(y[0], y[1 % VEC], y[2 % VEC], y[3 % VEC]));
       else st(o, y[0]);
       if (a.act2.ptr) {
@@ -1287,13 +1295,12 @@ static int conv_forward_impl(const eco_conv_geom* g, const eco_conv_plan* plan, 
   a.x = x; a.wp = wp; a.ktab = ktab;
   a.bias = ep->bias; a.bn_scale = ep->bn_scale; a.bn_shift = ep->bn_shift;
   a.residual = ep->residual; a.raw = ep->raw; a.act = ep->act; a.act2 = ep->act2; a.relu = ep->relu;
-  a.nseg = ep->nseg; a.seg_begin[0] = a.seg_begin[1] = 0;
+  a.nseg = ep->nseg; a.seg_begin[0] = a.seg_begin[1] = 0; a.seg_relu[0] = a.seg_relu[1] = 0;
   a.seg_act[0] = a.seg_act[1] = eco_view{nullptr, 0, 0, 0, 1};
   if (ep->nseg) {
     ECO_REQUIRE(ep->nseg >= 1 && ep->nseg <= 2, "conv: 1 or 2 extra output segments (got %d)", ep->nseg);
     ECO_REQUIRE(ep->act.ptr && ep->act.t == 1 && !ep->raw.ptr && !ep->residual.ptr && !ep->act2.ptr && batch == 1,
                 "conv: a segmented launch takes plain act destinations only (no raw / residual / act2 / batch)");
-    ECO_REQUIRE(plan->ksplit == 1, "conv: a segmented launch cannot use a split-K plan");
     int prev = 0;
     for (int s = 0; s < ep->nseg; ++s) {
       const eco_view& v = ep->seg_act[s];
@@ -1301,6 +1308,7 @@ static int conv_forward_impl(const eco_conv_geom* g, const eco_conv_plan* plan, 
       ECO_REQUIRE(ep->seg_begin[s] > prev && ep->seg_begin[s] < g->cout && ep->seg_begin[s] % 32 == 0,
                   "conv: segment boundary %d must be a multiple of 32 inside (%d, %d)", ep->seg_begin[s], prev, g->cout);
       prev = a.seg_begin[s] = ep->seg_begin[s];
+      a.seg_relu[s] = ep->seg_relu[s];
       a.seg_act[s] = v;
       a.seg_act[s].ptr = v.ptr - (long)ep->seg_begin[s] * v.stride_c;
     }
@@ -1388,7 +1396,8 @@ static int conv_forward_impl(const eco_conv_geom* g, const eco_conv_plan* plan, 
     return !v.ptr || (((uintptr_t)v.ptr & 15) == 0 && v.stride_b % 4 == 0 && v.stride_t % 4 == 0 && v.stride_c % 4 == 0);
   };
   const bool vec4 = a.s_out % 4 == 0 && (!a.dmajor || (a.Ho * a.Wo) % 4 == 0) && a.n_split0 % 4 == 0 && (a.ntot - a.n_split0) % 4 == 0 &&
-                    ((uintptr_t)a.ws & 15) == 0 && vec_ok(a.residual) && vec_ok(a.raw) && vec_ok(a.act) && vec_ok(a.act2);
+                    ((uintptr_t)a.ws & 15) == 0 && vec_ok(a.residual) && vec_ok(a.raw) && vec_ok(a.act) && vec_ok(a.act2) &&
+                    vec_ok(a.seg_act[0]) && vec_ok(a.seg_act[1]);
   long rblocks = ceil_div((long)a.cout * (a.ntot - a.n_split0), 256L * (vec4 ? 4 : 1));
   if (rblocks > 262144) rblocks = 262144;
   if (vec4)

@@ -864,79 +864,73 @@ class Engine:
                 ep.act = dest
         return ep, label
 
-    # -- sibling convolutions: one launch for the 1x1 convs that read the same bottom ----------------------------
+    # -- sibling convolutions: one launch for convs of one geometry that read the same bottom --------------------
     def _try_fuse_siblings(self, i, L, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed,
                            concat_skip) -> bool:
-        """The 1x1 / 3x3_reduce / double_3x3_reduce convs of an Inception block (models_ECO_Lite/kinetics/
-        deploy.prototxt:130-330) read the same blob: concatenated along the output channel they are one GEMM that
-        reads the input once, each member's 32-row tiles writing to its own destination (eco_conv_epilogue::nseg).
-        Members: 1x1 stride-1 unpadded convs whose value is only seen through a fused BN + ReLU."""
+        """Convs of one geometry reading the same blob -- the 1x1 / 3x3_reduce / double_3x3_reduce convs of an
+        Inception block (models_ECO_Lite/kinetics/deploy.prototxt:130-330), a residual block's first conv and its
+        projection shortcut (res4a_1 / res4a_down, res5a_1 / res5a_down: deploy.prototxt:1090-1180) -- concatenated
+        along the output channel are one GEMM that reads (gathers) the input once; each member's 32-row tiles write
+        to its own destination (eco_conv_epilogue::nseg).  A member is either seen only through its fused BN + ReLU
+        or keeps its raw value (a shortcut whose Eltwise then rides on the block's second conv)."""
         if self.dt or not self.siblings:
             return False
 
-        def point(Lc) -> bool:
+        def eligible(Lc) -> bool:
             g = Lc.geom
-            return all(k == 1 for k in g["kernel"]) and all(s == 1 for s in g["stride"]) and \
-                all(q == 0 for q in g["pad"]) and g["cout"] % 32 == 0 and g.get("group", 1) == 1
+            return g["cout"] % 32 == 0 and g.get("group", 1) == 1 and "wino" not in self._param_dev[Lc.name] and \
+                not (self.stem and self._stem_geometry(Lc))
 
-        def simple(Lc) -> bool:
-            value = Lc.tops[0]
-            br = bn_relu_after(value)
-            if br is None or br[0] in absorbed or sole_consumer(value, "Eltwise") is not None or value in outputs:
-                return False
-            return all(c == br[0] for c in consumers.get(value, []))
+        def same(Lc) -> bool:
+            return all(list(Lc.geom[k]) == list(L.geom[k]) for k in ("kernel", "stride", "pad")) and \
+                Lc.geom["cin"] == L.geom["cin"] and Lc.bottom_shapes[0] == L.bottom_shapes[0]
 
         src = self._resolve(L.bottoms[0])
-        if not (point(L) and simple(L)):
+        if not eligible(L):
             return False
         members = [i]
         for j in consumers.get(src, []):
             Lj = layers[j]
             if j <= i or j in absorbed or Lj.type != "Convolution" or len(members) == 3:
                 continue
-            if point(Lj) and simple(Lj) and Lj.geom["bias_term"] == L.geom["bias_term"] and \
-                    Lj.bottom_shapes[0] == L.bottom_shapes[0] and \
+            if eligible(Lj) and same(Lj) and \
                     not any(layers[k].inplace and self._resolve(layers[k].bottoms[0]) == src for k in range(i, j)):
                 members.append(j)
         if len(members) < 2:
             return False
-        geom = hip.conv_geom(L.bottom_shapes[0][0], L.geom["cin"], sum(layers[j].geom["cout"] for j in members),
-                             L.bottom_shapes[0][2:], L.geom["kernel"], L.geom["stride"], L.geom["pad"],
-                             L.top_shapes[0][2:])
-        plan = self.lib.conv_plan(geom, self.num_cu)
-        if plan.ksplit != 1:
-            return False
-        bns = [layers[bn_relu_after(layers[j].tops[0])[0]].name for j in members]
-        eps, labels = [], []
+        # every member is emitted at this position (its only input is the shared bottom): decide its epilogue now
+        found = []
         for j in members:
-            ep, label = self._conv_epilogue(j, layers[j], layers, consumers, outputs, sole_consumer, bn_relu_after,
+            Lj = layers[j]
+            br = bn_relu_after(Lj.tops[0])
+            ep, label = self._conv_epilogue(j, Lj, layers, consumers, outputs, sole_consumer, bn_relu_after,
                                             absorbed, concat_skip)
-            eps.append(ep)
-            labels.append(label)
             if j != i:
                 absorbed[j] = L.name
-        ok = [bool(ep.act.ptr) and ep.act.t == 1 and not ep.raw.ptr and not ep.act2.ptr and not ep.residual.ptr
-              for ep in eps]
-        fuse = [k for k in range(len(members)) if ok[k]]
-        if len(fuse) < 2:
-            fuse = []
-        for k, j in enumerate(members):
-            if k not in fuse:       # a destination the segmented epilogue cannot express (e.g. through Permute)
-                self._emit_conv(i, layers[j], eps[k], labels[k])
-        if fuse:
-            if len(fuse) != len(members):
-                geom = hip.conv_geom(L.bottom_shapes[0][0], L.geom["cin"],
-                                     sum(layers[members[k]].geom["cout"] for k in fuse), L.bottom_shapes[0][2:],
-                                     L.geom["kernel"], L.geom["stride"], L.geom["pad"], L.top_shapes[0][2:])
-                plan = self.lib.conv_plan(geom, self.num_cu)
-            self._emit_sibling_conv(i, [layers[members[k]] for k in fuse], [bns[k] for k in fuse],
-                                    [eps[k] for k in fuse], [labels[k] for k in fuse], geom, plan)
+            if ep is None:
+                continue                                  # (emitted by _conv_epilogue itself)
+            plain = not ep.residual.ptr and not ep.act2.ptr
+            if plain and ep.act.ptr and ep.act.t == 1 and not ep.raw.ptr and br is not None:
+                found.append((Lj, ep, label, ep.act, int(ep.relu), layers[br[0]].name))
+            elif plain and ep.raw.ptr and ep.raw.t == 1 and not ep.act.ptr:
+                found.append((Lj, ep, label, ep.raw, 0, None))
+            else:                                         # a destination the segmented epilogue cannot express
+                self._emit_conv(i, Lj, ep, label)
+        if len(found) == 1:
+            self._emit_conv(i, found[0][0], found[0][1], found[0][2])
+        elif found:
+            self._emit_sibling_conv(i, found)
         return True
 
-    def _emit_sibling_conv(self, i, Ls, bns, eps, labels, geom, plan) -> None:
+    def _emit_sibling_conv(self, i, found) -> None:
+        Ls = [f[0] for f in found]
+        L = Ls[0]
         key = "|".join(Lc.name for Lc in Ls)
         couts = [Lc.geom["cout"] for Lc in Ls]
         ctot = sum(couts)
+        geom = hip.conv_geom(L.bottom_shapes[0][0], L.geom["cin"], ctot, L.bottom_shapes[0][2:], L.geom["kernel"],
+                             L.geom["stride"], L.geom["pad"], L.top_shapes[0][2:])
+        plan = self.lib.conv_plan(geom, self.num_cu)
         st = self._group_dev.setdefault(key, {})
         old = st.get("plan")
         if old is None or (old.wp_elems, old.ktab_elems, st.get("ctot")) != (plan.wp_elems, plan.ktab_elems, ctot):
@@ -946,51 +940,67 @@ class Engine:
                 st[k] = self.alloc.empty(ctot, np.float32)
             st["ctot"] = ctot
         st["geom"], st["plan"] = geom, plan
-        bias_term = bool(Ls[0].geom["bias_term"])
-        self._groups[key] = {"convs": [Lc.name for Lc in Ls], "bns": list(bns), "bias_term": bias_term, "st": st}
+        if plan.ws_bytes > getattr(self, "_ws_bytes", 0):
+            self._ws = self.alloc.empty((plan.ws_bytes + 3) // 4, np.float32)
+            self._ws_bytes = plan.ws_bytes
+        self._groups[key] = {"convs": [Lc.name for Lc in Ls], "bns": [f[5] for f in found], "st": st}
         self._dirty_groups.add(key)
         ep = hip.ConvEpilogue()
-        ep.bias = self.alloc.ptr(st["bias"]) if bias_term else None
-        ep.bn_scale, ep.bn_shift, ep.relu = self.alloc.ptr(st["scale"]), self.alloc.ptr(st["shift"]), 1
+        ep.bias = self.alloc.ptr(st["bias"])
+        ep.bn_scale, ep.bn_shift = self.alloc.ptr(st["scale"]), self.alloc.ptr(st["shift"])
         ep.residual, ep.raw, ep.act2 = hip.null_view(), hip.null_view(), hip.null_view()
-        ep.act = eps[0].act
+        ep.act, ep.relu = found[0][3], found[0][4]
         ep.nseg = len(Ls) - 1
         begin = 0
         for s in range(1, len(Ls)):
             begin += couts[s - 1]
             ep.seg_begin[s - 1] = begin
-            ep.seg_act[s - 1] = eps[s].act
-        x = self._ptr(Ls[0].bottoms[0])
+            ep.seg_relu[s - 1] = found[s][4]
+            ep.seg_act[s - 1] = found[s][3]
+        x = self._ptr(L.bottoms[0])
         wp, kt = self.alloc.ptr(st["wp"]), self.alloc.ptr(st["ktab"])
         self._keep.append((geom, plan, ep))
         lib = self.lib
-        n_in, cin = _prod(Ls[0].bottom_shapes[0]), Ls[0].geom["cin"]
+        k = L.geom["cin"] * _prod(L.geom["kernel"])
         n_out = sum(_prod(Lc.top_shapes[0]) for Lc in Ls)
-        meta = {"kernel": hip.conv_kernel_name(plan), "flops": 2 * n_out * cin,
-                "bytes": 4 * (n_in + cin * ctot + n_out), "siblings": len(Ls)}
-        self._add(i, " | ".join(labels), lambda s, g=geom, plan=plan, x=x, wp=wp, kt=kt, ep=ep:
-                  lib.conv_forward(g, plan, x, wp, kt, ep, None, s), meta)
+        meta = {"kernel": hip.conv_kernel_name(plan), "flops": 2 * n_out * k,
+                "bytes": 4 * (_prod(L.bottom_shapes[0]) + k * ctot + n_out), "siblings": len(Ls)}
+
+        def run(s, g=geom, plan=plan, x=x, wp=wp, kt=kt, ep=ep):
+            lib.conv_forward(g, plan, x, wp, kt, ep, self.alloc.ptr(self._ws) if plan.ws_bytes else None, s)
+        self._add(i, " | ".join(f[2] for f in found), run, meta)
 
     def _sync_groups(self, dirty) -> None:
         """Repack the concatenated weights / bias / folded BN vectors of sibling groups with a changed member."""
         for key, grp in self._groups.items():
-            if key not in self._dirty_groups and not (dirty & set(grp["convs"] + grp["bns"])):
+            if key not in self._dirty_groups and not (dirty & set(grp["convs"] + [b for b in grp["bns"] if b])):
                 continue
             st = grp["st"]
             g, plan = st["geom"], st["plan"]
             w = np.ascontiguousarray(np.concatenate(
-                [np.asarray(self.params[n][0], np.float32).reshape(-1, g.cin) for n in grp["convs"]], 0))
+                [np.asarray(self.params[n][0], np.float32).reshape(self.spec.layer(n).geom["cout"], -1)
+                 for n in grp["convs"]], 0))
             wp = np.empty(plan.wp_elems, np.float32)
             kt = np.empty(plan.ktab_elems, np.int32)
             self.lib.conv_pack_weights(g, plan, w.ctypes.data, wp.ctypes.data, kt.ctypes.data)
             self.alloc.upload(st["wp"], wp)
             self.alloc.upload(st["ktab"], kt)
-            if grp["bias_term"]:
-                self.alloc.upload(st["bias"], np.concatenate([np.asarray(self.params[n][1], np.float32).ravel()
-                                                              for n in grp["convs"]]))
-            folded = [fold_bn(self.params[n], bn_eps(self.spec.layer(n))) for n in grp["bns"]]
-            self.alloc.upload(st["scale"], np.concatenate([a for a, _ in folded]).astype(np.float32))
-            self.alloc.upload(st["shift"], np.concatenate([b for _, b in folded]).astype(np.float32))
+            bias, scale, shift = [], [], []
+            for n, bn in zip(grp["convs"], grp["bns"]):
+                Lc = self.spec.layer(n)
+                c = Lc.geom["cout"]
+                bias.append(np.asarray(self.params[n][1], np.float32).ravel() if Lc.geom["bias_term"]
+                            else np.zeros(c, np.float32))
+                if bn is None:                        # the member keeps its raw value
+                    scale.append(np.ones(c, np.float32))
+                    shift.append(np.zeros(c, np.float32))
+                else:
+                    a, b = fold_bn(self.params[bn], bn_eps(self.spec.layer(bn)))
+                    scale.append(np.asarray(a, np.float32))
+                    shift.append(np.asarray(b, np.float32))
+            self.alloc.upload(st["bias"], np.concatenate(bias))
+            self.alloc.upload(st["scale"], np.concatenate(scale))
+            self.alloc.upload(st["shift"], np.concatenate(shift))
             self._dirty_groups.discard(key)
 
     def _act_destination(self, act_blob, L, layers, consumers, outputs, absorbed, concat_skip):

@@ -72,7 +72,8 @@ class ConvEpilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("residual", View), ("raw", View),
                 ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p),
                 ("relu", C.c_int32), ("act", View), ("act2", View),
-                ("nseg", C.c_int32), ("seg_begin", C.c_int32 * 2), ("seg_act", View * 2)]
+                ("nseg", C.c_int32), ("seg_begin", C.c_int32 * 2), ("seg_relu", C.c_int32 * 2),
+                ("seg_act", View * 2)]
 
 
 class PoolGeom(C.Structure):

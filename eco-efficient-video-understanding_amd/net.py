@@ -372,7 +372,7 @@ class Net:
     def _graph_replay(self) -> None:
         import torch
         eng = self._engine
-        if eng._dirty_params:
+        if eng._dirty_params or eng._dirty_groups:
             eng._sync_params()                       # uploads happen outside the capture (bumps the generation)
         key = eng.generation                         # monotonic: a stale capture can never match a new plan
         if getattr(self, "_graph_key", None) != key or getattr(self, "_graph", None) is None:

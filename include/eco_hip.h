@@ -124,12 +124,14 @@ typedef struct eco_view {
  * Any of bias / residual.ptr / raw.ptr / act.ptr / act2.ptr may be NULL (that step is skipped);
  * bn_scale==NULL means a = v.  At least one of raw.ptr / act.ptr must be non-NULL; act2 needs act.
  *
- * Sibling convolutions: the 1x1 / 3x3_reduce / double_3x3_reduce convs of an Inception block read the same
- * bottom (models_ECO_Lite/kinetics/deploy.prototxt:130-330) and can run as ONE conv whose weights, bias and
- * folded BN vectors are the members' concatenated along the output channel: nseg = members - 1 (0 = plain).
- * Channels [0, seg_begin[0]) go to `act` as usual; channels [seg_begin[s], seg_begin[s+1] or cout) go to
- * seg_act[s] at channel (c - seg_begin[s]).  Boundaries are multiples of 32; segmented launches take act only
- * (no residual / raw / act2), plain views (t = 1), and the fp32 direct kernels without split-K. */
+ * Sibling convolutions: convs of one geometry that read the same bottom -- the 1x1 / 3x3_reduce /
+ * double_3x3_reduce convs of an Inception block (models_ECO_Lite/kinetics/deploy.prototxt:130-330), a residual
+ * block's first conv and its projection shortcut (res4a_1 / res4a_down, res5a_1 / res5a_down) -- can run as ONE
+ * conv whose weights, bias and folded BN vectors are the members' concatenated along the output channel:
+ * nseg = members - 1 (0 = plain).  Channels [0, seg_begin[0]) go to `act` with `relu` as usual; channels
+ * [seg_begin[s], seg_begin[s+1] or cout) go to seg_act[s] at channel (c - seg_begin[s]) with seg_relu[s].  A member
+ * that wants its raw value gets scale 1 / shift 0 / no ReLU.  Boundaries are multiples of 32; segmented launches
+ * take act-style destinations only (no residual / raw / act2), plain views (t = 1), the fp32 direct kernels. */
 typedef struct eco_conv_epilogue {
   const float* bias;
   eco_view residual; /* read-only */
@@ -141,6 +143,7 @@ typedef struct eco_conv_epilogue {
   eco_view act2;
   int32_t nseg;
   int32_t seg_begin[2];
+  int32_t seg_relu[2];
   eco_view seg_act[2];
 } eco_conv_epilogue;
 

@@ -9,7 +9,8 @@ from eco_amd import fillers, hip
 from tests.test_kernels import TOL, relerr
 
 
-def _segmented(be, n, cin, couts, insp, kernel, pad, num_cu, concat_first=True):
+def _segmented(be, n, cin, couts, insp, kernel, pad, num_cu, concat_first=True, stride=None, raw_last=False,
+               want_split=False):
     rng = np.random.default_rng(sum(couts) + cin)
     nd = len(insp)
     x = rng.standard_normal((n, cin) + tuple(insp)).astype(np.float32)
@@ -17,16 +18,21 @@ def _segmented(be, n, cin, couts, insp, kernel, pad, num_cu, concat_first=True):
     bs = [rng.standard_normal(c).astype(np.float32) for c in couts]
     scs = [rng.uniform(0.5, 1.5, c).astype(np.float32) for c in couts]
     shs = [rng.standard_normal(c).astype(np.float32) for c in couts]
-    one = (1,) * nd
+    one = stride or (1,) * nd
     bshape = lambda c: (1, c) + (1,) * nd
-    refs = [np.maximum(orc.convolution(x, w, b, kernel, one, pad) * sc.reshape(bshape(len(b))) + sh.reshape(bshape(len(b))), 0)
+    if raw_last:        # the last member wants its raw value: scale 1, shift 0, no ReLU
+        scs[-1][:] = 1.0
+        shs[-1][:] = 0.0
+    refs = [orc.convolution(x, w, b, kernel, one, pad) * sc.reshape(bshape(len(b))) + sh.reshape(bshape(len(b)))
             for w, b, sc, sh in zip(ws, bs, scs, shs)]
-    S = int(np.prod(insp))
+    refs = [r if (raw_last and k == len(refs) - 1) else np.maximum(r, 0) for k, r in enumerate(refs)]
+    outsp = refs[0].shape[2:]
+    S = int(np.prod(outsp))
     ctot = sum(couts)
     lib = be.lib
-    g = hip.conv_geom(n, cin, ctot, insp, kernel, one, pad, insp)
+    g = hip.conv_geom(n, cin, ctot, insp, kernel, one, pad, outsp)
     plan = lib.conv_plan(g, num_cu)
-    assert plan.ksplit == 1
+    assert (plan.ksplit > 1) == want_split
     wcat = np.ascontiguousarray(np.concatenate(ws, 0))
     wp = np.zeros(plan.wp_elems, np.float32)
     kt = np.zeros(plan.ktab_elems, np.int32)
@@ -40,7 +46,7 @@ def _segmented(be, n, cin, couts, insp, kernel, pad, num_cu, concat_first=True):
     # member 0 writes into channels [5, 5 + c0) of a wider (Concat) tensor, the others into their own tensors
     c0off, wide = 5, couts[0] + 9
     if concat_first:
-        big = be.dev(np.full((n, wide) + tuple(insp), 7.0, np.float32))
+        big = be.dev(np.full((n, wide) + tuple(outsp), 7.0, np.float32))
         ep.act = hip.View(be.ptr(big, c0off * S), wide * S, 0, S, 1)
     else:
         big = be.empty(refs[0].shape)
@@ -52,10 +58,12 @@ def _segmented(be, n, cin, couts, insp, kernel, pad, num_cu, concat_first=True):
         t = be.dev(np.full(refs[s + 1].shape, -3.0, np.float32))
         outs.append(t)
         ep.seg_begin[s] = begin
+        ep.seg_relu[s] = 0 if (raw_last and s == len(couts) - 2) else 1
         ep.seg_act[s] = hip.plain_view(be.ptr(t), c, S)
-    lib.conv_forward(g, plan, be.ptr(dx), be.ptr(dwp), be.ptr(dkt), ep, None)
+    wsb = be.ptr(be.empty((plan.ws_bytes // 4,))) if plan.ws_bytes else None
+    lib.conv_forward(g, plan, be.ptr(dx), be.ptr(dwp), be.ptr(dkt), ep, wsb)
     if concat_first:
-        got = be.host(big, (n, wide) + tuple(insp))
+        got = be.host(big, (n, wide) + tuple(outsp))
         assert relerr(got[:, c0off:c0off + couts[0]], refs[0]) < TOL
         assert (got[:, :c0off] == 7.0).all() and (got[:, c0off + couts[0]:] == 7.0).all()
     else:
@@ -81,6 +89,15 @@ def test_segmented_point_conv(backend, n, cin, couts, insp, num_cu):
 def test_segmented_3x3_direct(backend):
     # the epilogue is shared by every direct kernel: a 3x3 conv through the span / gather kernels
     _segmented(backend, 2, 16, (32, 64), (9, 9), (3, 3), (1, 1), None, concat_first=False)
+
+
+def test_segmented_strided_block_pair(backend):
+    """res4a_1 | res4a_down: two stride-2 3x3x3 convs of one geometry; the shortcut keeps its raw value.  The default
+    device plan for this size is split-K: the reduce launch applies the members' destinations too."""
+    _segmented(backend, 2, 16, (64, 64), (4, 10, 10), (3, 3, 3), (1, 1, 1), None, concat_first=False, stride=(2, 2, 2),
+               raw_last=True, want_split=True)
+    _segmented(backend, 4, 16, (32, 64), (4, 12, 12), (3, 3, 3), (1, 1, 1), 1, concat_first=False, stride=(2, 2, 2),
+               raw_last=True)
 
 
 def test_segment_validation(backend):

@@ -16,6 +16,9 @@ python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 rocprofv3 --kernel-trace --stats -d $PWD/$OUT/trace_bf16 -o bench --output-format csv -- $B --segments 32 --dtype bf16 --steps 10 --warmup 3 > $OUT/trace_bf16.log 2>&1
 python bench.py --segments 32 --dtype bf16 > $OUT/bench_line_bf16.json 2> $OUT/bench_line_bf16.err
 python bench.py --variant full > $OUT/bench_line_full.json 2> $OUT/bench_line_full.err
+# online recognition: one clip per step, the launch list replayed as a hipGraph and submitted call by call
+python bench.py --clips-per-gpu 1 --graph --no-cpu-baseline --steps 200 --warmup 20 > $OUT/bench_line_b1_graph.json 2> $OUT/bench_line_b1_graph.err
+python bench.py --clips-per-gpu 1 --no-cpu-baseline --steps 200 --warmup 20 > $OUT/bench_line_b1.json 2> $OUT/bench_line_b1.err
 python tools/eco_time.py --iterations 5 > $OUT/eco_time.txt 2>&1
 python tools/eco_time.py --iterations 5 --segments 32 --dtype bf16 > $OUT/eco_time_bf16.txt 2>&1
 python tools/eco_time.py --iterations 5 --variant full > $OUT/eco_time_full.txt 2>&1

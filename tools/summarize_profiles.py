@@ -43,8 +43,8 @@ def main():
                 f.write("%s,%s,%.3f,%.1f,%.1f,%.1f,%s\n" % (short(r["Name"]).replace(",", ";"), r["Calls"],
                         float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3,
                         float(r["MaxNs"]) / 1e3, r["Percentage"]))
-    for nm in ("bench_line.json", "bench_line_bf16.json", "bench_line_full.json", "eco_time.txt", "eco_time_bf16.txt",
-               "eco_time_full.txt"):
+    for nm in ("bench_line.json", "bench_line_bf16.json", "bench_line_full.json", "bench_line_b1.json",
+               "bench_line_b1_graph.json", "eco_time.txt", "eco_time_bf16.txt", "eco_time_full.txt"):
         p = os.path.join(src, nm)
         if os.path.exists(p) and os.path.getsize(p):
             with open(p) as fi, open(os.path.join(out_dir, f"{tag}_{nm}"), "w") as fo:
