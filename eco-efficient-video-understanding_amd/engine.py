@@ -138,6 +138,10 @@ class Engine:
         self.wgemm = True          # F(4x4,3x3) GEMMs on the dedicated dense kernel (False: round-1 gather-kernel route)
         self.stem = True           # conv1 + BN + ReLU + pool1 as one launch (False: conv kernel + pooling kernel)
         self.siblings = True       # 1x1 convs reading the same bottom as one launch (fp32 path)
+        # ... and a residual block's strided first conv with its projection shortcut (res4a_1 | res4a_down).  Off:
+        # measured at 32 clips the 512-channel launch quantises worse over the CUs than the two 256-channel ones
+        # (1.73-1.89 ms against 2 x 0.80 ms; res5a: 0.80 against 0.85), see profiles/r02_notes.md
+        self.sibling_blocks = False
         self.num_cu = num_cu       # None = the device's 256 CUs (tests shrink it to reach split-K paths)
         self.params: Dict[str, List[np.ndarray]] = {}
         self._param_dev: Dict[str, dict] = {}    # layer name -> device-side state
@@ -887,6 +891,8 @@ class Engine:
 
         src = self._resolve(L.bottoms[0])
         if not eligible(L):
+            return False
+        if not self.sibling_blocks and not all(k == 1 for k in L.geom["kernel"]):
             return False
         members = [i]
         for j in consumers.get(src, []):

@@ -161,3 +161,26 @@ def test_engine_fuses_inception_siblings(backend, variant):
     ref2 = orc.forward(spec, params, {"data": x}, keep="all", fast_pool=False)
     assert relerr(net.forward()["fc8"], ref2["fc8"]) < TOL
     assert relerr(ref2["fc8"], ref["fc8"]) > 1e-4
+
+
+def test_engine_block_pairs_opt_in(backend):
+    """engine.sibling_blocks: res4a_1 | res4a_down and res5a_1 | res5a_down as one launch each (the shortcut keeps its
+    raw value, the Eltwise moves to the block's second conv): same logits and blobs as the oracle."""
+    from eco_amd.netspec import NetSpec
+    from tests.test_net import make_net, mini
+    proto = mini("lite")
+    spec = NetSpec.from_prototxt(proto)
+    params = fillers.synthetic_params(spec, seed=7)
+    x = fillers.synthetic_frames(8, 32, 32, seed=3)
+    ref = orc.forward(spec, params, {"data": x}, keep="all", fast_pool=False)
+    net = make_net(backend, proto, params, True, winograd=4)
+    net._engine.sibling_blocks = True
+    net._engine.build()
+    net.blobs["data"].data[...] = x
+    out = net.forward()
+    labels = net.op_labels()
+    assert "res4a_1+res4a_1_bn+res4a_1_relu | res4a_down" in labels and "res5a_1+res5a_1_bn+res5a_1_relu | res5a_down" in labels
+    assert relerr(out["fc8"], ref["fc8"]) < TOL
+    for name in ("res4a_down", "res4a", "res4a_bn", "res5a", "res5a_bn"):
+        got = net.blobs[name].data
+        assert relerr(got, ref[name].reshape(got.shape)) < TOL, name
