@@ -43,6 +43,10 @@ struct ConvBArgs {
   const float* bn_scale;
   const float* bn_shift;
   eco_view residual, raw, act, act2;   // blocked views: strides in 8-channel blocks
+  // sibling convs as one launch (eco_conv_epilogue::nseg): 32-row tiles at or above seg_begin[s] write through
+  // seg_act[s] at channel block (c - seg_begin[s]) / 8, with seg_relu[s]
+  int nseg, seg_begin[2], seg_relu[2];
+  eco_view seg_act[2];
   int relu;
   int cblocks, cout, mpad, nstages, taps;
   int Di, Hi, Wi, Do, Ho, Wo;
@@ -143,6 +147,7 @@ template <int TM, int TN, int NS>
 __device__ __forceinline__ void convb_epilogue(const ConvBArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw, int half,
                                                int l31) {
   long e_res[TN], e_raw[TN], e_act[TN], e_act2[TN];
+  int e_img[TN], e_sp[TN];
   bool e_ok[TN];
   const bool has_bias = a.bias != nullptr, has_bn = a.bn_scale != nullptr, has_res = a.residual.ptr != nullptr;
   const bool has_raw = a.raw.ptr != nullptr, has_act = a.act.ptr != nullptr, has_act2 = has_act && a.act2.ptr != nullptr;
@@ -152,6 +157,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvBArgs& a, f32x16 (&acc)
     e_ok[j] = n < a.ntot;
     int img, sp;
     decode_out(a, e_ok[j] ? n : 0, img, sp);
+    e_img[j] = img; e_sp[j] = sp;
     e_res[j] = has_res ? view_base(a.residual, img, sp) : 0;
     e_raw[j] = has_raw ? view_base(a.raw, img, sp) : 0;
     e_act[j] = has_act ? view_base(a.act, img, sp) : 0;
@@ -159,6 +165,18 @@ __device__ __forceinline__ void convb_epilogue(const ConvBArgs& a, f32x16 (&acc)
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    // the destination of this 32-row tile (wave-uniform): `act`, or a sibling's own tensor
+    void* aptr = a.act.ptr;
+    long astride_c = a.act.stride_c;
+    int relu = a.relu, cb0 = 0;
+    const int mt = mw + i * 32;
+    if (a.nseg > 0 && mt >= a.seg_begin[0]) {
+      const int sidx = (a.nseg > 1 && mt >= a.seg_begin[1]) ? 1 : 0;
+      const eco_view& sv = a.seg_act[sidx];
+      aptr = sv.ptr; astride_c = sv.stride_c; relu = a.seg_relu[sidx]; cb0 = a.seg_begin[sidx] / 8;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) e_act[j] = (long)e_img[j] * sv.stride_b + e_sp[j];
+    }   // (tiles ascend: once past seg_begin[0] a wave never returns to `act`)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int ch0 = mw + i * 32 + 8 * g + 4 * half;
@@ -189,9 +207,9 @@ __device__ __forceinline__ void convb_epilogue(const ConvBArgs& a, f32x16 (&acc)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             y[q] = v[q] * ps[q] + ph[q];
-            if (a.relu) y[q] = fmaxf(y[q], 0.0f);
+            if (relu) y[q] = fmaxf(y[q], 0.0f);
           }
-          store_quad<NS>(a.act.ptr, e_act[j] + (long)cbk * a.act.stride_c, half, y);
+          store_quad<NS>(aptr, e_act[j] + (long)(cbk - cb0) * astride_c, half, y);
           if (has_act2) store_quad<NS>(a.act2.ptr, e_act2[j] + (long)cbk * a.act2.stride_c, half, y);
         }
       }
@@ -245,13 +263,19 @@ __global__ __launch_bounds__(256) void convb_splitk_reduce_kernel(const ConvBArg
       }
       if (a.raw.ptr) store_quad<NS>(a.raw.ptr, view_base(a.raw, img, sp) + (long)cbk * a.raw.stride_c, half, v);
       if (a.act.ptr) {
+        eco_view av = a.act;       // sibling launches: the channel block's own destination
+        int relu = a.relu, cb0 = 0;
+        if (a.nseg > 0 && cbk * 8 >= a.seg_begin[0]) {
+          const int sidx = (a.nseg > 1 && cbk * 8 >= a.seg_begin[1]) ? 1 : 0;
+          av = a.seg_act[sidx]; relu = a.seg_relu[sidx]; cb0 = a.seg_begin[sidx] / 8;
+        }
         float y[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           y[q] = v[q] * (a.bn_scale ? ld(a.bn_scale + ch0 + q) : 1.0f) + (a.bn_scale ? ld(a.bn_shift + ch0 + q) : 0.0f);
-          if (a.relu) y[q] = fmaxf(y[q], 0.0f);
+          if (relu) y[q] = fmaxf(y[q], 0.0f);
         }
-        store_quad<NS>(a.act.ptr, view_base(a.act, img, sp) + (long)cbk * a.act.stride_c, half, y);
+        store_quad<NS>(av.ptr, view_base(av, img, sp) + (long)(cbk - cb0) * av.stride_c, half, y);
         if (a.act2.ptr) store_quad<NS>(a.act2.ptr, view_base(a.act2, img, sp) + (long)cbk * a.act2.stride_c, half, y);
       }
     }
@@ -1164,7 +1188,19 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
   ECO_REQUIRE(ep->raw.ptr || ep->act.ptr, "convb: at least one of raw/act outputs is required");
   ECO_REQUIRE(!ep->bn_scale == !ep->bn_shift, "convb: bn_scale and bn_shift must be given together");
   ECO_REQUIRE(!ep->act2.ptr || ep->act.ptr, "convb: act2 needs act");
-  ECO_REQUIRE(ep->nseg == 0, "convb: segmented (sibling) launches exist for the fp32 direct kernels only");
+  if (ep->nseg) {
+    ECO_REQUIRE(ep->nseg >= 1 && ep->nseg <= 2, "convb: 1 or 2 extra output segments (got %d)", ep->nseg);
+    ECO_REQUIRE(ep->act.ptr && ep->act.t == 1 && !ep->raw.ptr && !ep->residual.ptr && !ep->act2.ptr,
+                "convb: a segmented launch takes plain act destinations only (no raw / residual / act2)");
+    int prev = 0;
+    for (int s = 0; s < ep->nseg; ++s) {
+      ECO_REQUIRE(ep->seg_act[s].ptr && ep->seg_act[s].t == 1 && ep->seg_act[s].stride_c >= 1,
+                  "convb: segment %d needs a plain destination view", s + 1);
+      ECO_REQUIRE(ep->seg_begin[s] > prev && ep->seg_begin[s] < g->cout && ep->seg_begin[s] % 32 == 0,
+                  "convb: segment boundary %d must be a multiple of 32 inside (%d, %d)", ep->seg_begin[s], prev, g->cout);
+      prev = ep->seg_begin[s];
+    }
+  }
   const eco_view* views[4] = {&ep->residual, &ep->raw, &ep->act, &ep->act2};
   for (const eco_view* v : views)
     ECO_REQUIRE(!v->ptr || (v->t >= 1 && v->stride_c >= 1), "convb: view needs t >= 1 and stride_c >= 1");
@@ -1173,6 +1209,12 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
   a.x = x; a.wp = (const uint4*)wp;
   a.bias = ep->bias; a.bn_scale = ep->bn_scale; a.bn_shift = ep->bn_shift;
   a.residual = ep->residual; a.raw = ep->raw; a.act = ep->act; a.act2 = ep->act2; a.relu = ep->relu;
+  a.nseg = ep->nseg;
+  for (int s = 0; s < 2; ++s) {
+    a.seg_begin[s] = s < ep->nseg ? ep->seg_begin[s] : 0;
+    a.seg_relu[s] = s < ep->nseg ? ep->seg_relu[s] : 0;
+    a.seg_act[s] = s < ep->nseg ? ep->seg_act[s] : eco_view{nullptr, 0, 0, 0, 1};
+  }
   a.cout = g->cout; a.mpad = plan->mpad; a.nstages = plan->nstages; a.cblocks = plan->cblocks;
   a.Do = g->out[0]; a.Ho = g->out[1]; a.Wo = g->out[2];
   if (plan->stem) {

@@ -877,7 +877,7 @@ class Engine:
         along the output channel are one GEMM that reads (gathers) the input once; each member's 32-row tiles write
         to its own destination (eco_conv_epilogue::nseg).  A member is either seen only through its fused BN + ReLU
         or keeps its raw value (a shortcut whose Eltwise then rides on the block's second conv)."""
-        if self.dt or not self.siblings:
+        if not self.siblings:
             return False
 
         def eligible(Lc) -> bool:
@@ -936,17 +936,24 @@ class Engine:
         ctot = sum(couts)
         geom = hip.conv_geom(L.bottom_shapes[0][0], L.geom["cin"], ctot, L.bottom_shapes[0][2:], L.geom["kernel"],
                              L.geom["stride"], L.geom["pad"], L.top_shapes[0][2:])
-        plan = self.lib.conv_plan(geom, self.num_cu)
         st = self._group_dev.setdefault(key, {})
         old = st.get("plan")
-        if old is None or (old.wp_elems, old.ktab_elems, st.get("ctot")) != (plan.wp_elems, plan.ktab_elems, ctot):
-            st["wp"] = self.alloc.empty(plan.wp_elems, np.float32)
-            st["ktab"] = self.alloc.empty(plan.ktab_elems, np.int32)
+        if self.dt:
+            plan = self.lib.convb_plan(geom, self.dt, self.num_cu)
+            if old is None or (old.wp_vecs, st.get("ctot")) != (plan.wp_vecs, ctot):
+                st["wp"] = self.alloc.empty(plan.wp_vecs * 8, np.uint16)
+        else:
+            plan = self.lib.conv_plan(geom, self.num_cu)
+            if old is None or (old.wp_elems, old.ktab_elems, st.get("ctot")) != (plan.wp_elems, plan.ktab_elems, ctot):
+                st["wp"] = self.alloc.empty(plan.wp_elems, np.float32)
+                st["ktab"] = self.alloc.empty(plan.ktab_elems, np.int32)
+        if st.get("ctot") != ctot:
             for k in ("bias", "scale", "shift"):
                 st[k] = self.alloc.empty(ctot, np.float32)
             st["ctot"] = ctot
         st["geom"], st["plan"] = geom, plan
         if plan.ws_bytes > getattr(self, "_ws_bytes", 0):
+            self._keep.append(getattr(self, "_ws", None))   # launches recorded so far hold the old buffer's address
             self._ws = self.alloc.empty((plan.ws_bytes + 3) // 4, np.float32)
             self._ws_bytes = plan.ws_bytes
         self._groups[key] = {"convs": [Lc.name for Lc in Ls], "bns": [f[5] for f in found], "st": st}
@@ -964,16 +971,25 @@ class Engine:
             ep.seg_relu[s - 1] = found[s][4]
             ep.seg_act[s - 1] = found[s][3]
         x = self._ptr(L.bottoms[0])
-        wp, kt = self.alloc.ptr(st["wp"]), self.alloc.ptr(st["ktab"])
+        wp = self.alloc.ptr(st["wp"])
         self._keep.append((geom, plan, ep))
         lib = self.lib
         k = L.geom["cin"] * _prod(L.geom["kernel"])
         n_out = sum(_prod(Lc.top_shapes[0]) for Lc in Ls)
-        meta = {"kernel": hip.conv_kernel_name(plan), "flops": 2 * n_out * k,
-                "bytes": 4 * (_prod(L.bottom_shapes[0]) + k * ctot + n_out), "siblings": len(Ls)}
+        es = self.esize
+        meta = {"kernel": hip.convb_kernel_name(plan) if self.dt else hip.conv_kernel_name(plan), "flops": 2 * n_out * k,
+                "bytes": es * (_prod(L.bottom_shapes[0]) + n_out) + (2 if self.dt else 4) * k * ctot, "siblings": len(Ls)}
+        if self.dt:
+            if not self.tensors[L.bottoms[0]].dt:
+                raise NetSpecError(f"{L.name}: input blob {L.bottoms[0]} is not channel-blocked")
 
-        def run(s, g=geom, plan=plan, x=x, wp=wp, kt=kt, ep=ep):
-            lib.conv_forward(g, plan, x, wp, kt, ep, self.alloc.ptr(self._ws) if plan.ws_bytes else None, s)
+            def run(s, g=geom, plan=plan, x=x, wp=wp, ep=ep):
+                lib.convb_forward(g, plan, x, wp, ep, self.alloc.ptr(self._ws) if plan.ws_bytes else None, s)
+        else:
+            kt = self.alloc.ptr(st["ktab"])
+
+            def run(s, g=geom, plan=plan, x=x, wp=wp, kt=kt, ep=ep):
+                lib.conv_forward(g, plan, x, wp, kt, ep, self.alloc.ptr(self._ws) if plan.ws_bytes else None, s)
         self._add(i, " | ".join(f[2] for f in found), run, meta)
 
     def _sync_groups(self, dirty) -> None:
@@ -986,11 +1002,16 @@ class Engine:
             w = np.ascontiguousarray(np.concatenate(
                 [np.asarray(self.params[n][0], np.float32).reshape(self.spec.layer(n).geom["cout"], -1)
                  for n in grp["convs"]], 0))
-            wp = np.empty(plan.wp_elems, np.float32)
-            kt = np.empty(plan.ktab_elems, np.int32)
-            self.lib.conv_pack_weights(g, plan, w.ctypes.data, wp.ctypes.data, kt.ctypes.data)
-            self.alloc.upload(st["wp"], wp)
-            self.alloc.upload(st["ktab"], kt)
+            if self.dt:
+                wpb = np.empty(plan.wp_vecs * 8, np.uint16)
+                self.lib.convb_pack_weights(g, plan, w.ctypes.data, wpb.ctypes.data)
+                self.alloc.upload(st["wp"], wpb)
+            else:
+                wp = np.empty(plan.wp_elems, np.float32)
+                kt = np.empty(plan.ktab_elems, np.int32)
+                self.lib.conv_pack_weights(g, plan, w.ctypes.data, wp.ctypes.data, kt.ctypes.data)
+                self.alloc.upload(st["wp"], wp)
+                self.alloc.upload(st["ktab"], kt)
             bias, scale, shift = [], [], []
             for n, bn in zip(grp["convs"], grp["bns"]):
                 Lc = self.spec.layer(n)

@@ -131,7 +131,8 @@ typedef struct eco_view {
  * nseg = members - 1 (0 = plain).  Channels [0, seg_begin[0]) go to `act` with `relu` as usual; channels
  * [seg_begin[s], seg_begin[s+1] or cout) go to seg_act[s] at channel (c - seg_begin[s]) with seg_relu[s].  A member
  * that wants its raw value gets scale 1 / shift 0 / no ReLU.  Boundaries are multiples of 32; segmented launches
- * take act-style destinations only (no residual / raw / act2), plain views (t = 1), the fp32 direct kernels. */
+ * take act-style destinations only (no residual / raw / act2), plain views (t = 1), the direct kernels
+ * (eco_conv_forward, eco_convb_forward; the Winograd output transforms refuse them). */
 typedef struct eco_conv_epilogue {
   const float* bias;
   eco_view residual; /* read-only */

@@ -306,3 +306,36 @@ def test_blocked_path_refuses_unfused_and_foreign_graphs(backend):
     """
     with pytest.raises(NetSpecError, match="no stand-alone kernel on the blocked"):
         Net(lone_relu, dtype="bf16", **kw)
+
+
+def test_blocked_sibling_groups(backend):
+    """bf16 path: the sibling 1x1 convs of an Inception block run as one segmented launch (eco_convb_forward with
+    eco_conv_epilogue::nseg); width_div=2 keeps their widths multiples of 32."""
+    from eco_amd import fillers, models
+    from eco_amd.net import Net
+    from eco_amd.netspec import NetSpec
+    proto = models.eco_lite_deploy(num_segments=4, num_clips=1, num_classes=10, input_size=32, width_div=2)
+    spec = NetSpec.from_prototxt(proto)
+    params = fillers.synthetic_params(spec, seed=11)
+    x = fillers.synthetic_frames(4, 32, 32, seed=5)
+    kw = {"_backend": (backend.lib, backend.alloc)} if backend.kind == "emu" else {}
+    net = Net(proto, params=params, dtype="bf16", _num_cu=1, **kw)
+    net.blobs["data"].data[...] = x
+    out = net.forward()["fc8"].copy()
+    groups = [l for l in net.op_labels() if " | " in l]
+    assert len(groups) >= 2 and any(l.startswith("inception_3a_1x1+") and l.count(" | ") == 2 for l in groups)
+    stored = {n for n, t in net._engine.tensors.items() if t.dt}
+    ref = oracle_blocked(spec, params, x, BF16, stored)
+    assert np.abs(out - ref["fc8"]).max() <= 2e-2 * np.abs(ref["fc8"]).max()
+    for name in ("inception_3a_output", "inception_3b_output", "inception_3a_3x3_reduce_bn", "inception_3b_double_3x3_reduce_bn"):
+        if name in net._engine.tensors:
+            got = net.blobs[name].data
+            r = ref[name].reshape(got.shape)
+            assert np.abs(got - r).max() <= 2e-2 * (np.abs(r).max() + 1e-30), name
+    # switched off: same logits up to bf16 rounding of the same stored blobs
+    net._engine.siblings = False
+    net._engine.build()
+    net.blobs["data"].data[...] = x
+    assert not any(" | " in l for l in net.op_labels())
+    out2 = net.forward()["fc8"]
+    assert np.abs(out2 - out).max() <= 1e-3 * np.abs(out).max()
