@@ -889,6 +889,55 @@ __global__ __launch_bounds__(256) void poolb_kernel(const PoolBArgs a) {
   }
 }
 
+// 2-D 3x3 windows (every pooling layer of the BN-Inception head: pool1 / pool2 MAX 3x3 s2, inception_3x_pool AVE 3x3 s1
+// p1): the nine block loads of an output are independent and all in flight before the first is used (the generic
+// kernel's runtime-bounded loops fetch them one round trip at a time: 3.5 TB/s).  Same arithmetic, same order.
+template <int NS, int METHOD>
+__global__ __launch_bounds__(256) void poolb_k3_kernel(const PoolBArgs a) {
+  const long s_in = (long)a.Hi * a.Wi;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (long)gridDim.x * 256) {
+    const int ow = (int)(i % a.Wo);
+    const long t = i / a.Wo;
+    const int oh = (int)(t % a.Ho);
+    const long ncb = t / a.Ho;
+    const long xb = ncb * s_in;
+    const int hs = oh * a.sh - a.ph, ws = ow * a.sw - a.pw;
+    BlockVec<NS> v[3][3];
+    bool ok[3][3];
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int h = hs + dh, w = ws + dw;
+        ok[dh][dw] = (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi;
+        v[dh][dw] = load_block<NS>(a.x, xb + (ok[dh][dw] ? (long)h * a.Wi + w : 0l));
+      }
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = METHOD == ECO_POOL_MAX ? -FLT_MAX : 0.0f;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        float f[8];
+        block_to_f32<NS>(v[dh][dw], f);
+        if (ok[dh][dw]) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) r[e] = METHOD == ECO_POOL_MAX ? fmaxf(r[e], f[e]) : r[e] + f[e];
+        }
+      }
+    if (METHOD != ECO_POOL_MAX) {   // divisor: the window clipped to the padded image (pooling_layer.cpp:240-262)
+      const int he = min(hs + 3, a.Hi + a.ph), we = min(ws + 3, a.Wi + a.pw);
+      const float size = (float)((he - hs) * (we - ws));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] /= size;
+    }
+    const float lo[4] = {r[0], r[1], r[2], r[3]}, hi[4] = {r[4], r[5], r[6], r[7]};
+    store_quad<NS>(a.y, i, 0, lo);
+    store_quad<NS>(a.y, i, 1, hi);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // global_pool (AVE over the whole volume) -> reshape -> dropout(TEST) -> fc on a blocked volume x[b][c/8][s][8]:
 // grid = (ceil(n_out/128), b), 1024 threads.  Pooling: one wave per channel block, lanes stride over the s
@@ -1322,8 +1371,17 @@ extern "C" int eco_poolb_forward(const eco_pool_geom* g, int32_t dt, const void*
   a.pd = g->pad[0]; a.ph = g->pad[1]; a.pw = g->pad[2];
   a.method = g->method;
   a.total = (long)g->n * (g->c / 8) * a.Do * a.Ho * a.Wo;
-  if (ns == 1) hipLaunchKernelGGL((poolb_kernel<1>), dim3(grid_for_b(a.total)), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((poolb_kernel<3>), dim3(grid_for_b(a.total)), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid(grid_for_b(a.total)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (a.Di == 1 && a.kd == 1 && a.kh == 3 && a.kw == 3) {
+    if (ns == 1 && a.method == ECO_POOL_MAX) hipLaunchKernelGGL((poolb_k3_kernel<1, ECO_POOL_MAX>), grid, block, 0, s, a);
+    else if (ns == 1) hipLaunchKernelGGL((poolb_k3_kernel<1, ECO_POOL_AVE>), grid, block, 0, s, a);
+    else if (a.method == ECO_POOL_MAX) hipLaunchKernelGGL((poolb_k3_kernel<3, ECO_POOL_MAX>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((poolb_k3_kernel<3, ECO_POOL_AVE>), grid, block, 0, s, a);
+    return check_launch("eco_poolb_forward");
+  }
+  if (ns == 1) hipLaunchKernelGGL((poolb_kernel<1>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((poolb_kernel<3>), grid, block, 0, s, a);
   return check_launch("eco_poolb_forward");
 }
 

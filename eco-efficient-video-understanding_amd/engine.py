@@ -705,7 +705,8 @@ class Engine:
             if not self.tensors[L.bottoms[0]].dt:
                 raise NetSpecError(f"{L.name}: input blob {L.bottoms[0]} is not channel-blocked")
             self._add(i, L.name, lambda s, pg=pg, x=x, y=y: lib.poolb_forward(pg, dt, x, y, s),
-                      {"kernel": "eco::poolb_kernel", "flops": 0, "bytes": self.esize * (_prod(b) + _prod(L.top_shapes[0]))})
+                      {"kernel": "eco::poolb_k3_kernel" if len(b) == 4 and list(g["kernel"]) == [3, 3] else "eco::poolb_kernel",
+                       "flops": 0, "bytes": self.esize * (_prod(b) + _prod(L.top_shapes[0]))})
             return
         self._add(i, L.name, lambda s, pg=pg, x=x, y=y: lib.pool_forward(pg, x, y, s),
                   {"kernel": hip.pool_kernel_name(pg), "flops": 0,

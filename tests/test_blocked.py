@@ -172,6 +172,9 @@ def test_convb_concat_slice_and_permuted_store(backend, dt):
 
 
 POOLS = [((2, 16, 9, 9), "MAX", (3, 3), (2, 2), (0, 0)), ((1, 8, 7, 7), "AVE", (3, 3), (1, 1), (1, 1)),
+         ((1, 8, 8, 10), "MAX", (3, 3), (2, 2), (0, 0)),    # ceil rule: the last windows overhang the image
+         ((1, 8, 6, 6), "AVE", (3, 3), (2, 2), (1, 1)),     # divisor counts the padding the window covers
+
          ((2, 8, 4, 5, 5), "AVE", (4, 5, 5), (1, 1, 1), (0, 0, 0)), ((1, 16, 3, 6, 6), "MAX", (2, 3, 3), (1, 2, 2), (0, 1, 1))]
 
 
