@@ -64,6 +64,44 @@ __global__ __launch_bounds__(256) void pool_kernel(const PoolArgs a) {
   }
 }
 
+// 2-D 3x3 windows of any stride / pad (the planes the vector fast paths below do not take: 7x7 and 14x14 -> 7x7 in
+// ECO-Full's inception_4e / 5a / 5b pools): the nine loads of an output are independent and all in flight before the
+// first is used -- the generic kernel's runtime-bounded loops fetch them one round trip at a time.  Same values,
+// same order of the sum / max.
+template <int METHOD>
+__global__ __launch_bounds__(256) void pool2d_k3_kernel(const PoolArgs a) {
+  const long s_in = (long)a.Hi * a.Wi;
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < a.total; i += (long)gridDim.x * kThreads) {
+    const int ow = (int)(i % a.Wo);
+    const long t = i / a.Wo;
+    const int oh = (int)(t % a.Ho);
+    const long nc = t / a.Ho;
+    const float* xp = a.x + nc * s_in;
+    const int hs = oh * a.sh - a.ph, ws = ow * a.sw - a.pw;
+    float v[3][3];
+    bool ok[3][3];
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int h = hs + dh, w = ws + dw;
+        ok[dh][dw] = (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi;
+        v[dh][dw] = ld(xp + (ok[dh][dw] ? (long)h * a.Wi + w : 0l));
+      }
+    float r = METHOD == ECO_POOL_MAX ? -FLT_MAX : 0.0f;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw)
+        if (ok[dh][dw]) r = METHOD == ECO_POOL_MAX ? fmaxf(r, v[dh][dw]) : r + v[dh][dw];
+    if (METHOD != ECO_POOL_MAX) {   // divisor: the window clipped to the padded image (pooling_layer.cpp:240-262)
+      const int he = min(hs + 3, a.Hi + a.ph), we = min(ws + 3, a.Wi + a.pw);
+      r /= (float)((he - hs) * (we - ws));
+    }
+    st(a.y + i, r);
+  }
+}
+
 // VEC consecutive floats as one 16- or 8-byte access.
 template <int VEC>
 __device__ __forceinline__ void ld_vec(const float* p, float (&v)[VEC]) {
@@ -249,11 +287,11 @@ __global__ __launch_bounds__(256) void inner_product_kernel(const float* x, cons
 
 constexpr int kTailMaxC = 2048;
 constexpr int kTailThreads = 1024;        // 16 waves per workgroup
-constexpr int kTailOutPerBlock = 128;
+constexpr int kTailOutPerBlock = 512;      // every logit of a clip from one workgroup: its volume is pooled once
 
-// grid = (ceil(n_out / 128), b), 1024 threads.  Each workgroup pools its clip's C channels into LDS
-// (one wave per channel, two channels in flight per wave, 64-lane butterfly reduce), then its 16 waves
-// produce 128 logits (one wave per logit: lanes stride over C, butterfly reduce).
+// grid = (ceil(n_out / 512), b), 1024 threads.  Each workgroup pools its clip's C channels into LDS
+// (one wave per channel, four loads in flight per lane, 64-lane butterfly reduce), then its 16 waves
+// produce the logits (one wave per logit: lanes stride over C, butterfly reduce).
 // `t` > 1: the clip's volume is spread over t consecutive images of c x s each (a 2-D stream's frames,
 // x[b*t + f][c][s]) and the mean runs over all t*s values of a channel: 2-D global pool + segment consensus.
 __global__ __launch_bounds__(1024) void global_avgpool_fc_kernel(const float* x, const float* w, const float* bias,
@@ -267,22 +305,31 @@ __global__ __launch_bounds__(1024) void global_avgpool_fc_kernel(const float* x,
   const float* xb = x + (long)b * t * c * s;
   const float inv = 1.0f / ((float)s * (float)t);
   const long fstride = (long)c * s;
-  for (int ch = wave; ch < c; ch += 2 * kWaves) {
-    const int ch2 = ch + kWaves;
+  // one channel per wave at a time; a lane owns positions lane, lane+64, ... of each of the t frames (no division in
+  // the loop, four independent partial sums so that four loads are in flight)
+  for (int ch = wave; ch < c; ch += kWaves) {
     const float* xp = xb + (long)ch * s;
-    const float* xq = xb + (long)(ch2 < c ? ch2 : ch) * s;
-    float a0 = 0.0f, a1 = 0.0f;
-    for (int i = lane; i < s * t; i += kWave) {
-      const int f = i / s, r = i - f * s;
-      a0 += ld(xp + f * fstride + r);
-      a1 += ld(xq + f * fstride + r);
+    float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+    if (s <= kWave) {          // 2-D stream: one load per frame (7x7 planes)
+      int f = 0;
+      for (; f + 3 < t; f += 4) {
+        const float* row = xp + f * fstride + lane;
+        if (lane < s) { p0 += ld(row); p1 += ld(row + fstride); p2 += ld(row + 2 * fstride); p3 += ld(row + 3 * fstride); }
+      }
+      for (; f < t; ++f)
+        if (lane < s) p0 += ld(xp + f * fstride + lane);
+    } else {
+      for (int f = 0; f < t; ++f) {
+        const float* row = xp + f * fstride;
+        int r = lane;
+        for (; r + 3 * kWave < s; r += 4 * kWave) {
+          p0 += ld(row + r); p1 += ld(row + r + kWave); p2 += ld(row + r + 2 * kWave); p3 += ld(row + r + 3 * kWave);
+        }
+        for (; r < s; r += kWave) p0 += ld(row + r);
+      }
     }
-    a0 = wave_sum(a0);
-    a1 = wave_sum(a1);
-    if (lane == 0) {
-      pooled[ch] = a0 * inv;
-      if (ch2 < c) pooled[ch2] = a1 * inv;
-    }
+    const float a0 = wave_sum((p0 + p1) + (p2 + p3));
+    if (lane == 0) pooled[ch] = a0 * inv;
   }
   __syncthreads();
   const int o_begin = (int)blockIdx.x * kTailOutPerBlock;
@@ -481,6 +528,11 @@ extern "C" int eco_pool_forward(const eco_pool_geom* g, const float* x, float* y
   a.pd = g->pad[0]; a.ph = g->pad[1]; a.pw = g->pad[2];
   a.method = g->method;
   a.total = rows * a.Do * a.Ho * a.Wo;
+  if (two_d && a.kh == 3 && a.kw == 3) {
+    if (a.method == ECO_POOL_MAX) hipLaunchKernelGGL((pool2d_k3_kernel<ECO_POOL_MAX>), dim3(grid_for(a.total)), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((pool2d_k3_kernel<ECO_POOL_AVE>), dim3(grid_for(a.total)), dim3(kThreads), 0, s, a);
+    return check_launch("eco_pool_forward(3x3)");
+  }
   hipLaunchKernelGGL((pool_kernel), dim3(grid_for(a.total)), dim3(kThreads), 0, s, a);
   return check_launch("eco_pool_forward");
 }

@@ -145,6 +145,8 @@ def pool_kernel_name(g: "PoolGeom") -> str:
     if two_d and g.method == POOL_AVE and k == (3, 3) and s == (1, 1) and p == (1, 1) and g.in_[2] % 2 == 0 \
             and g.in_[1] >= 2 and g.in_[2] >= 4:
         return "eco::avgpool2d_k3s1p1_kernel<%d>" % (4 if g.in_[2] % 4 == 0 else 2)
+    if two_d and k == (3, 3):
+        return "eco::pool2d_k3_kernel"
     return "eco::pool_kernel"
 
 

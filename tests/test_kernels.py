@@ -239,6 +239,9 @@ POOLS = [
     ("MAX", (2, 2), (6, 6), (3, 3), (2, 2), (2, 2)),            # padded max (reference :475-518 geometry)
     ("MAX", (1, 3), (7, 7), (3, 3), (1, 1), (1, 1)),            # inception_5b_pool (ECO-Full)
     ("AVE", (2, 3), (6, 6), (3, 3), (1, 1), (1, 1)),            # inception_3a_pool
+    ("AVE", (1, 3), (7, 7), (3, 3), (1, 1), (1, 1)),            # inception_5a_pool (ECO-Full): unrolled 3x3 kernel
+    ("MAX", (2, 2), (14, 14), (3, 3), (2, 2), (0, 0)),          # inception_4e_pool: 14 -> 7, overhanging last window
+    ("AVE", (1, 2), (9, 7), (3, 3), (2, 2), (1, 1)),            # divisor counts covered padding, clipped at H + pad
     ("AVE", (1, 1), (3, 3, 3), (3, 3, 3), (1, 1, 1), (1, 1, 1)),  # reference 3-D AVE golden geometry
     ("AVE", (2, 5), (4, 7, 7), (4, 7, 7), (1, 1, 1), (0, 0, 0)),  # global_pool (wave-reduction kernel)
     ("AVE", (2, 1), (4, 10), (4, 1), (1, 1), (0, 0)),           # segment_consensus_st2 (kernel_h=N, kernel_w=1)
