@@ -1153,7 +1153,7 @@ extern "C" int eco_conv_plan_create_batched(const eco_conv_geom* g, int32_t num_
       if (work) *work = (double)nz_sum / ((double)g->kernel[0] * (ncols - col0 > 0 ? ncols - col0 : 1));
       return wgs;
     };
-    int max_sp = 16;
+    int max_sp = 64;
     if (max_sp > nstages / 8) max_sp = nstages / 8;
     if (max_sp > ngroups) max_sp = ngroups;
     // A batched launch (gridDim.y = batch entries of this plan, e.g. the Winograd transform points) fills the

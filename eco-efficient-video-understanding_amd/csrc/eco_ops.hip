@@ -287,16 +287,18 @@ __global__ __launch_bounds__(256) void inner_product_kernel(const float* x, cons
 
 constexpr int kTailMaxC = 2048;
 constexpr int kTailThreads = 1024;        // 16 waves per workgroup
-constexpr int kTailOutPerBlock = 512;      // every logit of a clip from one workgroup: its volume is pooled once
+constexpr int kTailWorkgroups = 64;        // launch at least this many workgroups when the batch alone is smaller
 
-// grid = (ceil(n_out / 512), b), 1024 threads.  Each workgroup pools its clip's C channels into LDS
-// (one wave per channel, four loads in flight per lane, 64-lane butterfly reduce), then its 16 waves
-// produce the logits (one wave per logit: lanes stride over C, butterfly reduce).
+// grid = (logit blocks, b), 1024 threads.  Each workgroup pools its clip's C channels into LDS (one wave per
+// channel, four loads in flight per lane, 64-lane butterfly reduce), then its 16 waves produce its block of logits
+// (one wave per logit: lanes stride over C, butterfly reduce).  With b >= 64 clips a workgroup makes every logit of
+// its clip (the volume is pooled once); smaller batches cut the logits into blocks so that ~64 workgroups run --
+// a single clip's 400 x 512 fc on one CU took 0.155 ms of a 1.75 ms online step.
 // `t` > 1: the clip's volume is spread over t consecutive images of c x s each (a 2-D stream's frames,
 // x[b*t + f][c][s]) and the mean runs over all t*s values of a channel: 2-D global pool + segment consensus.
 __global__ __launch_bounds__(1024) void global_avgpool_fc_kernel(const float* x, const float* w, const float* bias,
                                                                  float* y, int c, int s, int t, int n_out, int wk,
-                                                                 int c0, int accumulate) {
+                                                                 int c0, int accumulate, int out_per_block) {
   __shared__ float pooled[kTailMaxC];
   constexpr int kWaves = kTailThreads / kWave;
   const int lane = lane_id();
@@ -332,8 +334,8 @@ __global__ __launch_bounds__(1024) void global_avgpool_fc_kernel(const float* x,
     if (lane == 0) pooled[ch] = a0 * inv;
   }
   __syncthreads();
-  const int o_begin = (int)blockIdx.x * kTailOutPerBlock;
-  const int o_end = min(o_begin + kTailOutPerBlock, n_out);
+  const int o_begin = (int)blockIdx.x * out_per_block;
+  const int o_end = min(o_begin + out_per_block, n_out);
   for (int o = o_begin + wave; o < o_end; o += kWaves) {
     const float* wr = w + (long)o * wk + c0;
     float acc = 0.0f;
@@ -628,9 +630,12 @@ extern "C" int eco_global_avgpool_fc_seg_forward(const float* x, const float* w,
   ECO_REQUIRE(c0 >= 0 && c0 + c <= wk, "global_avgpool_fc: weight columns [%ld,%ld) outside row length %ld", (long)c0,
               (long)(c0 + c), (long)wk);
   ECO_REQUIRE(b <= 65535 && s < 2147483647l, "global_avgpool_fc: batch too large for one launch");
-  dim3 grid((unsigned)ceil_div(n_out, kTailOutPerBlock), (unsigned)b);
+  long blocks = ceil_div(kTailWorkgroups, b);                       // logit blocks per clip
+  if (blocks > ceil_div(n_out, 16)) blocks = ceil_div(n_out, 16);   // at least one logit per wave
+  const int out_per_block = (int)(ceil_div(ceil_div(n_out, blocks), 16) * 16);
+  dim3 grid((unsigned)ceil_div(n_out, out_per_block), (unsigned)b);
   hipLaunchKernelGGL((global_avgpool_fc_kernel), grid, dim3(kTailThreads), 0, (hipStream_t)stream, x, w, bias, y, (int)c,
-                     (int)s, (int)t, (int)n_out, (int)wk, (int)c0, accumulate);
+                     (int)s, (int)t, (int)n_out, (int)wk, (int)c0, accumulate, out_per_block);
   return check_launch("eco_global_avgpool_fc_forward");
 }
 
