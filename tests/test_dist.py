@@ -94,3 +94,52 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 4
     assert line["config"]["collective_ranks"] == 2 and line["config"]["collective_backend"] == "gloo"
     assert line["value"] > 0 and line["cpu_baseline"] is None and "step_frac" in line["roofline"]
+
+
+_RCCL_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+import torch.distributed as dist
+import eco_amd as caffe
+from eco_amd import fillers, models
+from eco_amd.netspec import NetSpec
+dev = torch.device("cuda", 0)
+caffe.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+proto = models.eco_lite_deploy(num_segments=4, num_clips=2, num_classes=10, input_size=32, width_div=8)
+spec = NetSpec.from_prototxt(proto)
+net = caffe.Net(proto, caffe.TEST, params=fillers.synthetic_params(spec, seed=3))
+net.set_input_device("data", torch.from_numpy(fillers.synthetic_frames(8, 32, 32, seed=1)).to(dev))
+logits = net.blobs["fc8"].tensor
+out = torch.full_like(logits, float("nan"))
+for _ in range(3):                       # the collective is ordered behind the launches of the same step
+    net.forward_device()
+    dist.all_gather_into_tensor(out, logits)
+torch.cuda.synchronize()
+assert torch.equal(out, logits) and bool(torch.isfinite(out).all()), (out, logits)
+print("RCCL_OK", dist.get_backend(), dist.get_world_size())
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_collective_behind_engine_launches(tmp_path):
+    """The production backend ("nccl" = RCCL) on the one GPU of the test box: a world-size-1 communicator, the
+    logits all-gather issued right behind the engine's launches (which go through the raw stream handle) and
+    compared after one synchronise.  Skipped when RCCL cannot bootstrap on the box (no usable interface)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(_RCCL_SCRIPT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               NCCL_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        out = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=300, env=env)
+    except subprocess.TimeoutExpired:
+        pytest.skip("RCCL bootstrap did not finish within 300 s on this box")
+    if out.returncode != 0 and ("ncclSystemError" in out.stderr or "ncclInternalError" in out.stderr or
+                                "No socket interface" in out.stderr or "unhandled system error" in out.stderr):
+        pytest.skip("RCCL cannot bootstrap here: " + out.stderr.strip().splitlines()[-1][:200])
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "RCCL_OK nccl 1" in out.stdout
