@@ -135,6 +135,7 @@ class Engine:
         if winograd not in (False, True, 2, 4):
             raise ValueError("winograd must be False, True, 2 or 4")
         self.winograd = winograd
+        self.wino_min_tiles = 64   # size rule of winograd=True: tile positions per transform point
         self.wgemm = True          # F(4x4,3x3) GEMMs on the dedicated dense kernel (False: round-1 gather-kernel route)
         self.stem = True           # conv1 + BN + ReLU + pool1 as one launch (False: conv kernel + pooling kernel)
         self.siblings = True       # 1x1 convs reading the same bottom as one launch (fp32 path)
@@ -495,12 +496,13 @@ class Engine:
             return False
         if g["cin"] < 64 or g["cout"] > 4 * g["cin"]:
             return False
-        # each transform point is a GEMM over n*D*ceil(H/M)*ceil(W/M) tile positions in 128/256-wide tiles: with
-        # a clip or two the deeper stages would be mostly tile padding (measured: a single clip is 8 % faster
-        # direct, two clips 16 % faster with Winograd); an explicit winograd=2/4 overrides the size rule
+        # each transform point is a GEMM over n*D*ceil(H/M)*ceil(W/M) tile positions in 128/256-wide tiles: below
+        # wino_min_tiles positions the layer is mostly tile padding and runs direct (split-K span kernel).  Measured
+        # per step at 1 / 2 / 4 clips: threshold 256: 1.47 / 1.90 / 2.93 ms, 64: 1.43 / 1.90 / 2.86, 16: 1.57 / 2.00 /
+        # 2.86; an explicit winograd=2/4 overrides the size rule
         if self.winograd is True:
             n, D, H, W, _ = self._wino_dims(L)
-            return n * D * -(-H // 4) * -(-W // 4) >= 256
+            return n * D * -(-H // 4) * -(-W // 4) >= self.wino_min_tiles
         return True
 
     def _plan_wino(self, L: LayerSpec, st: dict) -> None:
