@@ -442,6 +442,10 @@ extern "C" int eco_wgemm_plan_create(int32_t n, int32_t cin, int32_t cout, int32
         if (t < best * 0.97) { best = t; plan->bn = bn; plan->ksplit = sp; }
       }
   }
+  // Short reductions (the 2-D layers: 4-6 stages) sit on the HBM ridge and spend a third of a tile's life storing:
+  // 128-wide tiles keep three workgroups per CU instead of two in flight (measured over the seven 2-D GEMMs of the
+  // configs[1] step: 2.07 -> 1.98 ms).
+  if (plan->nstages <= 6 && plan->ksplit == 1) plan->bn = 128;
   const long nb = (long)n * th * tw;
   const int pd = kd / 2;
   plan->mblocks = (int)ceil_div(cout, bm);
