@@ -287,13 +287,16 @@ __global__ __launch_bounds__(256) void inner_product_kernel(const float* x, cons
 
 constexpr int kTailMaxC = 2048;
 constexpr int kTailThreads = 1024;        // 16 waves per workgroup
-constexpr int kTailWorkgroups = 64;        // launch at least this many workgroups when the batch alone is smaller
+// Workgroups to aim for: every one of them pools its clip's whole volume again, so a big volume (ECO-Full's 2-D
+// stream: 16 x 1024 x 49 floats per clip) is cut into few logit blocks and a small one (the 3-D stream: 512 x 196)
+// into many -- there the fc rows, one wave per logit, are the longer phase.
+constexpr int kTailWorkgroupsBigVolume = 64, kTailWorkgroupsSmallVolume = 256;
 
 // grid = (logit blocks, b), 1024 threads.  Each workgroup pools its clip's C channels into LDS (one wave per
 // channel, four loads in flight per lane, 64-lane butterfly reduce), then its 16 waves produce its block of logits
-// (one wave per logit: lanes stride over C, butterfly reduce).  With b >= 64 clips a workgroup makes every logit of
-// its clip (the volume is pooled once); smaller batches cut the logits into blocks so that ~64 workgroups run --
-// a single clip's 400 x 512 fc on one CU took 0.155 ms of a 1.75 ms online step.
+// (one wave per logit: lanes stride over C, butterfly reduce).  The logits of a clip are cut into blocks so that
+// 64-256 workgroups run whatever the batch (a single clip's 400 x 512 fc on one CU took 0.155 ms of a 1.75 ms
+// online step); every block pools the clip again, from L2.
 // `t` > 1: the clip's volume is spread over t consecutive images of c x s each (a 2-D stream's frames,
 // x[b*t + f][c][s]) and the mean runs over all t*s values of a channel: 2-D global pool + segment consensus.
 __global__ __launch_bounds__(1024) void global_avgpool_fc_kernel(const float* x, const float* w, const float* bias,
@@ -312,11 +315,16 @@ __global__ __launch_bounds__(1024) void global_avgpool_fc_kernel(const float* x,
   for (int ch = wave; ch < c; ch += kWaves) {
     const float* xp = xb + (long)ch * s;
     float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
-    if (s <= kWave) {          // 2-D stream: one load per frame (7x7 planes)
+    if (s <= kWave) {          // 2-D stream: one load per frame (7x7 planes), eight frames in flight
       int f = 0;
-      for (; f + 3 < t; f += 4) {
+      for (; f + 7 < t; f += 8) {
         const float* row = xp + f * fstride + lane;
-        if (lane < s) { p0 += ld(row); p1 += ld(row + fstride); p2 += ld(row + 2 * fstride); p3 += ld(row + 3 * fstride); }
+        if (lane < s) {
+          float q[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) q[u] = ld(row + u * fstride);
+          p0 += q[0] + q[4]; p1 += q[1] + q[5]; p2 += q[2] + q[6]; p3 += q[3] + q[7];
+        }
       }
       for (; f < t; ++f)
         if (lane < s) p0 += ld(xp + f * fstride + lane);
@@ -630,7 +638,8 @@ extern "C" int eco_global_avgpool_fc_seg_forward(const float* x, const float* w,
   ECO_REQUIRE(c0 >= 0 && c0 + c <= wk, "global_avgpool_fc: weight columns [%ld,%ld) outside row length %ld", (long)c0,
               (long)(c0 + c), (long)wk);
   ECO_REQUIRE(b <= 65535 && s < 2147483647l, "global_avgpool_fc: batch too large for one launch");
-  long blocks = ceil_div(kTailWorkgroups, b);                       // logit blocks per clip
+  const bool big = c * s * t > 262144;                              // > 1 MB of fp32 per clip
+  long blocks = ceil_div(big ? kTailWorkgroupsBigVolume : kTailWorkgroupsSmallVolume, b);   // logit blocks per clip
   if (blocks > ceil_div(n_out, 16)) blocks = ceil_div(n_out, 16);   // at least one logit per wave
   const int out_per_block = (int)(ceil_div(ceil_div(n_out, blocks), 16) * 16);
   dim3 grid((unsigned)ceil_div(n_out, out_per_block), (unsigned)b);
