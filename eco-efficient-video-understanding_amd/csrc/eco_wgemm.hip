@@ -255,6 +255,53 @@ __global__ __launch_bounds__(256) void wino_input_pk_kernel(const WinoInPkArgs a
   }
 }
 
+// The same transform into the layout of the fused 2-D kernel below, V4[p][c/8][r][c%2][(c/2)%4]: the four k-pair
+// elements a lane of wfused_kernel consumes in a row are one 16-byte vector.  One thread per float of a point's
+// plane, consecutive threads on consecutive floats (256 contiguous bytes per wave and point); D = 1, no padding planes.
+template <int VEC>
+__global__ __launch_bounds__(256) void wino_input_q4_kernel(const WinoInPkArgs a) {
+  const long total = (long)a.cin * a.NB;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c4 = (int)(idx & 3), e = (int)((idx >> 2) & 1);
+    const long pos = idx >> 3;
+    const int r = (int)(pos % a.NB);
+    const int q = (int)(pos / a.NB);
+    const int ch = 8 * q + 2 * c4 + e;
+    float* out = a.v + idx;
+    const int tw = r % a.TW, t2 = r / a.TW;
+    const int th = t2 % a.TH, b = t2 / a.TH;
+    const float* xp = a.x + ((long)b * a.cin + ch) * a.H * a.W;
+    float dd[6][6], v[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int h = 4 * th - 1 + i;
+      const bool hok = (unsigned)h < (unsigned)a.H;
+      const float* rp = xp + (hok ? (long)h * a.W : 0l);
+      const int wl = 4 * tw - 1, wr = 4 * tw + 4;
+      const bool lok = hok && wl >= 0, rok = hok && wr < a.W;
+      dd[i][0] = lok ? ld(rp + (lok ? wl : 0)) : 0.0f;
+      dd[i][5] = rok ? ld(rp + (rok ? wr : 0)) : 0.0f;
+      if (VEC == 4) {
+        const bool ok = hok && 4 * tw < a.W;   // W % 4 == 0: the four columns are inside or outside together
+        const float4 qv = ld((const float4*)(rp + (ok ? 4 * tw : 0)));
+        dd[i][1] = ok ? qv.x : 0.0f; dd[i][2] = ok ? qv.y : 0.0f; dd[i][3] = ok ? qv.z : 0.0f; dd[i][4] = ok ? qv.w : 0.0f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int w = 4 * tw + j;
+          const bool ok = hok && w < a.W;
+          dd[i][1 + j] = ok ? ld(rp + (ok ? w : 0)) : 0.0f;
+        }
+      }
+    }
+    wino_bt_d_b(dd, v);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) st(out + (long)(6 * i + j) * a.v_pstride, v[i][j]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Output transform from M[p][slice][cout][d][r]: y tile = A^T (sum over slices m) A, then the fused epilogue
 // (bias, Eltwise residual, raw store, folded BN, ReLU, both activated destinations; strided views).
@@ -279,6 +326,82 @@ struct WgVec<2> { typedef float2 type; };
 template <>
 struct WgVec<4> { typedef float4 type; };
 
+// Second half of an output tile: y = s4 A with s4 = A^T m (4 x 6), then the fused epilogue, for channel `ch` of image
+// `img`, depth `d`, tile (th, tw).
+template <int VEC>
+__device__ __forceinline__ void wino_output_from_s4(const WinoOutDmArgs& a, const float (&s4)[4][6], int ch, int img, int d,
+                                                    int th, int tw) {
+  constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+  typedef typename WgVec<VEC>::type vec_t;
+  const float b = a.bias ? ld(a.bias + ch) : 0.0f;
+  const float sc = a.bn_scale ? ld(a.bn_scale + ch) : 1.0f, sh = a.bn_scale ? ld(a.bn_shift + ch) : 0.0f;
+  const long o_res = a.residual.ptr ? view_base(a.residual, img, 0) + (long)ch * a.residual.stride_c : 0;
+  const long o_raw = a.raw.ptr ? view_base(a.raw, img, 0) + (long)ch * a.raw.stride_c : 0;
+  const long o_act = a.act.ptr ? view_base(a.act, img, 0) + (long)ch * a.act.stride_c : 0;
+  const long o_act2 = a.act2.ptr ? view_base(a.act2, img, 0) + (long)ch * a.act2.stride_c : 0;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int h = 4 * th + p;
+    if (h >= a.H) continue;
+#pragma unroll
+    for (int q0 = 0; q0 < 4; q0 += VEC) {
+      const int w0 = 4 * tw + q0;
+      if (w0 >= a.W) continue;  // W % VEC == 0: the VEC outputs are inside or outside together
+      float val[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float y = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          if (AT[q0 + e][k] != 0.0f) y += s4[p][k] * AT[q0 + e][k];
+        val[e] = y + b;
+      }
+      const int sp = (d * a.H + h) * a.W + w0;
+      if (a.residual.ptr) {
+        const vec_t rv = ld((const vec_t*)((const float*)a.residual.ptr + o_res + sp));
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) val[e] += ((const float*)&rv)[e];
+      }
+      if (a.raw.ptr) {
+        vec_t ov;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) ((float*)&ov)[e] = val[e];
+        st((vec_t*)(a.raw.ptr + o_raw + sp), ov);
+      }
+      if (a.act.ptr) {
+        vec_t ov;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float o = val[e] * sc + sh;
+          if (a.relu) o = fmaxf(o, 0.0f);
+          ((float*)&ov)[e] = o;
+        }
+        st((vec_t*)(a.act.ptr + o_act + sp), ov);
+        if (a.act2.ptr) st((vec_t*)(a.act2.ptr + o_act2 + sp), ov);
+      }
+    }
+  }
+}
+
+// One output tile: y = A^T m A, then the fused epilogue.
+template <int VEC>
+__device__ __forceinline__ void wino_output_tile(const WinoOutDmArgs& a, const float (&m)[6][6], int ch, int img, int d,
+                                                 int th, int tw) {
+  constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+  float s4[4][6];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (AT[p][k] != 0.0f) acc += AT[p][k] * m[k][j];
+      s4[p][j] = acc;
+    }
+  wino_output_from_s4<VEC>(a, s4, ch, img, d, th, tw);
+}
+
 // A thread takes one tile column r of one (channel, depth) row of M, in M's own order (ch, d, r): every point's load
 // is contiguous across the wave (256 B per point) and the stores are runs of one H x W plane per (img, ch, d).
 // (The (img, ch, d, t) order -- stores contiguous over the whole tensor, M read in runs of TH*TW floats: 196 / 64 /
@@ -286,8 +409,6 @@ struct WgVec<4> { typedef float4 type; };
 // loads of M were slower again: 72 / 144 live tile values.)
 template <int VEC>
 __global__ __launch_bounds__(256) void wino_output_dm_kernel(const WinoOutDmArgs a) {
-  constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
-  typedef typename WgVec<VEC>::type vec_t;
   const long total = (long)a.cout * a.ntot;
   const int tpp = a.TH * a.TW;
   for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
@@ -307,64 +428,124 @@ __global__ __launch_bounds__(256) void wino_output_dm_kernel(const WinoOutDmArgs
         for (int sl = 1; sl < a.ksplit; ++sl) s += ld(qq + (long)sl * a.cout * a.ntot);
         m[i][j] = s;
       }
-    float s4[4][6];
+    wino_output_tile<VEC>(a, m, ch, img, d, th, tw);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused transformed-domain GEMM + output transform for the short-reduction 2-D layers (kd = 1, cin = 64 / 96:
+// conv2_3x3 and the inception 3x3 convs).  As separate launches these layers write M (2.25x the output, fp32) and
+// read it back: conv2_3x3 alone moves 5.5 GB that way.  Here a workgroup owns 32 output channels x 32 tile columns
+// and walks the 36 points in three groups of two transform rows (12 points): wave w computes the 32x32 products of
+// three points of the group with both operands loaded straight from global memory into registers (four consecutive
+// k-pair elements of a lane are one 16-byte vector in V4's and the packed U's layouts, consecutive lanes on
+// consecutive vectors; the stream runs three 16-k-pair chunks ahead of the MFMAs, across group boundaries), parks them in LDS as
+// M[12][32][32] (48 KB: two workgroups per CU, one transforming while the other multiplies), and after a barrier
+// every thread folds the group's two rows into the A^T m partial sums of its four (channel, column) pairs.  After
+// the third group the second half of the transform and the epilogue run from registers.  M never exists in HBM.
+// The tile cannot be larger (36 points x 32 x 32 x 4 B = 144 KB is all of the LDS), so each product reads its
+// operands from L2 once: 8 flop per byte, L2-bandwidth bound (measured 11.5 TB/s with the MFMAs removed).
+struct WFusedArgs {
+  const float* v;     // V4[36][KP/4][NB][2][4]  (wino_input_q4_kernel)
+  const float* u;     // [36][mblocks][KP/4][64 lanes][4]: lane (m = l&31, half = l>>5) holds A[m][2*(4*q+i)+half], i < 4
+  WinoOutDmArgs o;    // epilogue, views, image / tile geometry (D = 1)
+  int mblocks, nblk;
+  int Q;
+  long v_pstride, u_pstride;
+};
+
+template <int KP, int VEC>
+__global__ __launch_bounds__(256, 2) void wfused_kernel(const WFusedArgs a) {
+  constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+  constexpr int CH = 16;                 // k-pairs per chunk
+  constexpr int NCH = KP / CH;           // chunks per point
+  constexpr int NPT = 9;                 // points per wave: three per group
+  constexpr int T = NPT * NCH;           // chunks per wave
+  constexpr int R = 3;                   // chunks in flight: 3 x 8 sixteen-byte loads per lane (4 would spill)
+  static_assert(KP % CH == 0, "");
+  ECO_DYNAMIC_LDS(lds);                  // M[12][32][32]: the group's points, local index lp = 6*(row & 1) + column
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tile = xcd_remap((int)blockIdx.x, a.mblocks * a.nblk);
+  const int mb = tile % a.mblocks, nb = tile / a.mblocks;
+  const int n0 = nb * 32;
+  const int loff = 2 * l31 + half;       // this lane's 16-byte vector within a (q, 32 columns) row of V4 ([col][2][4])
+
+  float4 ra[R][CH / 4], rb[R][CH / 4];
+  auto issue = [&](int slot, int t) {    // chunk t: point index t / NCH = 3*group + k, local point lp = wave + 4*k
+    const int pi = t / NCH, c = t % NCH;
+    const int p = 12 * (pi / 3) + wave + 4 * (pi % 3);
+    const float4* up = (const float4*)(a.u + (long)p * a.u_pstride + ((long)mb * KP + c * CH) * 64) + lane;
+    const float4* vp = (const float4*)(a.v + (long)p * a.v_pstride) + ((long)(c * (CH / 4)) * a.Q + n0) * 2 + loff;
+#pragma unroll
+    for (int k4 = 0; k4 < CH / 4; ++k4) ra[slot][k4] = ld(up + k4 * 64);
+#pragma unroll
+    for (int k4 = 0; k4 < CH / 4; ++k4) rb[slot][k4] = ld(vp + (long)k4 * a.Q * 2);
+  };
+#pragma unroll
+  for (int t = 0; t < R; ++t) issue(t, t);
+  sched_fence();
+  float s4[4][4][6];                     // A^T m partial sums of this thread's pairs (channel (tid>>5) + 8u, column tid&31)
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        float acc = 0.0f;
+      for (int j = 0; j < 6; ++j) s4[u][p][j] = 0.0f;
+  const int col = tid & 31, mrow0 = tid >> 5;
+  f32x16 acc;
 #pragma unroll
-        for (int k = 0; k < 6; ++k)
-          if (AT[p][k] != 0.0f) acc += AT[p][k] * m[k][j];
-        s4[p][j] = acc;
+  for (int t = 0; t < T; ++t) {
+    if (t % NCH == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < CH / 4; ++k4) {
+      const float4 av = ra[t % R][k4], bv = rb[t % R][k4];
+      acc = mfma_32x32x2(av.x, bv.x, acc);
+      acc = mfma_32x32x2(av.y, bv.y, acc);
+      acc = mfma_32x32x2(av.z, bv.z, acc);
+      acc = mfma_32x32x2(av.w, bv.w, acc);
+    }
+    sched_fence();
+    if (t + R < T) issue(t % R, t + R);
+    sched_fence();
+    if (t % NCH == NCH - 1) {
+      const int pi = t / NCH;
+      const int lp = wave + 4 * (pi % 3);
+      float* mo = lds + (lp * 32 + 4 * half) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mo[((r & 3) + 8 * (r >> 2)) * 32] = acc[r];
+      if (pi % 3 == 2) {                 // the group's 12 products are complete: fold its two rows into s4
+        const int g = pi / 3;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+              const float mv = lds[(((rr * 6 + j) * 32) + mrow0 + 8 * u) * 32 + col];
+#pragma unroll
+              for (int p = 0; p < 4; ++p)
+                if (AT[p][2 * g + rr] != 0.0f) s4[u][p][j] += AT[p][2 * g + rr] * mv;
+            }
+        if (g < 2) __syncthreads();
       }
-    const float b = a.bias ? ld(a.bias + ch) : 0.0f;
-    const float sc = a.bn_scale ? ld(a.bn_scale + ch) : 1.0f, sh = a.bn_scale ? ld(a.bn_shift + ch) : 0.0f;
-    const long o_res = a.residual.ptr ? view_base(a.residual, img, 0) + (long)ch * a.residual.stride_c : 0;
-    const long o_raw = a.raw.ptr ? view_base(a.raw, img, 0) + (long)ch * a.raw.stride_c : 0;
-    const long o_act = a.act.ptr ? view_base(a.act, img, 0) + (long)ch * a.act.stride_c : 0;
-    const long o_act2 = a.act2.ptr ? view_base(a.act2, img, 0) + (long)ch * a.act2.stride_c : 0;
+    }
+  }
+  const int tpp = a.o.TH * a.o.TW;
+  const int r = n0 + col;
+  if (r < a.o.NB) {
+    const int img = r / tpp, tt = r - img * tpp;
+    const int th = tt / a.o.TW, tw = tt - th * a.o.TW;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int h = 4 * th + p;
-      if (h >= a.H) continue;
-#pragma unroll
-      for (int q0 = 0; q0 < 4; q0 += VEC) {
-        const int w0 = 4 * tw + q0;
-        if (w0 >= a.W) continue;  // W % VEC == 0: the VEC outputs are inside or outside together
-        float val[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          float y = 0.0f;
-#pragma unroll
-          for (int k = 0; k < 6; ++k)
-            if (AT[q0 + e][k] != 0.0f) y += s4[p][k] * AT[q0 + e][k];
-          val[e] = y + b;
-        }
-        const int sp = (d * a.H + h) * a.W + w0;
-        if (a.residual.ptr) {
-          const vec_t rv = ld((const vec_t*)((const float*)a.residual.ptr + o_res + sp));
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) val[e] += ((const float*)&rv)[e];
-        }
-        if (a.raw.ptr) {
-          vec_t ov;
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) ((float*)&ov)[e] = val[e];
-          st((vec_t*)(a.raw.ptr + o_raw + sp), ov);
-        }
-        if (a.act.ptr) {
-          vec_t ov;
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            float o = val[e] * sc + sh;
-            if (a.relu) o = fmaxf(o, 0.0f);
-            ((float*)&ov)[e] = o;
-          }
-          st((vec_t*)(a.act.ptr + o_act + sp), ov);
-          if (a.act2.ptr) st((vec_t*)(a.act2.ptr + o_act2 + sp), ov);
-        }
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int ch = mb * 32 + mrow0 + 8 * u;
+      if (ch < a.o.cout) wino_output_from_s4<VEC>(a.o, s4[u], ch, img, 0, th, tw);
     }
   }
 }
@@ -499,6 +680,27 @@ extern "C" int eco_wino_input_pk_forward(const eco_wgemm_plan* plan, const float
   return check_launch("eco_wino_input_pk_forward");
 }
 
+extern "C" int eco_wino_input_q4_forward(const eco_wgemm_plan* plan, const float* x, float* v, int32_t h, int32_t w,
+                                         void* stream) {
+  clear_error();
+  if (int rc = wgemm_check_plan(plan)) return rc;
+  ECO_REQUIRE(x && v && h > 0 && w > 0, "winograd input transform: bad argument");
+  ECO_REQUIRE(plan->kd == 1 && plan->d == 1 && plan->cin % 8 == 0, "winograd input transform (fused layout): 2-D layers, cin %% 8 == 0");
+  ECO_REQUIRE(plan->th == (h + 3) / 4 && plan->tw == (w + 3) / 4, "winograd input transform: plan is for %dx%d tiles", plan->th,
+              plan->tw);
+  WinoInPkArgs a;
+  a.x = x; a.v = v; a.n = plan->n; a.cin = plan->cin; a.D = 1; a.H = h; a.W = w; a.TH = plan->th; a.TW = plan->tw;
+  a.pd = 0;
+  a.NB = plan->n * plan->th * plan->tw;
+  a.Q = a.NB;
+  a.v_pstride = (long)plan->cin * a.NB;
+  const long total = (long)plan->cin * a.NB;
+  const bool vec4 = w % 4 == 0 && ((uintptr_t)x & 15) == 0;
+  if (vec4) hipLaunchKernelGGL((wino_input_q4_kernel<4>), dim3(wg_grid(total)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((wino_input_q4_kernel<1>), dim3(wg_grid(total)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("eco_wino_input_q4_forward");
+}
+
 template <int TM, int TN, int WM, int WN>
 static int launch_wgemm(const WGemmArgs& a, int points, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, BMP = (BM + 63) / 64 * 64;
@@ -590,4 +792,100 @@ extern "C" int eco_wino_output_dm_forward(const eco_wgemm_plan* plan, const floa
   else if (vec == 2) hipLaunchKernelGGL((wino_output_dm_kernel<2>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((wino_output_dm_kernel<1>), grid, block, 0, s, a);
   return check_launch("eco_wino_output_dm_forward");
+}
+
+// ---- fused GEMM + output transform (wfused_kernel) ------------------------------------------------------------------
+static int wfused_check(const eco_wgemm_plan* p) {
+  if (int rc = wgemm_check_plan(p)) return rc;
+  ECO_REQUIRE(p->kd == 1 && p->d == 1 && (p->cin == 64 || p->cin == 96) && p->cout % 32 == 0,
+              "wfused: 2-D layers with 64 or 96 input channels and a multiple of 32 output channels (got cin=%d cout=%d d=%d kd=%d)",
+              p->cin, p->cout, p->d, p->kd);
+  return ECO_OK;
+}
+
+extern "C" int64_t eco_wfused_weight_elems(const eco_wgemm_plan* plan) {
+  if (!plan || plan->cout <= 0 || plan->cin <= 0) return 0;
+  return (int64_t)plan->points * ((plan->cout + 31) / 32) * (plan->cin / 2) * 64;
+}
+
+extern "C" int eco_wfused_pack_weights(const eco_wgemm_plan* plan, const float* u, float* up) {
+  clear_error();
+  if (int rc = wfused_check(plan)) return rc;
+  ECO_REQUIRE(u && up, "wfused pack: null argument");
+  const int cin = plan->cin, cout = plan->cout, kp = cin / 2, mblocks = cout / 32;
+  // u[p][co][ci] -> up[p][co/32][(ci/2)/4][lane = (ci%2)*32 + co%32][(ci/2)%4]: the A fragments of four consecutive
+  // k-pairs are one 16-byte vector per lane, consecutive lanes on consecutive vectors
+  for (int p = 0; p < plan->points; ++p)
+    for (int co = 0; co < cout; ++co)
+      for (int ci = 0; ci < cin; ++ci) {
+        const int kq = ci / 2, lane = (ci & 1) * 32 + co % 32;
+        up[((((long)p * mblocks + co / 32) * (kp / 4) + kq / 4) * 64 + lane) * 4 + kq % 4] = u[((long)p * cout + co) * cin + ci];
+      }
+  return ECO_OK;
+}
+
+extern "C" int eco_wfused_forward(const eco_wgemm_plan* plan, const float* v, const float* up, int32_t h, int32_t w,
+                                  const eco_conv_epilogue* ep, void* stream) {
+  clear_error();
+  if (int rc = wfused_check(plan)) return rc;
+  ECO_REQUIRE(v && up && ep && h > 0 && w > 0, "wfused: bad argument");
+  ECO_REQUIRE(plan->th == (h + 3) / 4 && plan->tw == (w + 3) / 4, "wfused: plan is for %dx%d tiles", plan->th, plan->tw);
+  ECO_REQUIRE(ep->raw.ptr || ep->act.ptr, "wfused: at least one of raw/act outputs is required");
+  ECO_REQUIRE(!ep->bn_scale == !ep->bn_shift, "wfused: bn_scale and bn_shift must be given together");
+  ECO_REQUIRE(!ep->act2.ptr || ep->act.ptr, "wfused: act2 needs act");
+  ECO_REQUIRE(ep->nseg == 0, "wfused: segmented (sibling) launches exist for the direct kernels only");
+  const eco_view* views[4] = {&ep->residual, &ep->raw, &ep->act, &ep->act2};
+  for (const eco_view* vw : views)
+    ECO_REQUIRE(!vw->ptr || (vw->t >= 1 && vw->stride_c >= 1), "wfused: view needs t >= 1 and stride_c >= 1");
+  WFusedArgs a;
+  a.v = v; a.u = up;
+  a.o.m = nullptr; a.o.bias = ep->bias; a.o.bn_scale = ep->bn_scale; a.o.bn_shift = ep->bn_shift;
+  a.o.residual = ep->residual; a.o.raw = ep->raw; a.o.act = ep->act; a.o.act2 = ep->act2; a.o.relu = ep->relu;
+  a.o.n = plan->n; a.o.cout = plan->cout; a.o.D = 1; a.o.H = h; a.o.W = w; a.o.TH = plan->th; a.o.TW = plan->tw;
+  a.o.NB = plan->n * plan->th * plan->tw;
+  a.o.ntot = a.o.NB; a.o.ksplit = 1; a.o.m_pstride = 0;
+  a.mblocks = plan->cout / 32;
+  a.nblk = (int)ceil_div(a.o.NB, 32);
+  a.Q = a.o.NB;
+  a.v_pstride = (long)plan->cin * a.o.NB;
+  a.u_pstride = (long)a.mblocks * (plan->cin / 2) * 64;
+  ECO_REQUIRE(((uintptr_t)v & 15) == 0 && ((uintptr_t)up & 15) == 0, "wfused: operands must be 16-byte aligned");
+  int vec = 4;
+  auto limit = [&](const eco_view& vw) {
+    if (!vw.ptr) return;
+    while (vec > 1 && (((uintptr_t)vw.ptr % (4 * vec)) || vw.stride_b % vec || vw.stride_t % vec || vw.stride_c % vec)) vec /= 2;
+  };
+  while (vec > 1 && w % vec) vec /= 2;
+  limit(a.o.residual); limit(a.o.raw); limit(a.o.act); limit(a.o.act2);
+  const long grid = (long)a.mblocks * a.nblk;
+  ECO_REQUIRE(grid < 2147483647l, "wfused: too many tiles for one launch");
+  const size_t lds = sizeof(float) * 12 * 32 * 32;
+  hipStream_t s = (hipStream_t)stream;
+#define ECO_WFUSED_LAUNCH(KP, VEC)                                                                                         \
+  do {                                                                                                                     \
+    ECO_WFUSED_RAISE(KP, VEC);                                                                                             \
+    hipLaunchKernelGGL((wfused_kernel<KP, VEC>), dim3((unsigned)grid), dim3(256), lds, s, a);                              \
+  } while (0)
+#ifdef ECO_EMU
+#define ECO_WFUSED_RAISE(KP, VEC)
+#else
+#define ECO_WFUSED_RAISE(KP, VEC)                                                                                          \
+  do {                                                                                                                     \
+    static thread_local bool raised = false;                                                                               \
+    if (!raised) {                                                                                                         \
+      hipError_t e = hipFuncSetAttribute((const void*)wfused_kernel<KP, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                         160 * 1024);                                                                      \
+      if (e != hipSuccess) return fail(ECO_ERR_RUNTIME, "wfused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); \
+      raised = true;                                                                                                       \
+    }                                                                                                                      \
+  } while (0)
+#endif
+  if (plan->cin == 64) {
+    if (vec == 4) ECO_WFUSED_LAUNCH(32, 4); else if (vec == 2) ECO_WFUSED_LAUNCH(32, 2); else ECO_WFUSED_LAUNCH(32, 1);
+  } else {
+    if (vec == 4) ECO_WFUSED_LAUNCH(48, 4); else if (vec == 2) ECO_WFUSED_LAUNCH(48, 2); else ECO_WFUSED_LAUNCH(48, 1);
+  }
+#undef ECO_WFUSED_LAUNCH
+#undef ECO_WFUSED_RAISE
+  return check_launch("eco_wfused_forward");
 }

@@ -136,6 +136,7 @@ class Engine:
             raise ValueError("winograd must be False, True, 2 or 4")
         self.winograd = winograd
         self.wino_min_tiles = 64   # size rule of winograd=True: tile positions per transform point
+        self.wfused = True         # ... and, for the short-reduction 2-D layers, GEMM + output transform in one kernel
         self.wgemm = True          # F(4x4,3x3) GEMMs on the dedicated dense kernel (False: round-1 gather-kernel route)
         self.stem = True           # conv1 + BN + ReLU + pool1 as one launch (False: conv kernel + pooling kernel)
         self.siblings = True       # 1x1 convs reading the same bottom as one launch (fp32 path)
@@ -224,8 +225,11 @@ class Engine:
                     cout, cin, kd = L.geom["cout"], L.geom["cin"], wn["kd"]
                     u = np.empty((36, cout, cin, kd), np.float32)
                     self.lib.wino_weight_transform(w.ctypes.data, cout, cin, kd, 4, u.ctypes.data)
-                    up = np.empty(wn["plan"].u_elems, np.float32)
-                    self.lib.wgemm_pack_weights(wn["plan"], u.ctypes.data, up.ctypes.data)
+                    up = np.zeros(wn["up_elems"], np.float32)
+                    if wn["fused"]:
+                        self.lib.wfused_pack_weights(wn["plan"], u.ctypes.data, up.ctypes.data)
+                    else:
+                        self.lib.wgemm_pack_weights(wn["plan"], u.ctypes.data, up.ctypes.data)
                     self.alloc.upload(wn["up"], up)
                 elif wn is not None:  # u[p] = (G g G^T)[p], each point packed for the (kd,1,1) gather kernel
                     cout, cin, kd = L.geom["cout"], L.geom["cin"], wn["kd"]
@@ -518,10 +522,18 @@ class Engine:
             # F(4x4,3x3) on the dedicated dense GEMM (csrc/eco_wgemm.hip): pair-interleaved depth-major V, LDS-DMA staging
             plan = self.lib.wgemm_plan(n, g["cin"], g["cout"], D, TH, TW, kd, self.num_cu)
             wn = dict(kind="wgemm", plan=plan, M=4, points=36, TH=TH, TW=TW, kd=kd, v_elems=plan.v_elems, m_elems=plan.m_elems)
-            if old is not None and old.get("kind") == "wgemm" and old["plan"].u_elems == plan.u_elems:
+            # short-reduction 2-D layers (conv2_3x3, the inception 3x3 convs): GEMM and output transform in one
+            # kernel, the transformed-domain products never leave LDS (csrc/eco_wgemm.hip, wfused_kernel)
+            wn["fused"] = bool(self.wfused and kd == 1 and D == 1 and g["cin"] in (64, 96) and g["cout"] % 32 == 0)
+            elems = self.lib.wfused_weight_elems(plan) if wn["fused"] else plan.u_elems
+            if wn["fused"]:
+                wn["m_elems"] = 0
+            if old is not None and old.get("kind") == "wgemm" and old.get("fused") == wn["fused"] and \
+                    old.get("up_elems") == elems:
                 wn["up"] = old["up"]
             else:
-                wn["up"] = self.alloc.empty(plan.u_elems, np.float32)
+                wn["up"] = self.alloc.empty(elems, np.float32)
+            wn["up_elems"] = elems
             st["wino"] = wn
             return
         gw = hip.conv_geom(n, g["cin"], g["cout"], (D, TH, TW), (kd, 1, 1), (1, 1, 1), (kd // 2, 0, 0), (D, TH, TW))
@@ -543,7 +555,8 @@ class Engine:
         n, D, H, W, kd = self._wino_dims(L)
         cin, cout = L.geom["cin"], L.geom["cout"]
         x = self._ptr(L.bottoms[0])
-        v, m = self.alloc.ptr(self._wino_buf_v_elems), self.alloc.ptr(self._wino_buf_m_elems)
+        v = self.alloc.ptr(self._wino_buf_v_elems)
+        m = self.alloc.ptr(self._wino_buf_m_elems) if getattr(self, "_wino_m_elems", 0) else None
         if wn["kind"] == "wgemm":
             plan, up = wn["plan"], self.alloc.ptr(wn["up"])
             self._keep.append((plan, ep))
@@ -551,9 +564,20 @@ class Engine:
             v_bytes = 4 * 36 * cin * (D + 2 * (kd // 2)) * n * wn["TH"] * wn["TW"]
             m_bytes = 4 * 36 * plan.ksplit * cout * tiles
             tag = "F(4x4,3x3)"
-            self._add(i, f"{label} [winograd {tag} input transform]", lambda s, plan=plan, x=x, v=v, H=H, W=W:
-                      lib.wino_input_pk_forward(plan, x, v, H, W, s),
-                      {"kernel": "eco::wino_input_pk_kernel", "flops": 0, "bytes": 4 * n * cin * D * H * W + v_bytes})
+            if wn["fused"]:
+                self._add(i, f"{label} [winograd {tag} input transform]", lambda s, plan=plan, x=x, v=v, H=H, W=W:
+                          lib.wino_input_q4_forward(plan, x, v, H, W, s),
+                          {"kernel": "eco::wino_input_q4_kernel", "flops": 0, "bytes": 4 * n * cin * D * H * W + v_bytes})
+            else:
+                self._add(i, f"{label} [winograd {tag} input transform]", lambda s, plan=plan, x=x, v=v, H=H, W=W:
+                          lib.wino_input_pk_forward(plan, x, v, H, W, s),
+                          {"kernel": "eco::wino_input_pk_kernel", "flops": 0, "bytes": 4 * n * cin * D * H * W + v_bytes})
+            if wn["fused"]:
+                self._add(i, f"{label} [36 transformed-domain GEMMs, K = {cin}, + winograd {tag} output transform]",
+                          lambda s, plan=plan, v=v, up=up, H=H, W=W, ep=ep: lib.wfused_forward(plan, v, up, H, W, ep, s),
+                          {"kernel": "eco::wfused_kernel", "flops": 2 * 36 * tiles * cout * cin,
+                           "bytes": v_bytes + 4 * 36 * cout * cin + nbytes - 4 * (n * cin * D * H * W + 9 * cin * cout)})
+                return
             self._add(i, f"{label} [36 transformed-domain GEMMs, K = {cin * kd}]", lambda s, plan=plan, v=v, up=up, m=m:
                       lib.wgemm_forward(plan, v, up, m, s),
                       {"kernel": hip.wgemm_kernel_name(plan), "flops": 2 * 36 * tiles * cout * cin * kd,

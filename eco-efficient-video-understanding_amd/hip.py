@@ -21,7 +21,7 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 13
+ABI_VERSION = 14
 DT_BF16 = 1
 DT_F32X3 = 3
 
@@ -206,6 +206,11 @@ _SIGNATURES = {
     "eco_stem_pack_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "eco_stem_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                    C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "eco_wino_input_q4_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "eco_wfused_weight_elems": (C.c_int64, [C.POINTER(WGemmPlan)]),
+    "eco_wfused_pack_weights": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p]),
+    "eco_wfused_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                     C.POINTER(ConvEpilogue), C.c_void_p]),
     "eco_wgemm_plan_create": (C.c_int, [C.c_int32] * 9 + [C.POINTER(WGemmPlan)]),
     "eco_wgemm_pack_weights": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p]),
     "eco_wino_input_pk_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
@@ -314,6 +319,19 @@ class EcoLib:
                      max_workgroups: int = 0) -> None:
         self._check(self._dll.eco_stem_forward(x, wp, bias, bn_scale, bn_shift, int(relu), y, n, h, w, cout,
                                                max_workgroups, stream))
+
+    # -- fused transformed-domain GEMM + output transform for the short-reduction 2-D layers --
+    def wino_input_q4_forward(self, plan: "WGemmPlan", x: int, v: int, h: int, w: int, stream=None) -> None:
+        self._check(self._dll.eco_wino_input_q4_forward(C.byref(plan), x, v, h, w, stream))
+
+    def wfused_weight_elems(self, plan: "WGemmPlan") -> int:
+        return int(self._dll.eco_wfused_weight_elems(C.byref(plan)))
+
+    def wfused_pack_weights(self, plan: "WGemmPlan", u_host: int, up_host: int) -> None:
+        self._check(self._dll.eco_wfused_pack_weights(C.byref(plan), u_host, up_host))
+
+    def wfused_forward(self, plan: "WGemmPlan", v: int, up: int, h: int, w: int, ep: "ConvEpilogue", stream=None) -> None:
+        self._check(self._dll.eco_wfused_forward(C.byref(plan), v, up, h, w, C.byref(ep), stream))
 
     # -- Winograd F(4x4,3x3) on the dedicated transformed-domain GEMM (csrc/eco_wgemm.hip) --
     def wgemm_plan(self, n, cin, cout, d, th, tw, kd, num_cu: Optional[int] = None) -> "WGemmPlan":

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 13
+#define ECO_ABI_VERSION 14
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -319,6 +319,19 @@ int eco_wino_input_pk_forward(const eco_wgemm_plan* plan, const float* x, float*
 int eco_wgemm_forward(const eco_wgemm_plan* plan, const float* v, const float* up, float* m, void* stream);
 int eco_wino_output_dm_forward(const eco_wgemm_plan* plan, const float* m, int32_t h, int32_t w,
                                const eco_conv_epilogue* ep, void* stream);
+
+/* Fused form of the last two steps for the short-reduction 2-D layers (kd = 1, d = 1, cin = 64 or 96, cout % 32 == 0:
+ * conv2_3x3 and the inception 3x3 convs, models_ECO_Lite/kinetics/deploy.prototxt:78-330): the 36 transformed-domain
+ * products of a 32-channel x 32-tile block stay in LDS and are output-transformed there; M never goes to HBM.
+ * V comes from eco_wino_input_q4_forward (the same transform, four k-pairs of a position as one 16-byte vector:
+ * V4[36][cin/8][tiles][2][4], plan->v_elems floats suffice), the epilogue is eco_wino_output_dm_forward's; weights
+ * are packed by eco_wfused_pack_weights from u[36][cout][cin] (eco_wino_weight_transform) into
+ * eco_wfused_weight_elems floats. */
+int eco_wino_input_q4_forward(const eco_wgemm_plan* plan, const float* x, float* v, int32_t h, int32_t w, void* stream);
+int64_t eco_wfused_weight_elems(const eco_wgemm_plan* plan);
+int eco_wfused_pack_weights(const eco_wgemm_plan* plan, const float* u, float* up); /* HOST */
+int eco_wfused_forward(const eco_wgemm_plan* plan, const float* v, const float* up, int32_t h, int32_t w,
+                       const eco_conv_epilogue* ep, void* stream);
 
 /* ---- channel-blocked ("NC8") path on the bf16 matrix cores (csrc/eco_blocked.hip) -------------------------
  *

@@ -126,11 +126,12 @@ def test_caffe_time_style_report():
     assert out.returncode == 0, out.stderr[-2000:]
     # 36 operators (conv1 + pool1 are one stem launch); at a single N=4 clip conv2_3x3 (4 x 14 x 14 tile positions per
     # point), the seven inception 3x3 convs and the three res3 convs (196 each) are above the Winograd size rule of 64
-    # and expand to three launches, res4 (32) and res5 (4) run direct; sibling 1x1 convs that share a launch are
-    # joined by " | " in its label
+    # and take the Winograd route -- the eight 2-D ones as two launches (input transform, fused GEMM + output
+    # transform), the res3 ones as three; res4 (32) and res5 (4) run direct; sibling 1x1 convs that share a launch
+    # are joined by " | " in its label
     assert "Average Forward pass" in out.stdout
-    assert out.stdout.count("forward:") + out.stdout.count(" | ") == 36 + 2 * 11
-    assert out.stdout.count("winograd F(4x4,3x3)") == 2 * 11
+    assert out.stdout.count("forward:") + out.stdout.count(" | ") == 36 + 8 + 2 * 3
+    assert out.stdout.count("winograd F(4x4,3x3)") == 2 * 11 and out.stdout.count("eco::wfused_kernel") == 8
 
 
 def _fast_oracle(spec, params, x, **kw):

@@ -85,3 +85,80 @@ def test_wgemm_plans_for_eco_layers(backend):
     assert (p3.bm, p3.nstages, p3.ksplit) == (128, 24, 1) and p3.q == 18 * 32 * 49
     assert p4.bm == 128 and p4.mblocks == 2 and p5.mblocks == 4 and p5.ksplit >= 1
     assert (pc.bm, pc.mblocks, pc.nstages, pc.ksplit) == (96, 2, 4, 1) and pc.q == 512 * 196
+
+
+# ---- fused transformed-domain GEMM + output transform (wfused_kernel): the short-reduction 2-D layers ---------------
+WTOL = 3e-5
+
+
+def relerr(got, ref):
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
+def run_wfused(be, n, cin, cout, H, W, mode="bn", num_cu=None):
+    lib = be.lib
+    rng = np.random.default_rng(n * 7 + cin + cout + H)
+    x = rng.standard_normal((n, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = orc.convolution(x, w, b, (3, 3), (1, 1), (1, 1))
+    TH, TW = (H + 3) // 4, (W + 3) // 4
+    plan = lib.wgemm_plan(n, cin, cout, 1, TH, TW, 1, num_cu)
+    u = np.empty((36, cout, cin, 1), np.float32)
+    lib.wino_weight_transform(w.ctypes.data, cout, cin, 1, 4, u.ctypes.data)
+    up = np.zeros(lib.wfused_weight_elems(plan), np.float32)
+    lib.wfused_pack_weights(plan, u.ctypes.data, up.ctypes.data)
+    dx, dup, db = be.dev(x), be.dev(up), be.dev(b)
+    v = be.dev(np.full(plan.v_elems, np.nan, np.float32))
+    lib.wino_input_q4_forward(plan, be.ptr(dx), be.ptr(v), H, W)
+    ep = hip.ConvEpilogue()
+    ep.bias = be.ptr(db)
+    ep.residual, ep.raw, ep.act, ep.act2 = hip.null_view(), hip.null_view(), hip.null_view(), hip.null_view()
+    S = H * W
+    if mode == "plain":
+        y = be.empty(ref.shape)
+        ep.raw = hip.plain_view(be.ptr(y), cout, S)
+        lib.wfused_forward(plan, be.ptr(v), be.ptr(dup), H, W, ep)
+        assert relerr(be.host(y, ref.shape), ref) < WTOL
+        return plan
+    # bias + residual + raw + BN + ReLU -> a channel slice of a wider (Concat) tensor
+    res = rng.standard_normal(ref.shape).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    dres, dsc, dsh = be.dev(res), be.dev(sc), be.dev(sh)
+    raw = be.empty(ref.shape)
+    c0, ctot = 8, cout + 16
+    big = be.dev(np.full((n, ctot, H, W), 7.0, np.float32))
+    ep.residual = hip.plain_view(be.ptr(dres), cout, S)
+    ep.raw = hip.plain_view(be.ptr(raw), cout, S)
+    ep.act = hip.View(be.ptr(big, c0 * S), ctot * S, 0, S, 1)
+    ep.bn_scale, ep.bn_shift, ep.relu = be.ptr(dsc), be.ptr(dsh), 1
+    lib.wfused_forward(plan, be.ptr(v), be.ptr(dup), H, W, ep)
+    exp_raw = ref + res
+    exp_act = np.maximum(exp_raw * sc.reshape(1, -1, 1, 1) + sh.reshape(1, -1, 1, 1), 0)
+    assert relerr(be.host(raw, ref.shape), exp_raw) < WTOL
+    got = be.host(big, (n, ctot, H, W))
+    assert relerr(got[:, c0:c0 + cout], exp_act) < WTOL
+    assert (got[:, :c0] == 7.0).all() and (got[:, c0 + cout:] == 7.0).all()
+    return plan
+
+
+@pytest.mark.parametrize("n,cin,cout,H,W,mode", [
+    (2, 64, 64, 28, 28, "bn"),       # inception_3a_3x3: 98 tile columns, last block of 32 ragged
+    (2, 96, 96, 12, 12, "bn"),       # 96 -> 96 (double_3x3_2): three 16-k-pair chunks per point
+    (1, 64, 192, 16, 16, "plain"),   # conv2_3x3's widths: six channel blocks
+    (2, 64, 96, 10, 14, "bn"),       # planes that do not tile by 4 (ragged tiles), W % 4 == 2: 8-byte stores
+    (2, 96, 64, 7, 9, "plain"),      # odd width: scalar stores
+])
+def test_wfused_conv(backend, n, cin, cout, H, W, mode):
+    run_wfused(backend, n, cin, cout, H, W, mode)
+
+
+def test_wfused_rejects_other_shapes(backend):
+    lib = backend.lib
+    plan = lib.wgemm_plan(1, 128, 128, 4, 4, 4, 3, None)     # a 3-D trunk layer
+    with pytest.raises(hip.EcoError, match="wfused"):
+        lib.wfused_pack_weights(plan, 0, 0)
+    plan = lib.wgemm_plan(1, 64, 48, 1, 4, 4, 1, None)        # cout not a multiple of 32
+    with pytest.raises(hip.EcoError, match="multiple of 32"):
+        lib.wfused_forward(plan, 0, 0, 16, 16, hip.ConvEpilogue())
