@@ -797,8 +797,8 @@ extern "C" int eco_wino_output_dm_forward(const eco_wgemm_plan* plan, const floa
 // ---- fused GEMM + output transform (wfused_kernel) ------------------------------------------------------------------
 static int wfused_check(const eco_wgemm_plan* p) {
   if (int rc = wgemm_check_plan(p)) return rc;
-  ECO_REQUIRE(p->kd == 1 && p->d == 1 && (p->cin == 64 || p->cin == 96) && p->cout % 32 == 0,
-              "wfused: 2-D layers with 64 or 96 input channels and a multiple of 32 output channels (got cin=%d cout=%d d=%d kd=%d)",
+  ECO_REQUIRE(p->kd == 1 && p->d == 1 && p->cin % 32 == 0 && p->cin >= 64 && p->cin <= 224 && p->cout % 32 == 0,
+              "wfused: 2-D layers with 64..224 input channels and output channels, both multiples of 32 (got cin=%d cout=%d d=%d kd=%d)",
               p->cin, p->cout, p->d, p->kd);
   return ECO_OK;
 }
@@ -880,11 +880,15 @@ extern "C" int eco_wfused_forward(const eco_wgemm_plan* plan, const float* v, co
     }                                                                                                                      \
   } while (0)
 #endif
-  if (plan->cin == 64) {
-    if (vec == 4) ECO_WFUSED_LAUNCH(32, 4); else if (vec == 2) ECO_WFUSED_LAUNCH(32, 2); else ECO_WFUSED_LAUNCH(32, 1);
-  } else {
-    if (vec == 4) ECO_WFUSED_LAUNCH(48, 4); else if (vec == 2) ECO_WFUSED_LAUNCH(48, 2); else ECO_WFUSED_LAUNCH(48, 1);
+#define ECO_WFUSED_KP(KP)                                                                                                  \
+  case 2 * KP:                                                                                                             \
+    if (vec == 4) ECO_WFUSED_LAUNCH(KP, 4); else if (vec == 2) ECO_WFUSED_LAUNCH(KP, 2); else ECO_WFUSED_LAUNCH(KP, 1);    \
+    break
+  switch (plan->cin) {
+    ECO_WFUSED_KP(32); ECO_WFUSED_KP(48); ECO_WFUSED_KP(64); ECO_WFUSED_KP(80); ECO_WFUSED_KP(96); ECO_WFUSED_KP(112);
+    default: return fail(ECO_ERR_INVALID, "wfused: unsupported cin %d", plan->cin);
   }
+#undef ECO_WFUSED_KP
 #undef ECO_WFUSED_LAUNCH
 #undef ECO_WFUSED_RAISE
   return check_launch("eco_wfused_forward");

@@ -137,6 +137,9 @@ class Engine:
         self.winograd = winograd
         self.wino_min_tiles = 64   # size rule of winograd=True: tile positions per transform point
         self.wfused = True         # ... and, for the short-reduction 2-D layers, GEMM + output transform in one kernel
+        # (the kernel takes up to 224 input channels; measured on ECO-Full at 32 clips: cut-off 96 / 128 / 160 / 224
+        # -> 26.57 / 26.19 / 26.26 / 26.75 ms per step -- above 128 the unfused GEMM's larger tiles win)
+        self.wfused_max_cin = 128
         self.wgemm = True          # F(4x4,3x3) GEMMs on the dedicated dense kernel (False: round-1 gather-kernel route)
         self.stem = True           # conv1 + BN + ReLU + pool1 as one launch (False: conv kernel + pooling kernel)
         self.siblings = True       # 1x1 convs reading the same bottom as one launch (fp32 path)
@@ -524,7 +527,8 @@ class Engine:
             wn = dict(kind="wgemm", plan=plan, M=4, points=36, TH=TH, TW=TW, kd=kd, v_elems=plan.v_elems, m_elems=plan.m_elems)
             # short-reduction 2-D layers (conv2_3x3, the inception 3x3 convs): GEMM and output transform in one
             # kernel, the transformed-domain products never leave LDS (csrc/eco_wgemm.hip, wfused_kernel)
-            wn["fused"] = bool(self.wfused and kd == 1 and D == 1 and g["cin"] in (64, 96) and g["cout"] % 32 == 0)
+            wn["fused"] = bool(self.wfused and kd == 1 and D == 1 and g["cin"] % 32 == 0 and
+                               64 <= g["cin"] <= self.wfused_max_cin and g["cout"] % 32 == 0)
             elems = self.lib.wfused_weight_elems(plan) if wn["fused"] else plan.u_elems
             if wn["fused"]:
                 wn["m_elems"] = 0

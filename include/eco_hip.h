@@ -320,7 +320,7 @@ int eco_wgemm_forward(const eco_wgemm_plan* plan, const float* v, const float* u
 int eco_wino_output_dm_forward(const eco_wgemm_plan* plan, const float* m, int32_t h, int32_t w,
                                const eco_conv_epilogue* ep, void* stream);
 
-/* Fused form of the last two steps for the short-reduction 2-D layers (kd = 1, d = 1, cin = 64 or 96, cout % 32 == 0:
+/* Fused form of the last two steps for the 2-D layers (kd = 1, d = 1, cin = 64..224 and cout multiples of 32:
  * conv2_3x3 and the inception 3x3 convs, models_ECO_Lite/kinetics/deploy.prototxt:78-330): the 36 transformed-domain
  * products of a 32-channel x 32-tile block stay in LDS and are output-transformed there; M never goes to HBM.
  * V comes from eco_wino_input_q4_forward (the same transform, four k-pairs of a position as one 16-byte vector:

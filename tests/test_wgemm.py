@@ -149,6 +149,8 @@ def run_wfused(be, n, cin, cout, H, W, mode="bn", num_cu=None):
     (1, 64, 192, 16, 16, "plain"),   # conv2_3x3's widths: six channel blocks
     (2, 64, 96, 10, 14, "bn"),       # planes that do not tile by 4 (ragged tiles), W % 4 == 2: 8-byte stores
     (2, 96, 64, 7, 9, "plain"),      # odd width: scalar stores
+    (1, 160, 64, 8, 8, "bn"),        # ECO-Full inception_4c/4d widths: five chunks per point
+    (1, 224, 32, 7, 7, "plain"),     # inception_5a/5b double_3x3_2: seven chunks per point, 7x7 planes
 ])
 def test_wfused_conv(backend, n, cin, cout, H, W, mode):
     run_wfused(backend, n, cin, cout, H, W, mode)
@@ -160,5 +162,5 @@ def test_wfused_rejects_other_shapes(backend):
     with pytest.raises(hip.EcoError, match="wfused"):
         lib.wfused_pack_weights(plan, 0, 0)
     plan = lib.wgemm_plan(1, 64, 48, 1, 4, 4, 1, None)        # cout not a multiple of 32
-    with pytest.raises(hip.EcoError, match="multiple of 32"):
+    with pytest.raises(hip.EcoError, match="multiples of 32"):
         lib.wfused_forward(plan, 0, 0, 16, 16, hip.ConvEpilogue())
