@@ -1,3 +1,5 @@
+# GPU-box check used during development (through gpurun, from the repo root): the -m gpu suite, then bench lines at
+# 1 / 4 / 32 clips (ECO-Lite) and 32 clips (ECO-Full), and the one-clip per-launch table.  Usage: bash tools/gpu_check.sh <tag>
 set -u
 O=gpurun_out/${1:-quick}
 mkdir -p $O
