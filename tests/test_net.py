@@ -145,6 +145,40 @@ layer { name: "cat" type: "Concat" bottom: "c1_bn" bottom: "c2" top: "cat" }
         assert out.shape == (3, 176, 9, 10) and relerr(out, ref["cat"]) < tol
 
 
+def test_fused_winograd_route_for_short_reduction_2d_convs(backend):
+    """2-D 3x3 stride-1 convs with 64..128 input channels and cout % 32 == 0 (conv2_3x3, the inception 3x3 convs) run as
+    two launches: input transform into the V4 layout, then GEMM + output transform fused (the transformed products
+    stay in LDS).  BN + ReLU and the Concat-slice store ride in its epilogue; a weight update repacks its operand;
+    wfused=False falls back to the three-launch form with the same result."""
+    proto = """name: "short2d"
+input: "data" input_dim: 2 input_dim: 96 input_dim: 10 input_dim: 9
+layer { name: "c1" type: "Convolution" bottom: "data" top: "c1" convolution_param { num_output: 64 kernel_size: 3 pad: 1 } }
+layer { name: "c1_bn" type: "BN" bottom: "c1" top: "c1_bn" bn_param { frozen: true } }
+layer { name: "c1_relu" type: "ReLU" bottom: "c1_bn" top: "c1_bn" }
+layer { name: "c2" type: "Convolution" bottom: "data" top: "c2" convolution_param { num_output: 32 kernel_size: 1 } }
+layer { name: "cat" type: "Concat" bottom: "c1_bn" bottom: "c2" top: "cat" }
+"""
+    spec = NetSpec.from_prototxt(proto)
+    params = fillers.synthetic_params(spec, seed=5)
+    x = np.random.default_rng(1).standard_normal((2, 96, 10, 9)).astype(np.float32)
+    ref = orc.forward(spec, params, {"data": x}, keep="all", fast_pool=False)
+    net = make_net(backend, proto, params, True, winograd=4)
+    labels = net.op_labels()
+    assert sum("winograd" in l for l in labels) == 2 and any("+ winograd F(4x4,3x3) output transform]" in l for l in labels), labels
+    net.blobs["data"].data[...] = x
+    out = net.forward()["cat"]
+    assert out.shape == (2, 96, 10, 9) and relerr(out, ref["cat"]) < 2e-4
+    net.params["c1"][0].data[...] *= -0.5
+    params["c1"] = [np.array(b.data) for b in net.params["c1"]]
+    ref2 = orc.forward(spec, params, {"data": x}, keep="all", fast_pool=False)
+    assert relerr(net.forward()["cat"], ref2["cat"]) < 2e-4 and relerr(ref2["cat"], ref["cat"]) > 1e-3
+    net._engine.wfused = False
+    net._engine.build()
+    assert sum("winograd" in l for l in net.op_labels()) == 2 and sum("transformed-domain" in l for l in net.op_labels()) == 1
+    net.blobs["data"].data[...] = x
+    assert relerr(net.forward()["cat"], ref2["cat"]) < 2e-4
+
+
 def test_reshape_grows_winograd_buffers(backend):
     """net.reshape() to a larger clip batch re-plans the Winograd route (transformed-volume scratch, batched
     plans, per-point weights) and still matches the oracle; shrinking back reuses the storage."""
