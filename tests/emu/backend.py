@@ -26,7 +26,7 @@ def build_emu(force: bool = False) -> str:
     stale = force or not os.path.exists(EMU_LIB) or any(
         os.path.getmtime(s) > os.path.getmtime(EMU_LIB) for s in srcs)
     if stale:
-        subprocess.run(["make", "-C", CSRC, "emu"], check=True, stdout=subprocess.DEVNULL)
+        subprocess.run(["make", "-j8", "-C", CSRC, "emu"], check=True, stdout=subprocess.DEVNULL)
     return EMU_LIB
 
 
