@@ -599,8 +599,10 @@ extern "C" int eco_wgemm_plan_create(int32_t n, int32_t cin, int32_t cout, int32
   plan->ksplit = 1;
   plan->bn = 256;
   if (cin % 16 == 0 && cin > 0 && n > 0 && d > 0 && th > 0 && tw > 0) {
-    // Tile width and split-K by a small cost model: workgroups per round = 2 per CU; a workgroup costs its MFMA
-    // time at half a CU plus ~3 us of pipeline fill and store; pick the (bn, ksplit) with the fewest rounds x cost.
+    // Tile width and split-K by a small cost model.  The CUs are MFMA-bound once two workgroups share one, so a
+    // launch takes (workgroups on the fullest CU) x (one workgroup's MFMA time on a whole CU) -- 576 workgroups on
+    // 256 CUs cost three of those, not 576/768 of a round -- plus ~3 us of pipeline fill and store per round of
+    // resident workgroups; pick the (bn, ksplit) that minimises it.
     const long nb = (long)n * th * tw, ntot = nb * d;
     const long mblocks = ceil_div(cout, bm);
     double best = 1e30;
@@ -614,12 +616,12 @@ extern "C" int eco_wgemm_plan_create(int32_t n, int32_t cin, int32_t cout, int32
         long occ = 160 * 1024 / lds;                                         // workgroups resident per CU (LDS-bound)
         if (occ > 4) occ = 4;
         const long slots = occ * num_cu;
-        const double t_wg = 2.0 * bm * bn * 16.0 * (plan->nstages / (double)sp) * occ / (157.3e12 / num_cu) + 3e-6;
+        const double t_cu = 2.0 * bm * bn * 16.0 * (plan->nstages / (double)sp) / (157.3e12 / num_cu);
         // every extra slice is one more write of M here and one more read in the output transform (~4 TB/s each,
         // measured on the transforms): without this term res4 (1152 tiles on 512 slots) took three slices and the
         // output transform gave back what the GEMM had gained
         const double t_slices = (sp - 1) * 2.0 * (double)points * cout * ntot * 4.0 / 4e12;
-        const double t = (double)ceil_div(wgs, slots) * t_wg + t_slices;
+        const double t = (double)ceil_div(wgs, (long)num_cu) * t_cu + (double)ceil_div(wgs, slots) * 3e-6 + t_slices;
         if (t < best * 0.97) { best = t; plan->bn = bn; plan->ksplit = sp; }
       }
   }
