@@ -103,6 +103,14 @@ __device__ __forceinline__ void wg_barrier_nodrain() {
 #endif
 }
 
+// Issue priority of this wave among the waves of its SIMD (s_setprio 0..3; 0 is the launch default).
+template <int P>
+__device__ __forceinline__ void set_wave_priority() {
+#ifndef ECO_EMU
+  __builtin_amdgcn_s_setprio(P);
+#endif
+}
+
 // Make a wave-uniform value provably uniform (SGPR) for the compiler.
 __device__ __forceinline__ int uniform(int v) {
 #ifdef ECO_EMU

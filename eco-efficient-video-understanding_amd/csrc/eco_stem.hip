@@ -14,16 +14,33 @@
 //   * the 17 x 29 conv outputs under the patch (one halo row / column, 10 % extra work) are computed as a
 //     cout x 512 x 148 GEMM on v_mfma_f32_32x32x2_f32: wave w owns 128 of the 512 position columns, all channels;
 //     the B fragment of k = (c, ky, kx) for conv position (r, q) is the LDS word patch[c][2r + ky][2q + kx], i.e.
-//     a per-lane base plus a per-k offset that every lane advances itself (k = 2*kp + half walks (c, ky, kx));
+//     a per-lane base plus a per-k offset (round 3: an instruction immediate, see below);
 //   * bias, folded BN and ReLU are applied to the accumulators, which go through LDS (reusing the patch's space,
 //     16 channels at a time) so that the 3x3 stride-2 windows can be taken across lanes; only the pooled
 //     cout x 8 x 14 values are stored.  conv1's output never exists in HBM.
 // Measured (512 frames of 224 x 224, warm): 1.35 ms = 65 % of the fp32-MFMA peak on the executed 139 GFLOP; the
 // first cut took 2.1 ms with its operand loads in rolled loops (one memory round trip each) and a table lookup in
 // front of every fragment read.
+// Round 3: the round-2 version read both operands with a two-word lane stride (patch word 2q + kx, weight word
+// 2m + half): every fragment ds_read_b32 was 2-way bank conflicted (SQ_LDS_BANK_CONFLICT 134 M cycles per launch, the
+// only kernel of the step with any) and each k-step advanced the per-lane patch offset with five VALU instructions.
+// Now the patch rows are stored column-parity split (even columns, then odd columns: column 2q + kx is word
+// (kx & 1)*32 + q + (kx >> 1), so consecutive positions read consecutive words), the weights as [k][cout], and
+// the offset of tap k is a compile-time immediate of the ds_read: the lanes of the upper half-wave (k odd) differ from
+// the lower half by one of five constants, kept as five per-lane base registers -- no VALU in the reduction at all.
+// What does NOT help (measured, profiles/r03_notes.md): starting the two workgroups of a CU half a patch apart, or
+// raising the epilogue's wave priority.  A wave issuing back-to-back f32 MFMAs keeps its SIMD's VALU to itself: the
+// other workgroup's epilogue wave on that SIMD gets no VALU slot and one LDS instruction per 32 cycles until the
+// reduction ends (tools/ubench/mfma_partner.hip), so reduction and epilogue of the two workgroups take turns whatever
+// their phase.  The levers are the epilogue's own instruction count and latency: the BN scale is folded into the
+// LDS-resident weights and the shift into the accumulators' start value, ReLU is applied to the pooled values.
 // fp32 arithmetic: the same products as the reference's sgemm, summed per output in k order by the MFMA chain.
 #include <float.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <type_traits>
+#include <utility>
 
 #include "eco_common.h"
 
@@ -35,9 +52,51 @@ constexpr int kStemNPos = kStemCR * kStemCQ;             // 493 conv positions, 
 constexpr int kStemIR = 2 * (kStemCR - 1) + 7, kStemIQ = 2 * (kStemCQ - 1) + 7;   // input patch: 39 x 63
 constexpr int kStemK = 147, kStemKP = 74;                // k = (c, ky, kx); k-pairs (148: one zero row)
 
+// LDS word of tap k = (c, ky, kx) relative to a position's base word (2r*IQ + q): patch row c*IR + ky, column kx in the
+// parity-split row layout.
+constexpr int stem_ko(int k) {
+  const int c = k / 49, ky = (k % 49) / 7, kx = k % 7;
+  return (c * kStemIR + ky) * kStemIQ + (kx & 1) * 32 + (kx >> 1);
+}
+// k-step kp multiplies taps 2kp (lanes 0-31) and 2kp+1 (lanes 32-63); the zero-weight padding row k = 147 re-reads tap
+// 145, a word of the position's own receptive field (a word outside it could turn 0 * inf into a NaN the reference's
+// output would not have).
+constexpr int stem_k1(int kp) { return 2 * kp + 1 < kStemK ? 2 * kp + 1 : kStemK - 2; }
+constexpr int stem_delta(int kp) { return stem_ko(stem_k1(kp)) - stem_ko(2 * kp); }
+constexpr int stem_imm(int kp) { return stem_delta(kp) < 0 ? stem_ko(stem_k1(kp)) : stem_ko(2 * kp); }
+constexpr int kStemDeltaChan = stem_ko(49) - stem_ko(48);   // the one pair that straddles two input channels
+// the five (lower half, upper half) base adjustments: next column even->odd, odd->even, next kernel row, next channel,
+// and the padding step
+constexpr int kStemNT = 5;
+template <int... I, class F>
+__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+constexpr int stem_type(int kp) {
+  const int d = stem_delta(kp);
+  return d == 32 ? 0 : d == -31 ? 1 : d == kStemIQ - 3 ? 2 : d == kStemDeltaChan ? 3 : d == 31 ? 4 : -1;
+}
+constexpr bool stem_types_ok() {
+  for (int kp = 0; kp < kStemKP; ++kp)
+    if (stem_type(kp) < 0 || stem_imm(kp) < 0) return false;
+  return true;
+}
+static_assert(stem_types_ok(), "every k-step's half-wave offset difference is one of the five known constants");
+
+#if defined(ECO_STEM_PROBE) && (ECO_STEM_PROBE & 4)   // bit 2: per-phase s_memtime stamps of the first patches (tools/exp)
+__device__ unsigned long long g_stem_ts[1024 * 64];
+#define STEM_STAMP(slot) do { if (tid == 0 && stamp_n < 64) g_stem_ts[(long)blockIdx.x * 64 + stamp_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STEM_STAMP(slot) do { } while (0)
+#endif
+
 struct StemArgs {
   const float* x;        // [n][3][H][W]
-  const float* wp;       // [74][cout][2] packed weights (k-pair interleaved), zero for k = 147
+  const float* wp;       // [148][cout] packed weights (k-major), zero for k = 147
   const float* bias;
   const float* bn_scale;
   const float* bn_shift;
@@ -60,10 +119,10 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
   static_assert(XS_WORDS >= IN_WORDS, "stage must cover the patch");
   constexpr int XU = (IN_ROWS + 3) / 4, WU = (W_WORDS / 4 + 255) / 256;
   ECO_DYNAMIC_LDS(lds);
-  float* const Xs = lds;                                 // [3][39][63]
+  float* const Xs = lds;                                 // [3][39][63], each row: even columns, then odd columns
   float* const Ss = lds;                                 // staging [16][STAGE_LD] (after the reduction)
-  float* const Ws = lds + XS_WORDS;                      // [74][COUT][2], resident for the workgroup's lifetime
-  float* const Es = Ws + W_WORDS;                        // epilogue constants [3][COUT]: bias, BN scale, BN shift
+  float* const Ws = lds + XS_WORDS;                      // [148][COUT], resident for the workgroup's lifetime
+  float* const Es = Ws + W_WORDS;                        // [2][COUT]: BN scale (used once), accumulator start value
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
@@ -71,7 +130,11 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
   const int half = lane >> 5, l31 = lane & 31;
   const int tpf = a.tiles_h * a.tiles_w;
 
-  // ---- once per workgroup: the packed weights and the epilogue's per-channel constants ----
+  // ---- once per workgroup: the packed weights, with the folded-BN scale multiplied in, and the per-channel constant
+  // the accumulators start from: y = (conv + bias) * scale + shift = sum_k (w * scale) x + (bias * scale + shift).
+  // f32 MFMAs and VALU instructions of the same SIMD do not overlap on gfx950 (tools/ubench/mfma_valu_overlap.hip:
+  // every VALU instruction costs ~6 cycles of the matrix pipe, whichever wave issues it), so the three VALU
+  // instructions per conv output the epilogue used to spend here came straight out of the reduction's time. ----
   {
     float4 wv[WU];
 #pragma unroll
@@ -79,14 +142,19 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
       const int i = tid + 256 * u;
       wv[u] = i < W_WORDS / 4 ? ld((const float4*)a.wp + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (tid < 3 * COUT) {
-      const int which = tid / COUT, ch = tid - which * COUT;
-      const float* src = which == 0 ? a.bias : which == 1 ? a.bn_scale : a.bn_shift;
-      Es[tid] = src ? ld(src + ch) : (which == 1 ? 1.0f : 0.0f);
+    if (tid < COUT) {
+      const float b = a.bias ? ld(a.bias + tid) : 0.0f;
+      const float sc = a.bn_scale ? ld(a.bn_scale + tid) : 1.0f, sh = a.bn_scale ? ld(a.bn_shift + tid) : 0.0f;
+      Es[tid] = sc;
+      Es[COUT + tid] = b * sc + sh;
     }
+    __syncthreads();
 #pragma unroll
     for (int u = 0; u < WU; ++u)
-      if (tid + 256 * u < W_WORDS / 4) ((float4*)Ws)[tid + 256 * u] = wv[u];
+      if (tid + 256 * u < W_WORDS / 4) {
+        const float4 sc = ((const float4*)Es)[(tid + 256 * u) % (COUT / 4)];   // row k of [148][COUT]: channel = word % COUT
+        ((float4*)Ws)[tid + 256 * u] = make_float4(wv[u].x * sc.x, wv[u].y * sc.y, wv[u].z * sc.z, wv[u].w * sc.w);
+      }
   }
 
   // A wave takes whole patch rows (lane = column): the row arithmetic is scalar, a lane's address is base + lane,
@@ -110,26 +178,29 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
   auto store_patch = [&]() {
 #pragma unroll
     for (int u = 0; u < XU; ++u)
-      if (lane < kStemIQ && wave + 4 * u < IN_ROWS) Xs[(wave + 4 * u) * kStemIQ + lane] = xv[u];
+      if (lane < kStemIQ && wave + 4 * u < IN_ROWS) Xs[(wave + 4 * u) * kStemIQ + (lane & 1) * 32 + (lane >> 1)] = xv[u];
   };
 
-  // ---- this lane's four position columns: conv position p = wave*128 + j*32 + l31 -> patch word 2r*IQ + 2q ----
+  // ---- this lane's four position columns: conv position p = wave*128 + j*32 + l31 -> patch word 2r*IQ + q ----
   int pbase[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     int p = wave * 128 + j * 32 + l31;
     if (p >= kStemNPos) p = kStemNPos - 1;                // padding columns: any valid word (never stored)
     const int r = p / kStemCQ, q = p - r * kStemCQ;
-    pbase[j] = 2 * r * kStemIQ + 2 * q;
+    pbase[j] = 2 * r * kStemIQ + q;
   }
   const bool last_col_ok = wave * 128 + 96 + l31 < kStemNPos;   // only wave 3's j = 3 has padding columns
-  const float* wl = Ws + 2 * l31 + half;                  // A[m = l31 (+32 i)][k = 2 kp + half]
+  const float* wl = Ws + half * COUT + l31;               // A[m = l31 (+32 i)][k = 2 kp + half]
   // pooling threads: 14 x 8 pooled positions x 2 channel phases = 224 of the 256
   const int pw = tid % kStemPW, ph = (tid / kStemPW) % kStemPH, clo = tid / (kStemPW * kStemPH);
   const float* const sp0 = Ss + clo * STAGE_LD + 2 * ph * kStemCQ + 2 * pw;
   float* const sw0 = Ss + 4 * half * STAGE_LD + wave * 128 + l31;
   const long ych = (long)a.PHo * a.PWo;
+  const float relu_floor = a.relu ? 0.0f : -FLT_MAX;
 
+  int stamp_n = 0;
+  (void)stamp_n;
   int patch = (int)blockIdx.x;
   load_patch(patch);
   store_patch();
@@ -137,53 +208,62 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
 
   while (true) {
     const int next = patch + (int)gridDim.x;
+    STEM_STAMP(0);
     if (next < a.total) load_patch(next);                 // in flight under the reduction below
 
     f32x16 acc[TMC][4];
 #pragma unroll
     for (int i = 0; i < TMC; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int r = 0; r < 16; ++r) {
+        const float c0 = Es[COUT + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int j = 0; j < 4; ++j) acc[i][j][r] = c0;
+      }
 
-    // patch word offset of this lane's k = 2*kp + half = (c, ky, kx), advanced by two taps per step with plain
-    // VALU (a per-step table lookup -- scalar or LDS -- would put a memory latency in front of every fragment read;
-    // the first cut did).  k = 147 (the zero-weight padding row) re-reads the window's first tap: a word of this
-    // position's own receptive field.  Step kp + 1's fragments are read before step kp's products issue.
-    // (The bases are made opaque per patch: as loop invariants the compiler would hoist all 74 x 4 fragment
-    // addresses out of the patch loop and spill them.)
-    int ko = half, kx = half, ky = 0;
+    // Fragment addresses: base register of the k-step's type + compile-time immediate (stem_imm).  The bases are made
+    // opaque per patch: as loop invariants the compiler would otherwise materialise all 74 x 4 fragment addresses
+    // outside the patch loop and spill them.
+    int pb[kStemNT][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ECO_OPAQUE(pbase[j]);
-    ECO_OPAQUE(ko);
-    ECO_OPAQUE(kx);
+    for (int j = 0; j < 4; ++j) {
+      pb[0][j] = pbase[j] + (half ? 32 : 0);
+      pb[1][j] = pbase[j] + (half ? 0 : 31);
+      pb[2][j] = pbase[j] + (half ? kStemIQ - 3 : 0);
+      pb[3][j] = pbase[j] + (half ? kStemDeltaChan : 0);
+      pb[4][j] = pbase[j] + (half ? 31 : 0);
+#pragma unroll
+      for (int t = 0; t < kStemNT; ++t) ECO_OPAQUE(pb[t][j]);
+    }
     float af[2][TMC], bf[2][4];
 #pragma unroll
-    for (int i = 0; i < TMC; ++i) af[0][i] = wl[(32 * i) * 2];
+    for (int i = 0; i < TMC; ++i) af[0][i] = wl[32 * i];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bf[0][j] = Xs[pbase[j] + ko];
+    for (int j = 0; j < 4; ++j) bf[0][j] = Xs[pb[stem_type(0)][j] + stem_imm(0)];
+    // unrolled over the 74 k-steps with the step as a compile-time constant (a `#pragma unroll` loop leaves the tap
+    // tables as run-time arithmetic until after the unroller has priced -- and refused -- the body)
+#if !defined(ECO_STEM_PROBE) || !(ECO_STEM_PROBE & 1)   // probe builds (tools/exp/stem_probe.sh): bit 0 drops the reduction
+    static_for<kStemKP>([&](auto KP) __attribute__((always_inline)) {
+      constexpr int kp = decltype(KP)::value;
+      constexpr int cur = kp & 1;
+      if constexpr (kp + 1 < kStemKP) {   // step kp + 1's fragments are read before step kp's products issue
+        constexpr int ty = stem_type(kp + 1), imm = stem_imm(kp + 1);
 #pragma unroll
-    for (int kp = 0; kp < kStemKP; ++kp) {
-      const int cur = kp & 1;
-      if (kp + 1 < kStemKP) {
-        kx += 2; ko += 2;
-        if (kx >= 7) {
-          kx -= 7; ko += kStemIQ - 7;
-          if (++ky == 7) { ky = 0; ko += (kStemIR - 7) * kStemIQ; }
-        }
+        for (int i = 0; i < TMC; ++i) af[cur ^ 1][i] = wl[(kp + 1) * 2 * COUT + 32 * i];
 #pragma unroll
-        for (int i = 0; i < TMC; ++i) af[cur ^ 1][i] = wl[((kp + 1) * COUT + 32 * i) * 2];
-        const int koe = (kp + 1 == kStemKP - 1 && half) ? 0 : ko;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bf[cur ^ 1][j] = Xs[pbase[j] + koe];
+        for (int j = 0; j < 4; ++j) bf[cur ^ 1][j] = Xs[pb[ty][j] + imm];
       }
+      sched_fence();   // reads of step kp + 1, then the products of step kp: the reads' latency hides under 8 MFMAs
 #pragma unroll
       for (int i = 0; i < TMC; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma_32x32x2(af[cur][i], bf[cur][j], acc[i][j]);
-    }
+      sched_fence();
+    });
+#endif
+    STEM_STAMP(1);
     __syncthreads();   // every wave is done with Xs: the space becomes the pooling stage
+    STEM_STAMP(2);
 
     // ---- per 16 channels: epilogue into the stage, 3x3 stride-2 max over it, pooled store.  A thread's nine window
     // offsets are fixed per patch (taps outside the conv image -- the MAX window is clipped to it,
@@ -201,6 +281,17 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
       for (int dx = 0; dx < 3; ++dx)
         woff[dy * 3 + dx] = (r0 + 2 * ph + dy < a.Ho && q0 + 2 * pw + dx < a.Wo) ? dy * kStemCQ + dx : 0;
     float* const yp0 = a.y + (((long)f * a.cout + clo) * a.PHo + gph) * a.PWo + gpw;
+#if defined(ECO_STEM_PROBE) && (ECO_STEM_PROBE & 2)   // bit 1 drops the epilogue (the accumulators stay live)
+    if (a.total < 0) {
+#pragma unroll
+      for (int i = 0; i < TMC; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st(yp0 + (i * 4 + j) * 16 + r, acc[i][j][r]);
+    }
+    if (a.total >= 0) goto epilogue_done;
+#endif
 #pragma unroll
     for (int i = 0; i < TMC; ++i) {
 #pragma unroll
@@ -209,14 +300,9 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
         for (int rr = 0; rr < 8; ++rr) {
           const int r = 8 * rh + rr;
           const int cl0 = (rr & 3) + 8 * (rr >> 2);        // + 4*half: this lane's channel within the 16
-          const int ch = 32 * i + 16 * rh + cl0 + 4 * half;
-          const float b = Es[ch], sc = Es[COUT + ch], sh = Es[2 * COUT + ch];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float v = (acc[i][j][r] + b) * sc + sh;
-            if (a.relu) v = fmaxf(v, 0.0f);
-            if (j < 3 || last_col_ok) sw0[cl0 * STAGE_LD + j * 32] = v;
-          }
+          for (int j = 0; j < 4; ++j)
+            if (j < 3 || last_col_ok) sw0[cl0 * STAGE_LD + j * 32] = acc[i][j][r];
         }
         __syncthreads();
         if (pool_thread) {
@@ -226,12 +312,16 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
             float m = sp[woff[0]];
 #pragma unroll
             for (int k = 1; k < 9; ++k) m = fmaxf(m, sp[woff[k]]);
-            st(yp0 + (32 * i + 16 * rh + 2 * u) * ych, m);
+            st(yp0 + (32 * i + 16 * rh + 2 * u) * ych, fmaxf(m, relu_floor));   // ReLU commutes with the MAX window
           }
         }
         __syncthreads();
       }
     }
+#if defined(ECO_STEM_PROBE) && (ECO_STEM_PROBE & 2)
+  epilogue_done:
+#endif
+    STEM_STAMP(3);
     if (next >= a.total) break;
     store_patch();
     __syncthreads();
@@ -242,6 +332,13 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
 }  // namespace eco
 
 using namespace eco;
+
+#if defined(ECO_STEM_PROBE) && (ECO_STEM_PROBE & 4)
+extern "C" int eco_stem_probe_read(unsigned long long* dst) {
+  hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stem_ts), sizeof(g_stem_ts));
+}
+#endif
 
 static int stem_dims(int h, int w, int* ho, int* wo, int* pho, int* pwo) {
   *ho = (h + 6 - 7) / 2 + 1;
@@ -257,7 +354,7 @@ extern "C" int eco_stem_pack_weights(const float* w, int32_t cout, float* wp) {
   ECO_REQUIRE(w && wp && (cout == 32 || cout == 64), "stem: weights for 32 or 64 output channels (got %d)", cout);
   memset(wp, 0, sizeof(float) * (size_t)kStemKP * cout * 2);
   for (int k = 0; k < kStemK; ++k)
-    for (int m = 0; m < cout; ++m) wp[((long)(k / 2) * cout + m) * 2 + (k & 1)] = w[(long)m * kStemK + k];
+    for (int m = 0; m < cout; ++m) wp[(long)k * cout + m] = w[(long)m * kStemK + k];
   return ECO_OK;
 }
 

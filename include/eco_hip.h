@@ -282,7 +282,8 @@ int eco_softmax_loss_forward(const float* x, const float* label, float* out, int
  * stride 2, ceil rule): models_ECO_Lite/kinetics/deploy.prototxt:8-77; conv_layer.cpp:28-43, bn_layer.cpp:93-207,
  * relu_layer.cpp:10-20, pooling_layer.cpp:131-147,199-237.  x: [n,3,h,w] fp32 -> y: [n,cout,PH,PW] with
  * HO = (h-1)/2+1, PH = ceil((HO-3)/2)+1 (same for w); conv1's own output is never written. */
-/* HOST: w[cout][3][7][7] -> wp[74][cout][2] (k-pair interleaved, k = c*49 + ky*7 + kx; row 147 zero). */
+/* HOST: w[cout][3][7][7] -> wp[148][cout] (k-major, k = c*49 + ky*7 + kx; row 147 zero).  The kernel multiplies the
+ * folded-BN scale into its LDS copy of the weights and starts the accumulators from bias*scale + shift. */
 int eco_stem_pack_weights(const float* w, int32_t cout, float* wp);
 /* max_workgroups: 0 = two persistent workgroups per compute unit of the current device. */
 int eco_stem_forward(const float* x, const float* wp, const float* bias, const float* bn_scale, const float* bn_shift,

@@ -1,8 +1,10 @@
 // TEST INFRASTRUCTURE (oracle/ref_shim): minimal stand-in for caffe/common.hpp so that a few reference source
-// files (util/im2col.cpp, layers/pooling_layer.cpp) compile *unmodified, from where they lie under
-// /root/reference* without glog / gflags / boost / protobuf / CUDA.  Only what those files use is provided.
+// files (util/im2col.cpp and layers/{pooling,bn,permute,eltwise,concat,inner_product,reshape,relu}_layer.cpp)
+// compile *unmodified, from where they lie under /root/reference* without glog / gflags / boost / protobuf /
+// CUDA.  Only what those files use is provided.
 // Never part of the product; see oracle/Makefile.
 #pragma once
+#include <algorithm>
 #include <cfloat>
 #include <climits>
 #include <cmath>
@@ -29,6 +31,12 @@ struct Fatal {
   template <typename T> Fatal& operator<<(const T& v) { os << v; return *this; }
 };
 struct Voidify { void operator&(const Fatal&) {} };
+// LOG(INFO) / LOG(WARNING) / LOG(ERROR): swallowed; LOG(FATAL) aborts like a failed CHECK.
+struct Quiet { template <typename T> Quiet& operator<<(const T&) { return *this; } };
+struct Log_INFO : Quiet { Log_INFO(const char*, int) {} };
+struct Log_WARNING : Quiet { Log_WARNING(const char*, int) {} };
+struct Log_ERROR : Quiet { Log_ERROR(const char*, int) {} };
+struct Log_FATAL : Fatal { Log_FATAL(const char* f, int l) : Fatal(f, l, "LOG(FATAL)") {} };
 }  // namespace ref_shim
 #define CHECK(c) (c) ? (void)0 : ref_shim::Voidify() & ref_shim::Fatal(__FILE__, __LINE__, #c)
 #define CHECK_OP(a, b, op) CHECK((a) op (b))
@@ -43,7 +51,7 @@ struct Voidify { void operator&(const Fatal&) {} };
 #define DCHECK_GT(a, b) CHECK_GT(a, b)
 #define DCHECK_GE(a, b) CHECK_GE(a, b)
 #define DCHECK_LE(a, b) CHECK_LE(a, b)
-#define LOG(sev) ref_shim::Fatal(__FILE__, __LINE__, #sev)
+#define LOG(sev) ref_shim::Log_##sev(__FILE__, __LINE__)
 #define NOT_IMPLEMENTED LOG(FATAL) << "Not Implemented Yet"
 #define NO_GPU LOG(FATAL) << "Cannot use GPU in CPU-only Caffe: check mode."
 

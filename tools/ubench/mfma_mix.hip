@@ -1,0 +1,101 @@
+// What does one extra instruction of each class cost the f32 MFMA stream of the SAME wave on gfx950?
+// One wave per SIMD (256-thread workgroup per CU, launch_bounds(256,1)) or two (512 threads); per iteration 16
+// v_mfma_f32_32x32x2_f32 (= 1024 cycles of matrix pipe) or 32 v_mfma_f32_16x16x4_f32, plus N fillers issued from
+// inline asm between them.  Reports cycles per iteration at the measured time (assuming 2.3 GHz) and the cost per filler.
+//   hipcc --offload-arch=gfx950 -O3 mfma_mix.hip -o mfma_mix
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { F_NONE, F_VFMA, F_VMOV, F_DS32, F_DS64, F_DS128, F_SALU, F_DSW32, F_VFMA_DEP };
+
+template <int FILL, int NF, int MF16>
+__global__ __launch_bounds__(512) void k(float* out, const float* in, int iters) {
+  __shared__ float lds[8192];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 8192; i += blockDim.x) lds[i] = in[i & 4095];
+  __syncthreads();
+  f32x16 acc[4];
+  f32x4 acc4[8];
+  for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  for (int j = 0; j < 8; ++j) for (int r = 0; r < 4; ++r) acc4[j][r] = 0.f;
+  const float a = in[tid], b = in[tid + 64];
+  float v[8];
+  for (int j = 0; j < 8; ++j) v[j] = in[tid + j];
+  const float m = in[tid + 100], c = in[tid + 101];
+  unsigned addr = (unsigned)(tid & 63) * 16u;
+  float d0, d1; float2 d2; float4 d4;
+  int sacc = iters;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (MF16) {
+        acc4[(2 * u) & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc4[(2 * u) & 7], 0, 0, 0);
+        acc4[(2 * u + 1) & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc4[(2 * u + 1) & 7], 0, 0, 0);
+      } else {
+        acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[u & 3], 0, 0, 0);
+      }
+      if (u < NF) {
+        if (FILL == F_VFMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[u & 7]) : "v"(m), "v"(c));
+        if (FILL == F_VFMA_DEP) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[0]) : "v"(m), "v"(c));
+        if (FILL == F_VMOV) asm volatile("v_mov_b32 %0, %1" : "=v"(v[u & 7]) : "v"(m));
+        if (FILL == F_DS32) asm volatile("ds_read_b32 %0, %1" : "=v"(d0) : "v"(addr));
+        if (FILL == F_DS64) asm volatile("ds_read_b64 %0, %1" : "=v"(d2) : "v"(addr));
+        if (FILL == F_DS128) asm volatile("ds_read_b128 %0, %1" : "=v"(d4) : "v"(addr));
+        if (FILL == F_DSW32) asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(m));
+        if (FILL == F_SALU) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (FILL == F_DS32 || FILL == F_DS64 || FILL == F_DS128 || FILL == F_DSW32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  float res = (float)sacc;
+  for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) res += acc[j][r];
+  for (int j = 0; j < 8; ++j) for (int r = 0; r < 4; ++r) res += acc4[j][r];
+  for (int j = 0; j < 8; ++j) res += v[j];
+  if (res == 12345.678f) out[blockIdx.x * 512 + tid] = res + d0 + d2.x + d4.x;
+}
+
+static float g_base[2][2];
+template <int FILL, int NF, int MF16>
+void run(const char* name, float* out, const float* in, int threads) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int iters = 20000;
+  hipLaunchKernelGGL((k<FILL, NF, MF16>), dim3(256), dim3(threads), 0, 0, out, in, 100);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((k<FILL, NF, MF16>), dim3(256), dim3(threads), 0, 0, out, in, iters);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const int w = threads / 256 - 1;
+  if (FILL == F_NONE) g_base[MF16][w] = ms;
+  const double cyc = ms * 1e-3 * 2.3e9 / iters;   // cycles per iteration per SIMD (both waves of a SIMD together)
+  const double per = NF ? (ms - g_base[MF16][w]) * 1e-3 * 2.3e9 / iters / (NF * (threads / 256)) : 0.0;
+  printf("%-12s %s waves/SIMD %d  fillers/iter %2d: %.3f ms  %7.1f cyc/iter  -> %5.1f cycles per filler\n",
+         MF16 ? "16x16x4" : "32x32x2", name, threads / 256, NF, ms, cyc, per);
+}
+
+template <int MF16>
+void all(float* out, const float* in, int threads) {
+  run<F_NONE, 0, MF16>("none      ", out, in, threads);
+  run<F_VFMA, 16, MF16>("v_fma     ", out, in, threads);
+  run<F_VFMA, 8, MF16>("v_fma     ", out, in, threads);
+  run<F_VFMA_DEP, 16, MF16>("v_fma dep ", out, in, threads);
+  run<F_VMOV, 16, MF16>("v_mov     ", out, in, threads);
+  run<F_DS32, 16, MF16>("ds_read32 ", out, in, threads);
+  run<F_DS64, 16, MF16>("ds_read64 ", out, in, threads);
+  run<F_DS128, 16, MF16>("ds_read128", out, in, threads);
+  run<F_DS128, 8, MF16>("ds_read128", out, in, threads);
+  run<F_DSW32, 16, MF16>("ds_write32", out, in, threads);
+  run<F_SALU, 16, MF16>("s_add     ", out, in, threads);
+}
+
+int main() {
+  float *in, *out;
+  hipMalloc(&in, 8192 * 4); hipMalloc(&out, 256 * 512 * 4);
+  float h[8192]; for (int i = 0; i < 8192; ++i) h[i] = (rand() / (float)RAND_MAX) * 2 - 1;
+  hipMemcpy(in, h, 8192 * 4, hipMemcpyHostToDevice);
+  for (int threads = 256; threads <= 512; threads += 256) { all<0>(out, in, threads); all<1>(out, in, threads); }
+  return 0;
+}
