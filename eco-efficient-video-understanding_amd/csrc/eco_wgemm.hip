@@ -203,102 +203,126 @@ __device__ __forceinline__ void wino_bt_d_b(const float (&d)[6][6], float (&v)[6
     }
 }
 
+// The 6x6 input tile of (channel plane xp, tile th, tw), zero outside the image.
 template <int VEC>
-__global__ __launch_bounds__(256) void wino_input_pk_kernel(const WinoInPkArgs a) {
-  const int Dp = a.D + 2 * a.pd;
-  const long total = (long)(a.cin / 2) * Dp * a.NB * 2;     // one thread per (channel pair, plane, position, parity)
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int e = (int)(idx & 1);
-    const long pos = idx >> 1;
-    const int r = (int)(pos % a.NB);
-    const long t1 = pos / a.NB;
-    const int dp = (int)(t1 % Dp);
-    const int cp = (int)(t1 / Dp);
-    const int d = dp - a.pd;
-    float* out = a.v + idx;                                 // (cp*Q + dp*NB + r)*2 + e: consecutive lanes, consecutive floats
-    if ((unsigned)d >= (unsigned)a.D) {   // padding plane: zeros at every transform point
+__device__ __forceinline__ void wino_load_tile(const float* xp, int H, int W, int th, int tw, float (&dd)[6][6]) {
 #pragma unroll
-      for (int p = 0; p < kWgP; ++p) st(out + (long)p * a.v_pstride, 0.0f);
-      continue;
-    }
-    const int tw = r % a.TW, t2 = r / a.TW;
-    const int th = t2 % a.TH, b = t2 / a.TH;
-    const float* xp = a.x + (((long)b * a.cin + 2 * cp + e) * a.D + d) * a.H * a.W;
-    float dd[6][6], v[6][6];
+  for (int i = 0; i < 6; ++i) {
+    const int h = 4 * th - 1 + i;
+    const bool hok = (unsigned)h < (unsigned)H;
+    const float* rp = xp + (hok ? (long)h * W : 0l);
+    const int wl = 4 * tw - 1, wr = 4 * tw + 4;
+    const bool lok = hok && wl >= 0, rok = hok && wr < W;
+    dd[i][0] = lok ? ld(rp + (lok ? wl : 0)) : 0.0f;
+    dd[i][5] = rok ? ld(rp + (rok ? wr : 0)) : 0.0f;
+    if (VEC == 4) {
+      const bool ok = hok && 4 * tw < W;   // W % 4 == 0: the four columns are inside or outside together
+      const float4 q = ld((const float4*)(rp + (ok ? 4 * tw : 0)));
+      dd[i][1] = ok ? q.x : 0.0f; dd[i][2] = ok ? q.y : 0.0f; dd[i][3] = ok ? q.z : 0.0f; dd[i][4] = ok ? q.w : 0.0f;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int h = 4 * th - 1 + i;
-      const bool hok = (unsigned)h < (unsigned)a.H;
-      const float* rp = xp + (hok ? (long)h * a.W : 0l);
-      const int wl = 4 * tw - 1, wr = 4 * tw + 4;
-      const bool lok = hok && wl >= 0, rok = hok && wr < a.W;
-      dd[i][0] = lok ? ld(rp + (lok ? wl : 0)) : 0.0f;
-      dd[i][5] = rok ? ld(rp + (rok ? wr : 0)) : 0.0f;
-      if (VEC == 4) {
-        const bool ok = hok && 4 * tw < a.W;   // W % 4 == 0: the four columns are inside or outside together
-        const float4 q = ld((const float4*)(rp + (ok ? 4 * tw : 0)));
-        dd[i][1] = ok ? q.x : 0.0f; dd[i][2] = ok ? q.y : 0.0f; dd[i][3] = ok ? q.z : 0.0f; dd[i][4] = ok ? q.w : 0.0f;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int w = 4 * tw + j;
-          const bool ok = hok && w < a.W;
-          dd[i][1 + j] = ok ? ld(rp + (ok ? w : 0)) : 0.0f;
-        }
+      for (int j = 0; j < 4; ++j) {
+        const int w = 4 * tw + j;
+        const bool ok = hok && w < W;
+        dd[i][1 + j] = ok ? ld(rp + (ok ? w : 0)) : 0.0f;
       }
     }
-    wino_bt_d_b(dd, v);
+  }
+}
+
+// Both layouts below are written as runs of consecutive floats per transform point: a workgroup owns the 256 floats
+// [base, base + 256) of each of the 36 planes.  STAGED: every thread parks its 36 values in LDS ([36][256] floats) and
+// the run of a point leaves as ONE 16-byte store per lane of one wave (1 KB per instruction, nine instructions per
+// wave) instead of 36 four-byte stores per lane: the round-2 kernels were store-ISSUE bound (rocprof: wait_inst 0.50-0.75
+// of the wave cycles at 3.7-5.0 TB/s).  Needs total % 4 == 0 and 16-byte aligned planes; otherwise the scalar form.
+template <bool STAGED>
+__device__ __forceinline__ void wino_store_points(float* vbase, long v_pstride, long base, long total, const float (&v)[6][6],
+                                                  bool active, float* stage) {
+  const int tid = (int)threadIdx.x;
+  if (!STAGED) {
+    if (active) {
+#pragma unroll
+      for (int p = 0; p < kWgP; ++p) st(vbase + (long)p * v_pstride + base + tid, v[p / 6][p % 6]);
+    }
+    return;
+  }
+#pragma unroll
+  for (int p = 0; p < kWgP; ++p) stage[p * 256 + tid] = v[p / 6][p % 6];
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  if (base + 4 * lane < total) {
+#pragma unroll
+    for (int k = 0; k < kWgP / 4; ++k) {
+      const int p = wave * (kWgP / 4) + k;
+      const float4 q = *(const float4*)(stage + p * 256 + 4 * lane);
+      st((float4*)(vbase + (long)p * v_pstride + base + 4 * lane), q);
+    }
+  }
+  __syncthreads();
+}
+
+// Pair layout V[p][c/2][d'][r][c%2]: float index idx = ((cp*Dp + dp)*NB + r)*2 + e.  The two padding planes get zeros.
+template <int VEC, bool STAGED>
+__global__ __launch_bounds__(256) void wino_input_pk_kernel(const WinoInPkArgs a) {
+  __shared__ __attribute__((aligned(16))) float stage[STAGED ? kWgP * 256 : 4];
+  const int Dp = a.D + 2 * a.pd;
+  const long total = (long)(a.cin / 2) * Dp * a.NB * 2;     // one thread per (channel pair, plane, position, parity)
+  for (long base = (long)blockIdx.x * 256; base < total; base += (long)gridDim.x * 256) {
+    const long idx = base + threadIdx.x;
+    const bool active = idx < total;
+    float v[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int j = 0; j < 6; ++j) st(out + (long)(6 * i + j) * a.v_pstride, v[i][j]);
+      for (int j = 0; j < 6; ++j) v[i][j] = 0.0f;
+    if (active) {
+      const int e = (int)(idx & 1);
+      const long pos = idx >> 1;
+      const int r = (int)(pos % a.NB);
+      const long t1 = pos / a.NB;
+      const int dp = (int)(t1 % Dp);
+      const int cp = (int)(t1 / Dp);
+      const int d = dp - a.pd;
+      if ((unsigned)d < (unsigned)a.D) {   // else a padding plane: zeros at every transform point
+        const int tw = r % a.TW, t2 = r / a.TW;
+        const int th = t2 % a.TH, b = t2 / a.TH;
+        float dd[6][6];
+        wino_load_tile<VEC>(a.x + (((long)b * a.cin + 2 * cp + e) * a.D + d) * a.H * a.W, a.H, a.W, th, tw, dd);
+        wino_bt_d_b(dd, v);
+      }
+    }
+    wino_store_points<STAGED>(a.v, a.v_pstride, base, total, v, active, stage);
   }
 }
 
 // The same transform into the layout of the fused 2-D kernel below, V4[p][c/8][r][c%2][(c/2)%4]: the four k-pair
 // elements a lane of wfused_kernel consumes in a row are one 16-byte vector.  One thread per float of a point's
-// plane, consecutive threads on consecutive floats (256 contiguous bytes per wave and point); D = 1, no padding planes.
-template <int VEC>
+// plane, consecutive threads on consecutive floats; D = 1, no padding planes.
+template <int VEC, bool STAGED>
 __global__ __launch_bounds__(256) void wino_input_q4_kernel(const WinoInPkArgs a) {
+  __shared__ __attribute__((aligned(16))) float stage[STAGED ? kWgP * 256 : 4];
   const long total = (long)a.cin * a.NB;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int c4 = (int)(idx & 3), e = (int)((idx >> 2) & 1);
-    const long pos = idx >> 3;
-    const int r = (int)(pos % a.NB);
-    const int q = (int)(pos / a.NB);
-    const int ch = 8 * q + 2 * c4 + e;
-    float* out = a.v + idx;
-    const int tw = r % a.TW, t2 = r / a.TW;
-    const int th = t2 % a.TH, b = t2 / a.TH;
-    const float* xp = a.x + ((long)b * a.cin + ch) * a.H * a.W;
-    float dd[6][6], v[6][6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int h = 4 * th - 1 + i;
-      const bool hok = (unsigned)h < (unsigned)a.H;
-      const float* rp = xp + (hok ? (long)h * a.W : 0l);
-      const int wl = 4 * tw - 1, wr = 4 * tw + 4;
-      const bool lok = hok && wl >= 0, rok = hok && wr < a.W;
-      dd[i][0] = lok ? ld(rp + (lok ? wl : 0)) : 0.0f;
-      dd[i][5] = rok ? ld(rp + (rok ? wr : 0)) : 0.0f;
-      if (VEC == 4) {
-        const bool ok = hok && 4 * tw < a.W;   // W % 4 == 0: the four columns are inside or outside together
-        const float4 qv = ld((const float4*)(rp + (ok ? 4 * tw : 0)));
-        dd[i][1] = ok ? qv.x : 0.0f; dd[i][2] = ok ? qv.y : 0.0f; dd[i][3] = ok ? qv.z : 0.0f; dd[i][4] = ok ? qv.w : 0.0f;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int w = 4 * tw + j;
-          const bool ok = hok && w < a.W;
-          dd[i][1 + j] = ok ? ld(rp + (ok ? w : 0)) : 0.0f;
-        }
-      }
-    }
-    wino_bt_d_b(dd, v);
+  for (long base = (long)blockIdx.x * 256; base < total; base += (long)gridDim.x * 256) {
+    const long idx = base + threadIdx.x;
+    const bool active = idx < total;
+    float v[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int j = 0; j < 6; ++j) st(out + (long)(6 * i + j) * a.v_pstride, v[i][j]);
+      for (int j = 0; j < 6; ++j) v[i][j] = 0.0f;
+    if (active) {
+      const int c4 = (int)(idx & 3), e = (int)((idx >> 2) & 1);
+      const long pos = idx >> 3;
+      const int r = (int)(pos % a.NB);
+      const int q = (int)(pos / a.NB);
+      const int ch = 8 * q + 2 * c4 + e;
+      const int tw = r % a.TW, t2 = r / a.TW;
+      const int th = t2 % a.TH, b = t2 / a.TH;
+      float dd[6][6];
+      wino_load_tile<VEC>(a.x + ((long)b * a.cin + ch) * a.H * a.W, a.H, a.W, th, tw, dd);
+      wino_bt_d_b(dd, v);
+    }
+    wino_store_points<STAGED>(a.v, a.v_pstride, base, total, v, active, stage);
   }
 }
 
@@ -407,27 +431,60 @@ __device__ __forceinline__ void wino_output_tile(const WinoOutDmArgs& a, const f
 // (The (img, ch, d, t) order -- stores contiguous over the whole tensor, M read in runs of TH*TW floats: 196 / 64 /
 // 16 bytes in res3 / 4 / 5 -- was 9 % slower over the step's 17 transforms; 2 or 4 columns per thread with vector
 // loads of M were slower again: 72 / 144 live tile values.)
-template <int VEC>
+// STAGED (round 3): the 256 consecutive floats a workgroup needs of each point's plane are one 1 KB run; wave w moves
+// the runs of points 9w .. 9w+8 into LDS by LDS-DMA (16 bytes per lane, nine instructions per wave and slice, all in
+// flight at once, no VGPRs) and every thread then picks its 36 values with conflict-free ds_read_b32 -- instead of 36
+// four-byte global loads per thread and slice, which kept the small res4 / res5 launches latency bound (0.22-0.45 of
+// the HBM floor).  Needs 16-byte aligned planes (cout * ntot and the plane stride multiples of 4 floats).
+template <int VEC, bool STAGED>
 __global__ __launch_bounds__(256) void wino_output_dm_kernel(const WinoOutDmArgs a) {
+  __shared__ __attribute__((aligned(16))) float stage[STAGED ? kWgP * 256 : 4];
   const long total = (long)a.cout * a.ntot;
   const int tpp = a.TH * a.TW;
-  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+  const int tid = (int)threadIdx.x;
+  for (long base = (long)blockIdx.x * 256; base < total; base += (long)gridDim.x * 256) {
+    const long q = base + tid;
+    const bool active = q < total;
+    float m[6][6];
+    if (STAGED) {
+      const int lane = tid & 63, wave = uniform(tid >> 6);
+      const bool dma_ok = base + 4 * lane < total;       // total % 4 == 0: a lane's four floats are inside or outside together
+      for (int sl = 0; sl < a.ksplit; ++sl) {
+        const float* src = a.m + (long)sl * a.cout * a.ntot + base + 4 * lane;
+        if (dma_ok) {
+#pragma unroll
+          for (int k = 0; k < kWgP / 4; ++k) {
+            const int p = wave * (kWgP / 4) + k;
+            glds16((const uint4*)(src + (long)p * a.m_pstride), (uint4*)(stage + p * 256));
+          }
+        }
+        wait_dma_all_but<0>();
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < kWgP; ++p) {
+          const float v = stage[p * 256 + tid];
+          m[p / 6][p % 6] = sl == 0 ? v : m[p / 6][p % 6] + v;
+        }
+        __syncthreads();
+      }
+    } else if (active) {
+      const float* mp = a.m + q;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const float* qq = mp + (long)(6 * i + j) * a.m_pstride;
+          float s = ld(qq);
+          for (int sl = 1; sl < a.ksplit; ++sl) s += ld(qq + (long)sl * a.cout * a.ntot);
+          m[i][j] = s;
+        }
+    }
+    if (!active) continue;
     const int ch = (int)(q / a.ntot);
     const int rem = (int)(q - (long)ch * a.ntot);
     const int d = rem / a.NB, r = rem - d * a.NB;
     const int img = r / tpp, t = r - img * tpp;
     const int th = t / a.TW, tw = t - th * a.TW;
-    const float* mp = a.m + q;
-    float m[6][6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const float* qq = mp + (long)(6 * i + j) * a.m_pstride;
-        float s = ld(qq);
-        for (int sl = 1; sl < a.ksplit; ++sl) s += ld(qq + (long)sl * a.cout * a.ntot);
-        m[i][j] = s;
-      }
     wino_output_tile<VEC>(a, m, ch, img, d, th, tw);
   }
 }
@@ -677,8 +734,16 @@ extern "C" int eco_wino_input_pk_forward(const eco_wgemm_plan* plan, const float
   a.v_pstride = (long)(plan->cin / 2) * plan->q * 2;
   const long total = (long)(plan->cin / 2) * (plan->d + 2 * a.pd) * a.NB * 2;
   const bool vec4 = w % 4 == 0 && ((uintptr_t)x & 15) == 0;
-  if (vec4) hipLaunchKernelGGL((wino_input_pk_kernel<4>), dim3(wg_grid(total)), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((wino_input_pk_kernel<1>), dim3(wg_grid(total)), dim3(256), 0, (hipStream_t)stream, a);
+  const bool staged = total % 4 == 0 && a.v_pstride % 4 == 0 && ((uintptr_t)v & 15) == 0;   // 16-byte stores of V
+  const dim3 grid(wg_grid(total)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (staged) {
+    if (vec4) hipLaunchKernelGGL((wino_input_pk_kernel<4, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((wino_input_pk_kernel<1, true>), grid, block, 0, s, a);
+  } else {
+    if (vec4) hipLaunchKernelGGL((wino_input_pk_kernel<4, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((wino_input_pk_kernel<1, false>), grid, block, 0, s, a);
+  }
   return check_launch("eco_wino_input_pk_forward");
 }
 
@@ -698,8 +763,16 @@ extern "C" int eco_wino_input_q4_forward(const eco_wgemm_plan* plan, const float
   a.v_pstride = (long)plan->cin * a.NB;
   const long total = (long)plan->cin * a.NB;
   const bool vec4 = w % 4 == 0 && ((uintptr_t)x & 15) == 0;
-  if (vec4) hipLaunchKernelGGL((wino_input_q4_kernel<4>), dim3(wg_grid(total)), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((wino_input_q4_kernel<1>), dim3(wg_grid(total)), dim3(256), 0, (hipStream_t)stream, a);
+  const bool staged = total % 4 == 0 && a.v_pstride % 4 == 0 && ((uintptr_t)v & 15) == 0;   // 16-byte stores of V
+  const dim3 grid(wg_grid(total)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (staged) {
+    if (vec4) hipLaunchKernelGGL((wino_input_q4_kernel<4, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((wino_input_q4_kernel<1, true>), grid, block, 0, s, a);
+  } else {
+    if (vec4) hipLaunchKernelGGL((wino_input_q4_kernel<4, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((wino_input_q4_kernel<1, false>), grid, block, 0, s, a);
+  }
   return check_launch("eco_wino_input_q4_forward");
 }
 
@@ -790,9 +863,19 @@ extern "C" int eco_wino_output_dm_forward(const eco_wgemm_plan* plan, const floa
   const long tiles = (long)a.n * a.cout * a.D * a.TH * a.TW;
   const dim3 grid(wg_grid(tiles)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (vec == 4) hipLaunchKernelGGL((wino_output_dm_kernel<4>), grid, block, 0, s, a);
-  else if (vec == 2) hipLaunchKernelGGL((wino_output_dm_kernel<2>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((wino_output_dm_kernel<1>), grid, block, 0, s, a);
+  // LDS-DMA of M for the small launches (res4 / res5: a round or two of workgroups, latency bound: 0.045 -> 0.035 ms per
+  // res5 transform); the large ones stream at 4.9-5.3 TB/s either way and lose 5-10 % to the extra barriers
+  const bool staged = ((long)a.cout * a.ntot) % 4 == 0 && a.m_pstride % 4 == 0 && ((uintptr_t)m & 15) == 0 &&
+                      (long)a.cout * a.ntot <= (2l << 20);
+  if (staged) {
+    if (vec == 4) hipLaunchKernelGGL((wino_output_dm_kernel<4, true>), grid, block, 0, s, a);
+    else if (vec == 2) hipLaunchKernelGGL((wino_output_dm_kernel<2, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((wino_output_dm_kernel<1, true>), grid, block, 0, s, a);
+  } else {
+    if (vec == 4) hipLaunchKernelGGL((wino_output_dm_kernel<4, false>), grid, block, 0, s, a);
+    else if (vec == 2) hipLaunchKernelGGL((wino_output_dm_kernel<2, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((wino_output_dm_kernel<1, false>), grid, block, 0, s, a);
+  }
   return check_launch("eco_wino_output_dm_forward");
 }
 
