@@ -14,6 +14,9 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <type_traits>
+#include <utility>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace eco {
@@ -103,6 +106,19 @@ __device__ __forceinline__ void wg_barrier_nodrain() {
 #endif
 }
 
+// Compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>).  For bodies whose
+// tables / register-array indices must be constants: a `#pragma unroll` loop leaves them as run-time arithmetic until
+// after the unroller has priced the body, and a body it then refuses to unroll indexes its register arrays through
+// scratch memory (wfused_kernel<48, *> ran 4x slower that way for one build of round 3).
+template <int... I, class F>
+__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
 // Issue priority of this wave among the waves of its SIMD (s_setprio 0..3; 0 is the launch default).
 template <int P>
 __device__ __forceinline__ void set_wave_priority() {
@@ -171,6 +187,14 @@ __device__ __forceinline__ void st(T* p, T v) {
   if (!emu::check_access(p, sizeof(T), true)) return;
 #endif
   *p = v;
+}
+
+// Load from (wave-uniform base) + (per-lane 32-bit byte offset): the `saddr` form of global_load -- SGPR base, VGPR
+// offset, immediate -- so that a stream of loads off one uniform base costs no per-lane 64-bit address arithmetic.
+// (Beside f32 MFMAs every VALU instruction is ~6 cycles of matrix-pipe time: profiles/r03_notes.md.)
+template <typename T>
+__device__ __forceinline__ T ld_su(const void* uniform_base, unsigned lane_byte_offset) {
+  return ld((const T*)((const char*)uniform_base + lane_byte_offset));
 }
 
 // Dynamic LDS of the launch as a float array (16-byte aligned; no static __shared__ may precede it).

@@ -39,9 +39,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <type_traits>
-#include <utility>
-
 #include "eco_common.h"
 
 namespace eco {
@@ -68,14 +65,6 @@ constexpr int kStemDeltaChan = stem_ko(49) - stem_ko(48);   // the one pair that
 // the five (lower half, upper half) base adjustments: next column even->odd, odd->even, next kernel row, next channel,
 // and the padding step
 constexpr int kStemNT = 5;
-template <int... I, class F>
-__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, I...>, F&& f) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
-}
 constexpr int stem_type(int kp) {
   const int d = stem_delta(kp);
   return d == 32 ? 0 : d == -31 ? 1 : d == kStemIQ - 3 ? 2 : d == kStemDeltaChan ? 3 : d == 31 ? 4 : -1;

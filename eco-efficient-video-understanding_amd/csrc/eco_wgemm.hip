@@ -350,39 +350,44 @@ struct WgVec<2> { typedef float2 type; };
 template <>
 struct WgVec<4> { typedef float4 type; };
 
-// Second half of an output tile: y = s4 A with s4 = A^T m (4 x 6), then the fused epilogue, for channel `ch` of image
-// `img`, depth `d`, tile (th, tw).
+// Element offsets of (image img, channel ch, spatial 0) in the four views of the epilogue (0 where a view is absent).
+struct WinoViewOffsets { long res, raw, act, act2; };
+__device__ __forceinline__ WinoViewOffsets wino_view_offsets(const WinoOutDmArgs& a, int img, int ch) {
+  WinoViewOffsets o;
+  o.res = a.residual.ptr ? view_base(a.residual, img, 0) + (long)ch * a.residual.stride_c : 0;
+  o.raw = a.raw.ptr ? view_base(a.raw, img, 0) + (long)ch * a.raw.stride_c : 0;
+  o.act = a.act.ptr ? view_base(a.act, img, 0) + (long)ch * a.act.stride_c : 0;
+  o.act2 = a.act2.ptr ? view_base(a.act2, img, 0) + (long)ch * a.act2.stride_c : 0;
+  return o;
+}
+
+// Second half of an output tile: y = s4 A with s4 = A^T m (4 x 6), then the fused epilogue, for channel `ch` (view
+// offsets `o`), depth `d`, tile (th, tw).
 template <int VEC>
-__device__ __forceinline__ void wino_output_from_s4(const WinoOutDmArgs& a, const float (&s4)[4][6], int ch, int img, int d,
-                                                    int th, int tw) {
-  constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+__device__ __forceinline__ void wino_output_store(const WinoOutDmArgs& a, const float (&s4)[4][6], int ch, const WinoViewOffsets& o,
+                                                  int d, int th, int tw) {
   typedef typename WgVec<VEC>::type vec_t;
-  const float b = a.bias ? ld(a.bias + ch) : 0.0f;
-  const float sc = a.bn_scale ? ld(a.bn_scale + ch) : 1.0f, sh = a.bn_scale ? ld(a.bn_shift + ch) : 0.0f;
-  const long o_res = a.residual.ptr ? view_base(a.residual, img, 0) + (long)ch * a.residual.stride_c : 0;
-  const long o_raw = a.raw.ptr ? view_base(a.raw, img, 0) + (long)ch * a.raw.stride_c : 0;
-  const long o_act = a.act.ptr ? view_base(a.act, img, 0) + (long)ch * a.act.stride_c : 0;
-  const long o_act2 = a.act2.ptr ? view_base(a.act2, img, 0) + (long)ch * a.act2.stride_c : 0;
+  const unsigned cho = 4u * (unsigned)ch;
+  const float b = a.bias ? ld_su<float>(a.bias, cho) : 0.0f;
+  const float sc = a.bn_scale ? ld_su<float>(a.bn_scale, cho) : 1.0f, sh = a.bn_scale ? ld_su<float>(a.bn_shift, cho) : 0.0f;
+  const float floor_v = a.relu ? 0.0f : -3.402823466e38f;   // one v_max instead of v_max + v_cndmask per output
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int h = 4 * th + p;
     if (h >= a.H) continue;
+    // y = s A, factored (10 VALU instructions instead of 18: beside f32 MFMAs each one is matrix-pipe time)
+    const float t1 = s4[p][1] + s4[p][2], t2 = s4[p][1] - s4[p][2], t3 = s4[p][3] + s4[p][4], t4 = s4[p][3] - s4[p][4];
+    const float yrow[4] = {s4[p][0] + t1 + t3, t2 + 2.0f * t4, t1 + 4.0f * t3, t2 + 8.0f * t4 + s4[p][5]};
 #pragma unroll
     for (int q0 = 0; q0 < 4; q0 += VEC) {
       const int w0 = 4 * tw + q0;
       if (w0 >= a.W) continue;  // W % VEC == 0: the VEC outputs are inside or outside together
       float val[VEC];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        float y = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-          if (AT[q0 + e][k] != 0.0f) y += s4[p][k] * AT[q0 + e][k];
-        val[e] = y + b;
-      }
+      for (int e = 0; e < VEC; ++e) val[e] = yrow[q0 + e] + b;
       const int sp = (d * a.H + h) * a.W + w0;
       if (a.residual.ptr) {
-        const vec_t rv = ld((const vec_t*)((const float*)a.residual.ptr + o_res + sp));
+        const vec_t rv = ld((const vec_t*)((const float*)a.residual.ptr + o.res + sp));
 #pragma unroll
         for (int e = 0; e < VEC; ++e) val[e] += ((const float*)&rv)[e];
       }
@@ -390,39 +395,38 @@ __device__ __forceinline__ void wino_output_from_s4(const WinoOutDmArgs& a, cons
         vec_t ov;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) ((float*)&ov)[e] = val[e];
-        st((vec_t*)(a.raw.ptr + o_raw + sp), ov);
+        st((vec_t*)(a.raw.ptr + o.raw + sp), ov);
       }
       if (a.act.ptr) {
         vec_t ov;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          float o = val[e] * sc + sh;
-          if (a.relu) o = fmaxf(o, 0.0f);
-          ((float*)&ov)[e] = o;
-        }
-        st((vec_t*)(a.act.ptr + o_act + sp), ov);
-        if (a.act2.ptr) st((vec_t*)(a.act2.ptr + o_act2 + sp), ov);
+        for (int e = 0; e < VEC; ++e) ((float*)&ov)[e] = fmaxf(val[e] * sc + sh, floor_v);
+        st((vec_t*)(a.act.ptr + o.act + sp), ov);
+        if (a.act2.ptr) st((vec_t*)(a.act2.ptr + o.act2 + sp), ov);
       }
     }
   }
+}
+
+template <int VEC>
+__device__ __forceinline__ void wino_output_from_s4(const WinoOutDmArgs& a, const float (&s4)[4][6], int ch, int img, int d,
+                                                    int th, int tw) {
+  wino_output_store<VEC>(a, s4, ch, wino_view_offsets(a, img, ch), d, th, tw);
 }
 
 // One output tile: y = A^T m A, then the fused epilogue.
 template <int VEC>
 __device__ __forceinline__ void wino_output_tile(const WinoOutDmArgs& a, const float (&m)[6][6], int ch, int img, int d,
                                                  int th, int tw) {
-  constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
-  float s4[4][6];
+  float s4[4][6];   // A^T m, factored as in wino_output_store
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      float acc = 0.0f;
-#pragma unroll
-      for (int k = 0; k < 6; ++k)
-        if (AT[p][k] != 0.0f) acc += AT[p][k] * m[k][j];
-      s4[p][j] = acc;
-    }
+  for (int j = 0; j < 6; ++j) {
+    const float t1 = m[1][j] + m[2][j], t2 = m[1][j] - m[2][j], t3 = m[3][j] + m[4][j], t4 = m[3][j] - m[4][j];
+    s4[0][j] = m[0][j] + t1 + t3;
+    s4[1][j] = t2 + 2.0f * t4;
+    s4[2][j] = t1 + 4.0f * t3;
+    s4[3][j] = t2 + 8.0f * t4 + m[5][j];
+  }
   wino_output_from_s4<VEC>(a, s4, ch, img, d, th, tw);
 }
 
@@ -513,14 +517,14 @@ struct WFusedArgs {
 
 template <int KP, int VEC>
 __global__ __launch_bounds__(256, 2) void wfused_kernel(const WFusedArgs a) {
-  constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+  const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   constexpr int CH = 16;                 // k-pairs per chunk
   constexpr int NCH = KP / CH;           // chunks per point
   constexpr int NPT = 9;                 // points per wave: three per group
   constexpr int T = NPT * NCH;           // chunks per wave
   constexpr int R = 3;                   // chunks in flight: 3 x 8 sixteen-byte loads per lane (4 would spill)
   static_assert(KP % CH == 0, "");
-  ECO_DYNAMIC_LDS(lds);                  // M[12][32][32]: the group's points, local index lp = 6*(row & 1) + column
+  ECO_DYNAMIC_LDS(lds);                  // M[12][32][32]: the group's points, local index lp = 6*(0 | 1: which row of the pair) + column
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   const int wave = uniform(tid >> 6);
@@ -528,81 +532,95 @@ __global__ __launch_bounds__(256, 2) void wfused_kernel(const WFusedArgs a) {
   const int tile = xcd_remap((int)blockIdx.x, a.mblocks * a.nblk);
   const int mb = tile % a.mblocks, nb = tile / a.mblocks;
   const int n0 = nb * 32;
-  const int loff = 2 * l31 + half;       // this lane's 16-byte vector within a (q, 32 columns) row of V4 ([col][2][4])
+  const unsigned a_voff = 16u * (unsigned)lane;             // this lane's 16-byte vector of a packed-U piece
+  const unsigned b_voff = 16u * (unsigned)(2 * l31 + half);  // ... and within a (q, 32 columns) row of V4 ([col][2][4])
 
   float4 ra[R][CH / 4], rb[R][CH / 4];
   auto issue = [&](int slot, int t) {    // chunk t: point index t / NCH = 3*group + k, local point lp = wave + 4*k
+#if defined(ECO_WFUSED_PROBE) && (ECO_WFUSED_PROBE & 1)   // probe builds (tools/exp): bit 0 = every chunk re-reads one of the first R (cache hits)
+    t = t % R;
+#endif
     const int pi = t / NCH, c = t % NCH;
-    const int p = 12 * (pi / 3) + wave + 4 * (pi % 3);
-    const float4* up = (const float4*)(a.u + (long)p * a.u_pstride + ((long)mb * KP + c * CH) * 64) + lane;
-    const float4* vp = (const float4*)(a.v + (long)p * a.v_pstride) + ((long)(c * (CH / 4)) * a.Q + n0) * 2 + loff;
+    const int lp = wave + 4 * (pi % 3), rr = lp >= 6 ? 1 : 0;
+    const int g = pi / 3;                // group g holds transform rows (1, 2), (3, 4), (0, 5): see the fold below
+    const int p = 6 * (g == 0 ? 1 + rr : g == 1 ? 3 + rr : 5 * rr) + lp - 6 * rr;
+    // wave-uniform bases (SALU) + this lane's constant byte offset: no per-lane address arithmetic per load
+    const float* us = a.u + (long)p * a.u_pstride + ((long)mb * KP + c * CH) * 64;
+    const float* vs = a.v + (long)p * a.v_pstride + ((long)(c * (CH / 4)) * a.Q + n0) * 8;
 #pragma unroll
-    for (int k4 = 0; k4 < CH / 4; ++k4) ra[slot][k4] = ld(up + k4 * 64);
+    for (int k4 = 0; k4 < CH / 4; ++k4) ra[slot][k4] = ld_su<float4>(us + k4 * 256, a_voff);
 #pragma unroll
-    for (int k4 = 0; k4 < CH / 4; ++k4) rb[slot][k4] = ld(vp + (long)k4 * a.Q * 2);
+    for (int k4 = 0; k4 < CH / 4; ++k4) rb[slot][k4] = ld_su<float4>(vs + (long)k4 * a.Q * 8, b_voff);
   };
 #pragma unroll
   for (int t = 0; t < R; ++t) issue(t, t);
   sched_fence();
   float s4[4][4][6];                     // A^T m partial sums of this thread's pairs (channel (tid>>5) + 8u, column tid&31)
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-      for (int j = 0; j < 6; ++j) s4[u][p][j] = 0.0f;
   const int col = tid & 31, mrow0 = tid >> 5;
   f32x16 acc;
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    if (t % NCH == 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    }
+  static_for<T>([&](auto TT) __attribute__((always_inline)) {   // every chunk index a compile-time constant
+    constexpr int t = decltype(TT)::value;
 #pragma unroll
     for (int k4 = 0; k4 < CH / 4; ++k4) {
       const float4 av = ra[t % R][k4], bv = rb[t % R][k4];
-      acc = mfma_32x32x2(av.x, bv.x, acc);
+#if defined(ECO_WFUSED_PROBE) && (ECO_WFUSED_PROBE & 2)   // bit 1 = one MFMA per chunk piece instead of four
+      acc = mfma_32x32x2(av.x + av.y + av.z + av.w, bv.x + bv.y + bv.z + bv.w, (t % NCH == 0 && k4 == 0) ? kZero16 : acc);
+#else
+      // a point's first product takes the constant 0 as its C operand: no 16 v_mov per point to clear the accumulator
+      acc = mfma_32x32x2(av.x, bv.x, (t % NCH == 0 && k4 == 0) ? kZero16 : acc);
       acc = mfma_32x32x2(av.y, bv.y, acc);
       acc = mfma_32x32x2(av.z, bv.z, acc);
       acc = mfma_32x32x2(av.w, bv.w, acc);
+#endif
     }
     sched_fence();
-    if (t + R < T) issue(t % R, t + R);
+    if constexpr (t + R < T) issue(t % R, t + R);
     sched_fence();
-    if (t % NCH == NCH - 1) {
-      const int pi = t / NCH;
+    if constexpr (t % NCH == NCH - 1) {
+      constexpr int pi = t / NCH;
       const int lp = wave + 4 * (pi % 3);
       float* mo = lds + (lp * 32 + 4 * half) * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) mo[((r & 3) + 8 * (r >> 2)) * 32] = acc[r];
-      if (pi % 3 == 2) {                 // the group's 12 products are complete: fold its two rows into s4
-        const int g = pi / 3;
+      if constexpr (pi % 3 == 2) {       // the group's 12 products are complete: fold its two rows into s4
+        constexpr int g = pi / 3;
         __syncthreads();
+        // A^T m with the rows taken in the pairs the transform factors into -- t = m1 +- m2 feeds (1, 1, 1, 1) /
+        // (1, -1, 1, -1), t = m3 +- m4 feeds (1, 2, 4, 8) / (1, -2, 4, -8) -- 10 VALU instructions per column instead
+        // of 18, and nothing to clear first
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-              const float mv = lds[(((rr * 6 + j) * 32) + mrow0 + 8 * u) * 32 + col];
-#pragma unroll
-              for (int p = 0; p < 4; ++p)
-                if (AT[p][2 * g + rr] != 0.0f) s4[u][p][j] += AT[p][2 * g + rr] * mv;
+          for (int j = 0; j < 6; ++j) {
+            const float ma = lds[((j * 32) + mrow0 + 8 * u) * 32 + col];
+            const float mb2 = lds[(((6 + j) * 32) + mrow0 + 8 * u) * 32 + col];
+            if (g == 0) {          // rows 1, 2
+              const float t1 = ma + mb2, t2 = ma - mb2;
+              s4[u][0][j] = t1; s4[u][1][j] = t2; s4[u][2][j] = t1; s4[u][3][j] = t2;
+            } else if (g == 1) {   // rows 3, 4
+              const float t3 = ma + mb2, t4 = ma - mb2;
+              s4[u][0][j] += t3; s4[u][1][j] += 2.0f * t4; s4[u][2][j] += 4.0f * t3; s4[u][3][j] += 8.0f * t4;
+            } else {               // rows 0, 5
+              s4[u][0][j] += ma; s4[u][3][j] += mb2;
             }
+          }
         if (g < 2) __syncthreads();
       }
     }
-  }
+  });
   const int tpp = a.o.TH * a.o.TW;
   const int r = n0 + col;
   if (r < a.o.NB) {
     const int img = r / tpp, tt = r - img * tpp;
     const int th = tt / a.o.TW, tw = tt - th * a.o.TW;
+    // the image / tile decode and the view bases once per thread; the four channels are 8 * stride_c apart
+    WinoViewOffsets o = wino_view_offsets(a.o, img, mb * 32 + mrow0);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int ch = mb * 32 + mrow0 + 8 * u;
-      if (ch < a.o.cout) wino_output_from_s4<VEC>(a.o, s4[u], ch, img, 0, th, tw);
+      if (ch < a.o.cout) wino_output_store<VEC>(a.o, s4[u], ch, o, 0, th, tw);
+      o.res += 8 * a.o.residual.stride_c; o.raw += 8 * a.o.raw.stride_c;
+      o.act += 8 * a.o.act.stride_c; o.act2 += 8 * a.o.act2.stride_c;
     }
   }
 }
