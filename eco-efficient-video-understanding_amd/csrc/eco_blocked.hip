@@ -30,6 +30,7 @@
 #include <float.h>
 #include <string.h>
 
+#define ECO_GLDS_READFIRSTLANE 1   // see eco_device.h, glds16
 #include "eco_common.h"
 
 namespace eco {
@@ -45,8 +46,8 @@ struct ConvBArgs {
   eco_view residual, raw, act, act2;   // blocked views: strides in 8-channel blocks
   // sibling convs as one launch (eco_conv_epilogue::nseg): 32-row tiles at or above seg_begin[s] write through
   // seg_act[s] at channel block (c - seg_begin[s]) / 8, with seg_relu[s]
-  int nseg, seg_begin[2], seg_relu[2];
-  eco_view seg_act[2];
+  int nseg, seg_begin[ECO_MAX_SEG], seg_relu[ECO_MAX_SEG];
+  eco_view seg_act[ECO_MAX_SEG];
   int relu;
   int cblocks, cout, mpad, nstages, taps;
   int Di, Hi, Wi, Do, Ho, Wo;
@@ -171,11 +172,22 @@ __device__ __forceinline__ void convb_epilogue(const ConvBArgs& a, f32x16 (&acc)
     int relu = a.relu, cb0 = 0;
     const int mt = mw + i * 32;
     if (a.nseg > 0 && mt >= a.seg_begin[0]) {
-      const int sidx = (a.nseg > 1 && mt >= a.seg_begin[1]) ? 1 : 0;
-      const eco_view& sv = a.seg_act[sidx];
-      aptr = sv.ptr; astride_c = sv.stride_c; relu = a.seg_relu[sidx]; cb0 = a.seg_begin[sidx] / 8;
+      // (constant indices only: a run-time index into the kernel argument struct makes the compiler copy it to scratch)
+      // every candidate is loaded (constant indices, scalar loads) and the VALUES are selected: a conditional load, or
+      // a run-time index, into the kernel argument struct makes the compiler copy the struct to scratch memory
+      long sstride_b = a.seg_act[0].stride_b;
+      aptr = a.seg_act[0].ptr; astride_c = a.seg_act[0].stride_c; relu = a.seg_relu[0]; cb0 = a.seg_begin[0] / 8;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) e_act[j] = (long)e_img[j] * sv.stride_b + e_sp[j];
+      for (int q = 1; q < ECO_MAX_SEG; ++q) {
+        void* const qp = a.seg_act[q].ptr;
+        const long qc = a.seg_act[q].stride_c, qb = a.seg_act[q].stride_b;
+        const int qr = a.seg_relu[q], qbeg = a.seg_begin[q];
+        const bool take = q < a.nseg && mt >= qbeg;
+        aptr = take ? qp : aptr; astride_c = take ? qc : astride_c; sstride_b = take ? qb : sstride_b;
+        relu = take ? qr : relu; cb0 = take ? qbeg / 8 : cb0;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) e_act[j] = (long)e_img[j] * sstride_b + e_sp[j];
     }   // (tiles ascend: once past seg_begin[0] a wave never returns to `act`)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -266,8 +278,16 @@ __global__ __launch_bounds__(256) void convb_splitk_reduce_kernel(const ConvBArg
         eco_view av = a.act;       // sibling launches: the channel block's own destination
         int relu = a.relu, cb0 = 0;
         if (a.nseg > 0 && cbk * 8 >= a.seg_begin[0]) {
-          const int sidx = (a.nseg > 1 && cbk * 8 >= a.seg_begin[1]) ? 1 : 0;
-          av = a.seg_act[sidx]; relu = a.seg_relu[sidx]; cb0 = a.seg_begin[sidx] / 8;
+          av = a.seg_act[0]; relu = a.seg_relu[0]; cb0 = a.seg_begin[0] / 8;
+#pragma unroll
+          for (int sq = 1; sq < ECO_MAX_SEG; ++sq) {
+            const eco_view qv = a.seg_act[sq];
+            const int qr = a.seg_relu[sq], qbeg = a.seg_begin[sq];
+            const bool take = sq < a.nseg && cbk * 8 >= qbeg;
+            av.ptr = take ? qv.ptr : av.ptr; av.stride_b = take ? qv.stride_b : av.stride_b;
+            av.stride_c = take ? qv.stride_c : av.stride_c; av.stride_t = take ? qv.stride_t : av.stride_t;
+            av.t = take ? qv.t : av.t; relu = take ? qr : relu; cb0 = take ? qbeg / 8 : cb0;
+          }
         }
         float y[4];
 #pragma unroll
@@ -1238,7 +1258,7 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
   ECO_REQUIRE(!ep->bn_scale == !ep->bn_shift, "convb: bn_scale and bn_shift must be given together");
   ECO_REQUIRE(!ep->act2.ptr || ep->act.ptr, "convb: act2 needs act");
   if (ep->nseg) {
-    ECO_REQUIRE(ep->nseg >= 1 && ep->nseg <= 2, "convb: 1 or 2 extra output segments (got %d)", ep->nseg);
+    ECO_REQUIRE(ep->nseg >= 1 && ep->nseg <= ECO_MAX_SEG, "convb: 1 to %d extra output segments (got %d)", ECO_MAX_SEG, ep->nseg);
     ECO_REQUIRE(ep->act.ptr && ep->act.t == 1 && !ep->raw.ptr && !ep->residual.ptr && !ep->act2.ptr,
                 "convb: a segmented launch takes plain act destinations only (no raw / residual / act2)");
     int prev = 0;
@@ -1259,7 +1279,7 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
   a.bias = ep->bias; a.bn_scale = ep->bn_scale; a.bn_shift = ep->bn_shift;
   a.residual = ep->residual; a.raw = ep->raw; a.act = ep->act; a.act2 = ep->act2; a.relu = ep->relu;
   a.nseg = ep->nseg;
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < ECO_MAX_SEG; ++s) {
     a.seg_begin[s] = s < ep->nseg ? ep->seg_begin[s] : 0;
     a.seg_relu[s] = s < ep->nseg ? ep->seg_relu[s] : 0;
     a.seg_act[s] = s < ep->nseg ? ep->seg_act[s] : eco_view{nullptr, 0, 0, 0, 1};

@@ -42,8 +42,8 @@ struct ConvKernelArgs {
   eco_view residual, raw, act, act2;
   // sibling convs run as one (eco_conv_epilogue::nseg): 32-row tiles at or above seg_begin[s] write through
   // seg_act[s], whose ptr the host moved back by seg_begin[s] channels so that the global channel indexes it
-  int nseg, seg_begin[2], seg_relu[2];
-  eco_view seg_act[2];
+  int nseg, seg_begin[ECO_MAX_SEG], seg_relu[ECO_MAX_SEG];
+  eco_view seg_act[ECO_MAX_SEG];
   int relu;
   int cin, cout, mpad, kpad;
   int Di, Hi, Wi, Do, Ho, Wo;
@@ -171,11 +171,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&
     int relu = a.relu;
     const int mt = mw + i * 32;
     if (a.nseg > 0 && mt >= a.seg_begin[0]) {
-      const int sidx = (a.nseg > 1 && mt >= a.seg_begin[1]) ? 1 : 0;
-      const eco_view& sv = a.seg_act[sidx];
-      aptr = sv.ptr; astride_c = sv.stride_c; relu = a.seg_relu[sidx];
+      // (constant indices only: a run-time index into the kernel argument struct makes the compiler copy it to scratch)
+      // every candidate is loaded (constant indices, scalar loads) and the VALUES are selected: a conditional load, or
+      // a run-time index, into the kernel argument struct makes the compiler copy the struct to scratch memory
+      long sstride_b = a.seg_act[0].stride_b;
+      aptr = a.seg_act[0].ptr; astride_c = a.seg_act[0].stride_c; relu = a.seg_relu[0];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) e_act[j] = (long)e_img[j] * sv.stride_b + e_sp[j];
+      for (int q = 1; q < ECO_MAX_SEG; ++q) {
+        float* const qp = a.seg_act[q].ptr;
+        const long qc = a.seg_act[q].stride_c, qb = a.seg_act[q].stride_b;
+        const int qr = a.seg_relu[q];
+        const bool take = q < a.nseg && mt >= a.seg_begin[q];
+        aptr = take ? qp : aptr; astride_c = take ? qc : astride_c; sstride_b = take ? qb : sstride_b; relu = take ? qr : relu;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) e_act[j] = (long)e_img[j] * sstride_b + e_sp[j];
     }   // (tiles ascend: once past seg_begin[0] a wave never returns to `act`, whose offsets e_act held so far)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -295,8 +305,16 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKerne
       eco_view av = a.act;       // sibling launches: the channel's own destination (ptr already moved back)
       int relu = a.relu;
       if (a.nseg > 0 && ch >= a.seg_begin[0]) {
-        const int sidx = (a.nseg > 1 && ch >= a.seg_begin[1]) ? 1 : 0;
-        av = a.seg_act[sidx]; relu = a.seg_relu[sidx];
+        av = a.seg_act[0]; relu = a.seg_relu[0];
+#pragma unroll
+        for (int q = 1; q < ECO_MAX_SEG; ++q) {
+          const eco_view qv = a.seg_act[q];
+          const int qr = a.seg_relu[q];
+          const bool take = q < a.nseg && ch >= a.seg_begin[q];
+          av.ptr = take ? qv.ptr : av.ptr; av.stride_b = take ? qv.stride_b : av.stride_b;
+          av.stride_c = take ? qv.stride_c : av.stride_c; av.stride_t = take ? qv.stride_t : av.stride_t;
+          av.t = take ? qv.t : av.t; relu = take ? qr : relu;
+        }
       }
       float y[VEC];
 #pragma unroll
@@ -1295,10 +1313,10 @@ static int conv_forward_impl(const eco_conv_geom* g, const eco_conv_plan* plan, 
   a.x = x; a.wp = wp; a.ktab = ktab;
   a.bias = ep->bias; a.bn_scale = ep->bn_scale; a.bn_shift = ep->bn_shift;
   a.residual = ep->residual; a.raw = ep->raw; a.act = ep->act; a.act2 = ep->act2; a.relu = ep->relu;
-  a.nseg = ep->nseg; a.seg_begin[0] = a.seg_begin[1] = 0; a.seg_relu[0] = a.seg_relu[1] = 0;
-  a.seg_act[0] = a.seg_act[1] = eco_view{nullptr, 0, 0, 0, 1};
+  a.nseg = ep->nseg;
+  for (int q = 0; q < ECO_MAX_SEG; ++q) { a.seg_begin[q] = 0; a.seg_relu[q] = 0; a.seg_act[q] = eco_view{nullptr, 0, 0, 0, 1}; }
   if (ep->nseg) {
-    ECO_REQUIRE(ep->nseg >= 1 && ep->nseg <= 2, "conv: 1 or 2 extra output segments (got %d)", ep->nseg);
+    ECO_REQUIRE(ep->nseg >= 1 && ep->nseg <= ECO_MAX_SEG, "conv: 1 to %d extra output segments (got %d)", ECO_MAX_SEG, ep->nseg);
     ECO_REQUIRE(ep->act.ptr && ep->act.t == 1 && !ep->raw.ptr && !ep->residual.ptr && !ep->act2.ptr && batch == 1,
                 "conv: a segmented launch takes plain act destinations only (no raw / residual / act2 / batch)");
     int prev = 0;
@@ -1397,7 +1415,7 @@ static int conv_forward_impl(const eco_conv_geom* g, const eco_conv_plan* plan, 
   };
   const bool vec4 = a.s_out % 4 == 0 && (!a.dmajor || (a.Ho * a.Wo) % 4 == 0) && a.n_split0 % 4 == 0 && (a.ntot - a.n_split0) % 4 == 0 &&
                     ((uintptr_t)a.ws & 15) == 0 && vec_ok(a.residual) && vec_ok(a.raw) && vec_ok(a.act) && vec_ok(a.act2) &&
-                    vec_ok(a.seg_act[0]) && vec_ok(a.seg_act[1]);
+                    vec_ok(a.seg_act[0]) && vec_ok(a.seg_act[1]) && vec_ok(a.seg_act[2]);
   long rblocks = ceil_div((long)a.cout * (a.ntot - a.n_split0), 256L * (vec4 ? 4 : 1));
   if (rblocks > 262144) rblocks = 262144;
   if (vec4)

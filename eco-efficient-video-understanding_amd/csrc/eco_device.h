@@ -82,7 +82,14 @@ __device__ __forceinline__ void glds16(const uint4* gptr, uint4* lds_wave_base) 
   if (emu::check_access(gptr, 16, false)) memcpy(&q, (const void*)gptr, 16);   // the source may be only 4-byte aligned
   lds_wave_base[emu::tls_cur->lane] = q;
 #else
+#ifdef ECO_GLDS_READFIRSTLANE
+  // Under SGPR pressure (eco_blocked.hip's kernels with their large argument structs) the register allocator has handed
+  // the "s" operand a VGPR -- spilled SGPRs live in VGPR lanes -- which the assembler rejects; a readfirstlane pins it.
+  // Opt-in per file: where the offset is not already in an SGPR it costs a VALU instruction per DMA piece.
+  const unsigned lds_off = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+#else
   const unsigned lds_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+#endif
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(gptr) : "memory", "m0");
 #endif
 }

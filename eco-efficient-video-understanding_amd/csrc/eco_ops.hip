@@ -102,21 +102,24 @@ __global__ __launch_bounds__(256) void pool2d_k3_kernel(const PoolArgs a) {
   }
 }
 
-// VEC consecutive floats as one 16- or 8-byte access.
+// VEC consecutive floats as one 16-, 8- or 4-byte access.
 template <int VEC>
 __device__ __forceinline__ void ld_vec(const float* p, float (&v)[VEC]) {
   if (VEC == 4) {
     const float4 q = ld((const float4*)p);
     v[0] = q.x; v[1 % VEC] = q.y; v[2 % VEC] = q.z; v[3 % VEC] = q.w;
-  } else {
+  } else if (VEC == 2) {
     const float2 q = ld((const float2*)p);
     v[0] = q.x; v[1 % VEC] = q.y;
+  } else {
+    v[0] = ld(p);
   }
 }
 template <int VEC>
 __device__ __forceinline__ void st_vec(float* p, const float (&v)[VEC]) {
   if (VEC == 4) st((float4*)p, make_float4(v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]));
-  else st((float2*)p, make_float2(v[0], v[1 % VEC]));
+  else if (VEC == 2) st((float2*)p, make_float2(v[0], v[1 % VEC]));
+  else st(p, v[0]);
 }
 
 // 2-D MAX 3x3 stride 2, no padding (pool1 / pool2 / the ECO-Full stride-2 pools): one thread per VEC
@@ -196,6 +199,60 @@ __global__ __launch_bounds__(256) void avgpool2d_k3s1p1_kernel(const float* x, f
 #pragma unroll
       for (int e = 0; e < VEC; ++e) sum[e] = ((0.0f + rs[o][e]) + rs[o + 1][e] + rs[o + 2][e]) * inv;
       st_vec<VEC>(y + (pl * H + oh) * W + VEC * q, sum);
+    }
+  }
+}
+
+// The same pooling followed by a per-channel affine map and ReLU, written through a strided view:
+//   y(img, ch, :) = relu(((avgpool3x3(x) + bias[ch]) * scale[ch]) + shift[ch]).
+// This is what remains of  AVE pool 3x3/1/1 -> 1x1 conv -> BN -> ReLU  (inception_3a/3b_pool + pool_proj,
+// models_ECO_Lite/kinetics/deploy.prototxt:330-400) once the two linear maps are exchanged: the 1x1 convolution is
+// applied to the block's input (as one more member of the block's sibling 1x1 launch, without its bias) and the
+// window average -- zero padding, constant divisor 9: a linear map with constant coefficients -- to its cout output
+// channels instead of to the cin input channels (192 / 256 -> 32 / 64 in ECO).  conv(avg(x)) = avg(conv(x)) exactly
+// in exact arithmetic; in fp32 the two orders differ by rounding.
+template <int VEC>
+__global__ __launch_bounds__(256) void avgpool2d_k3s1p1_affine_kernel(const float* x, const float* bias, const float* scale,
+                                                                      const float* shift, float floor_v, eco_view dst,
+                                                                      long planes, int C, int H, int W) {
+  const int wq = W / VEC;
+  const int hq = (H + kAvgRows - 1) / kAvgRows;
+  const long total = planes * hq * wq;
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+    const int q = (int)(i % wq);
+    const long t = i / wq;
+    const int oh0 = (int)(t % hq) * kAvgRows;
+    const long pl = t / hq;
+    const float* xp = x + pl * H * W + VEC * q;
+    float rs[kAvgRows + 2][VEC];  // horizontal 3-sums of input rows oh0-1 .. oh0+kAvgRows
+#pragma unroll
+    for (int r = 0; r < kAvgRows + 2; ++r) {
+      const int h = oh0 - 1 + r;
+      const bool ok = h >= 0 && h < H;
+      const float* row = xp + (ok ? (long)h * W : 0l);
+      float in[VEC + 2], mid[VEC];
+      ld_vec<VEC>(row, mid);
+      in[0] = (q > 0) ? ld(row - 1) : 0.0f;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) in[1 + e] = mid[e];
+      in[VEC + 1] = (VEC * q + VEC < W) ? ld(row + VEC) : 0.0f;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) rs[r][e] = ok ? in[e] + in[e + 1] + in[e + 2] : 0.0f;
+    }
+    const int img = (int)(pl / C), ch = (int)(pl - (long)img * C);
+    const float b = bias ? ld(bias + ch) : 0.0f;
+    const float sc = scale ? ld(scale + ch) : 1.0f, sh = scale ? ld(shift + ch) : 0.0f;
+    float* yp = dst.ptr + view_base(dst, img, 0) + (long)ch * dst.stride_c + VEC * q;
+    const float inv = 1.0f / 9.0f;
+#pragma unroll
+    for (int o = 0; o < kAvgRows; ++o) {
+      const int oh = oh0 + o;
+      if (oh >= H) break;
+      float out[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        out[e] = fmaxf((((0.0f + rs[o][e]) + rs[o + 1][e] + rs[o + 2][e]) * inv + b) * sc + sh, floor_v);
+      st_vec<VEC>(yp + (long)oh * W, out);
     }
   }
 }
@@ -545,6 +602,29 @@ extern "C" int eco_pool_forward(const eco_pool_geom* g, const float* x, float* y
   }
   hipLaunchKernelGGL((pool_kernel), dim3(grid_for(a.total)), dim3(kThreads), 0, s, a);
   return check_launch("eco_pool_forward");
+}
+
+extern "C" int eco_avgpool_affine_forward(const float* x, const float* bias, const float* bn_scale, const float* bn_shift,
+                                          int32_t relu, const eco_view* dst, int32_t n, int32_t c, int32_t h, int32_t w,
+                                          void* stream) {
+  clear_error();
+  ECO_REQUIRE(x && dst && dst->ptr && n > 0 && c > 0 && h > 0 && w > 0, "avgpool_affine: bad argument");
+  ECO_REQUIRE(!bn_scale == !bn_shift, "avgpool_affine: bn_scale and bn_shift must be given together");
+  ECO_REQUIRE(dst->t >= 1 && dst->stride_c >= 1, "avgpool_affine: view needs t >= 1 and stride_c >= 1");
+  int vec = 4;
+  while (vec > 1 && (w % vec || ((uintptr_t)x % (4 * vec)) || ((uintptr_t)dst->ptr % (4 * vec)) || dst->stride_b % vec ||
+                     dst->stride_t % vec || dst->stride_c % vec))
+    vec /= 2;
+  const long planes = (long)n * c;
+  const long hq = (h + kAvgRows - 1) / kAvgRows;
+  const long total = planes * hq * (w / vec);
+  const float floor_v = relu ? 0.0f : -FLT_MAX;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(grid_for(total)), block(kThreads);
+  if (vec == 4) hipLaunchKernelGGL((avgpool2d_k3s1p1_affine_kernel<4>), grid, block, 0, s, x, bias, bn_scale, bn_shift, floor_v, *dst, planes, c, h, w);
+  else if (vec == 2) hipLaunchKernelGGL((avgpool2d_k3s1p1_affine_kernel<2>), grid, block, 0, s, x, bias, bn_scale, bn_shift, floor_v, *dst, planes, c, h, w);
+  else hipLaunchKernelGGL((avgpool2d_k3s1p1_affine_kernel<1>), grid, block, 0, s, x, bias, bn_scale, bn_shift, floor_v, *dst, planes, c, h, w);
+  return check_launch("eco_avgpool_affine_forward");
 }
 
 extern "C" int eco_bn_forward(const float* x, float* y, const float* scale, const float* shift, int64_t n, int64_t c,

@@ -143,6 +143,11 @@ class Engine:
         self.wgemm = True          # F(4x4,3x3) GEMMs on the dedicated dense kernel (False: round-1 gather-kernel route)
         self.stem = True           # conv1 + BN + ReLU + pool1 as one launch (False: conv kernel + pooling kernel)
         self.siblings = True       # 1x1 convs reading the same bottom as one launch (fp32 path)
+        # AVE pool 3x3/1/1 -> 1x1 conv (inception_3a/3b pool + pool_proj): both maps are linear, so the conv runs first
+        # -- on the block's input, as one more member of the block's sibling launch -- and the window average (+ bias,
+        # BN, ReLU) on its cout output channels instead of on the cin input channels (csrc/eco_ops.hip,
+        # avgpool2d_k3s1p1_affine_kernel).  fp32 path; logits differ from the reference order by fp32 rounding.
+        self.pool_commute = True
         # ... and a residual block's strided first conv with its projection shortcut (res4a_1 | res4a_down).  Off:
         # measured at 32 clips the 512-channel launch quantises worse over the CUs than the two 256-channel ones
         # (1.73-1.89 ms against 2 x 0.80 ms; res5a: 0.80 against 0.85), see profiles/r02_notes.md
@@ -701,13 +706,13 @@ class Engine:
                   {"kernel": hip.convb_kernel_name(bp), "flops": 2 * n_out * k,
                    "bytes": es * _prod(L.bottom_shapes[0]) + 2 * k * L.geom["cout"] + es * n_out * outs})
 
-    def _emit_conv(self, i: int, L: LayerSpec, ep: "hip.ConvEpilogue", label: str) -> None:
+    def _emit_conv(self, i: int, L: LayerSpec, ep: "hip.ConvEpilogue", label: str, src: Optional[str] = None) -> None:
         if self.dt:
             self._emit_blocked_conv(i, L, ep, label)
             return
         st = self._param_dev[L.name]
         g, plan = st["geom"], st["plan"]
-        x = self._ptr(L.bottoms[0])
+        x = self._ptr(src if src is not None else L.bottoms[0])   # (src: a conv that runs ahead of its AVE pool)
         wp, kt = self.alloc.ptr(st["wp"]), self.alloc.ptr(st["ktab"])
         self._keep.append((g, plan, ep))
         lib = self.lib
@@ -806,10 +811,33 @@ class Engine:
 
         absorbed: Dict[int, str] = {}       # layer idx -> label of the group that runs it
         concat_skip: Dict[int, List[int]] = {}
-        # act-destination overrides decided per conv: blob name -> (dest blob, View factory)
+        # AVE pool 3x3/1/1 whose only consumer is a 1x1 conv seen only through BN + ReLU: conv idx -> (pool idx, source)
+        self._commute: Dict[int, Tuple[int, str]] = {}
+        self._commute_pools: Dict[int, int] = {}
+        if self.pool_commute and self.siblings and not self.dt:
+            for pi, P in enumerate(layers):
+                if P.type != "Pooling" or len(P.bottom_shapes[0]) != 4 or P.geom["method"] != "AVE" or \
+                        list(P.geom["kernel"]) != [3, 3] or list(P.geom["stride"]) != [1, 1] or list(P.geom["pad"]) != [1, 1] or \
+                        tuple(P.top_shapes[0]) != tuple(P.bottom_shapes[0]) or P.bottoms[0] in P.tops:
+                    continue
+                ci = sole_consumer(P.tops[0], "Convolution")
+                if ci is None:
+                    continue
+                Cv = layers[ci]
+                g = Cv.geom
+                if not (all(k == 1 for k in g["kernel"]) and all(k == 1 for k in g["stride"]) and not any(g["pad"]) and
+                        g.get("group", 1) == 1 and g["cout"] % 32 == 0 and "wino" not in self._param_dev[Cv.name]):
+                    continue
+                # the conv's value must exist only inside its fused BN + ReLU (no Eltwise, no second reader, not an output)
+                if sole_consumer(Cv.tops[0], "BN") is None or bn_relu_after(Cv.tops[0]) is None:
+                    continue
+                self._commute[ci] = (pi, self._resolve(P.bottoms[0]))
+                self._commute_pools[pi] = ci
         for i, L in enumerate(layers):
             if i in absorbed:
                 continue
+            if L.type == "Pooling" and i in self._commute_pools:
+                continue                     # runs behind its 1x1 conv (emitted with the conv, below)
             if L.type == "Convolution":
                 if not self._try_fuse_siblings(i, L, layers, consumers, outputs, sole_consumer, bn_relu_after,
                                                absorbed, concat_skip):
@@ -920,23 +948,26 @@ class Engine:
             return all(list(Lc.geom[k]) == list(L.geom[k]) for k in ("kernel", "stride", "pad")) and \
                 Lc.geom["cin"] == L.geom["cin"] and Lc.bottom_shapes[0] == L.bottom_shapes[0]
 
-        src = self._resolve(L.bottoms[0])
+        commuted = getattr(self, "_commute", {})
+        # a conv that runs ahead of its AVE pool (pool_commute) reads the pool's input
+        src = commuted[i][1] if i in commuted else self._resolve(L.bottoms[0])
         if not eligible(L):
             return False
         if not self.sibling_blocks and not all(k == 1 for k in L.geom["kernel"]):
             return False
         members = [i]
-        for j in consumers.get(src, []):
+        for j in sorted(set(consumers.get(src, [])) | {c for c, (_, sb) in commuted.items() if sb == src}):
             Lj = layers[j]
-            if j <= i or j in absorbed or Lj.type != "Convolution" or len(members) == 3:
+            if j <= i or j in absorbed or Lj.type != "Convolution" or len(members) == hip.MAX_SEG + 1:
                 continue
             if eligible(Lj) and same(Lj) and \
                     not any(layers[k].inplace and self._resolve(layers[k].bottoms[0]) == src for k in range(i, j)):
                 members.append(j)
-        if len(members) < 2:
+        if len(members) < 2 and i not in commuted:
             return False
         # every member is emitted at this position (its only input is the shared bottom): decide its epilogue now
         found = []
+        after = []                                        # pool launches that follow the conv launch (pool_commute)
         for j in members:
             Lj = layers[j]
             br = bn_relu_after(Lj.tops[0])
@@ -947,19 +978,44 @@ class Engine:
             if ep is None:
                 continue                                  # (emitted by _conv_epilogue itself)
             plain = not ep.residual.ptr and not ep.act2.ptr
-            if plain and ep.act.ptr and ep.act.t == 1 and not ep.raw.ptr and br is not None:
-                found.append((Lj, ep, label, ep.act, int(ep.relu), layers[br[0]].name))
+            if j in commuted:
+                # conv first, on the pool's input and without its bias, raw into a scratch tensor; the window average,
+                # bias, BN and ReLU follow on the conv's channels and write the destination the epilogue chose
+                pi = commuted[j][0]
+                Pj = layers[pi]
+                absorbed[pi] = L.name
+                z = Lj.name + "/before_" + Pj.name
+                self._materialize(z, Lj.top_shapes[0])
+                self.fused_away[Pj.tops[0]] = f"{Pj.name} runs behind {Lj.name} (linear maps exchanged) on {z}"
+                n_, c_, h_, w_ = Lj.top_shapes[0]
+                zv = self._view(z, c_, h_ * w_)
+                after.append((self._ptr(z), ep, f"{Pj.name}+{label} [average, bias, BN, ReLU]", (n_, c_, h_, w_)))
+                ep2 = hip.ConvEpilogue()
+                ep2.bias = None
+                ep2.residual, ep2.act, ep2.act2 = hip.null_view(), hip.null_view(), hip.null_view()
+                ep2.bn_scale = ep2.bn_shift = None
+                ep2.relu = 0
+                ep2.raw = zv
+                found.append((Lj, ep2, f"{Lj.name} [ahead of {Pj.name}]", zv, 0, None, True))
+            elif plain and ep.act.ptr and ep.act.t == 1 and not ep.raw.ptr and br is not None:
+                found.append((Lj, ep, label, ep.act, int(ep.relu), layers[br[0]].name, False))
             elif plain and ep.raw.ptr and ep.raw.t == 1 and not ep.act.ptr:
-                found.append((Lj, ep, label, ep.raw, 0, None))
+                found.append((Lj, ep, label, ep.raw, 0, None, False))
             else:                                         # a destination the segmented epilogue cannot express
                 self._emit_conv(i, Lj, ep, label)
         if len(found) == 1:
-            self._emit_conv(i, found[0][0], found[0][1], found[0][2])
+            self._emit_conv(i, found[0][0], found[0][1], found[0][2], src=src)
         elif found:
-            self._emit_sibling_conv(i, found)
+            self._emit_sibling_conv(i, found, src)
+        lib = self.lib
+        for zp, ep, label, (n_, c_, h_, w_) in after:
+            self._keep.append(ep)
+            self._add(i, label, lambda s, zp=zp, ep=ep, n_=n_, c_=c_, h_=h_, w_=w_: lib.avgpool_affine_forward(
+                zp, ep.bias, ep.bn_scale, ep.bn_shift, ep.relu, ep.act, n_, c_, h_, w_, s),
+                {"kernel": "eco::avgpool2d_k3s1p1_affine_kernel", "flops": 0, "bytes": 8 * n_ * c_ * h_ * w_})
         return True
 
-    def _emit_sibling_conv(self, i, found) -> None:
+    def _emit_sibling_conv(self, i, found, src=None) -> None:
         Ls = [f[0] for f in found]
         L = Ls[0]
         key = "|".join(Lc.name for Lc in Ls)
@@ -987,7 +1043,8 @@ class Engine:
             self._keep.append(getattr(self, "_ws", None))   # launches recorded so far hold the old buffer's address
             self._ws = self.alloc.empty((plan.ws_bytes + 3) // 4, np.float32)
             self._ws_bytes = plan.ws_bytes
-        self._groups[key] = {"convs": [Lc.name for Lc in Ls], "bns": [f[5] for f in found], "st": st}
+        self._groups[key] = {"convs": [Lc.name for Lc in Ls], "bns": [f[5] for f in found], "st": st,
+                             "nobias": [f[6] for f in found]}
         self._dirty_groups.add(key)
         ep = hip.ConvEpilogue()
         ep.bias = self.alloc.ptr(st["bias"])
@@ -1001,7 +1058,7 @@ class Engine:
             ep.seg_begin[s - 1] = begin
             ep.seg_relu[s - 1] = found[s][4]
             ep.seg_act[s - 1] = found[s][3]
-        x = self._ptr(L.bottoms[0])
+        x = self._ptr(src if src is not None else L.bottoms[0])
         wp = self.alloc.ptr(st["wp"])
         self._keep.append((geom, plan, ep))
         lib = self.lib
@@ -1044,10 +1101,11 @@ class Engine:
                 self.alloc.upload(st["wp"], wp)
                 self.alloc.upload(st["ktab"], kt)
             bias, scale, shift = [], [], []
-            for n, bn in zip(grp["convs"], grp["bns"]):
+            for n, bn, nobias in zip(grp["convs"], grp["bns"], grp["nobias"]):
                 Lc = self.spec.layer(n)
                 c = Lc.geom["cout"]
-                bias.append(np.asarray(self.params[n][1], np.float32).ravel() if Lc.geom["bias_term"]
+                # (a conv that runs ahead of its AVE pool adds its bias behind the pool)
+                bias.append(np.asarray(self.params[n][1], np.float32).ravel() if Lc.geom["bias_term"] and not nobias
                             else np.zeros(c, np.float32))
                 if bn is None:                        # the member keeps its raw value
                     scale.append(np.ones(c, np.float32))

@@ -21,7 +21,8 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 14
+ABI_VERSION = 15
+MAX_SEG = 3   # ECO_MAX_SEG: extra output segments of a sibling launch
 DT_BF16 = 1
 DT_F32X3 = 3
 
@@ -72,8 +73,8 @@ class ConvEpilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("residual", View), ("raw", View),
                 ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p),
                 ("relu", C.c_int32), ("act", View), ("act2", View),
-                ("nseg", C.c_int32), ("seg_begin", C.c_int32 * 2), ("seg_relu", C.c_int32 * 2),
-                ("seg_act", View * 2)]
+                ("nseg", C.c_int32), ("seg_begin", C.c_int32 * MAX_SEG), ("seg_relu", C.c_int32 * MAX_SEG),
+                ("seg_act", View * MAX_SEG)]
 
 
 class PoolGeom(C.Structure):
@@ -196,6 +197,8 @@ _SIGNATURES = {
     "eco_global_avgpool_fc_seg_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                                     C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
                                                     C.c_void_p]),
+    "eco_avgpool_affine_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(View),
+                                             C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "eco_video_input_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_float, C.c_int32, C.c_void_p]),
     "eco_softmax_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
@@ -407,6 +410,11 @@ class EcoLib:
     def global_avgpool_fc_seg_forward(self, x, w, bias, y, b, t, c, s, n_out, wk, c0=0, accumulate=False, stream=None) -> None:
         self._check(self._dll.eco_global_avgpool_fc_seg_forward(x, w, bias, y, b, t, c, s, n_out, wk, c0,
                                                                 int(accumulate), stream))
+
+    def avgpool_affine_forward(self, x, bias, bn_scale, bn_shift, relu, dst: "View", n, c, h, w, stream=None) -> None:
+        """AVE 3x3 stride 1 pad 1 of x[n,c,h,w], then (+ bias) * bn_scale + bn_shift, ReLU, into the strided view."""
+        self._check(self._dll.eco_avgpool_affine_forward(x, bias, bn_scale, bn_shift, int(relu), C.byref(dst), n, c, h, w,
+                                                         stream))
 
     def video_input_forward(self, frames, y, num_frames, height, width, crop_h, crop_w, h_off, w_off, mean, scale=1.0,
                             mirror=False, stream=None) -> None:

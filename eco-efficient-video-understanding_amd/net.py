@@ -151,7 +151,7 @@ class _LayerView:
 class Net:
     def __init__(self, model, weights=None, phase=TEST, *, fuse: bool = True, winograd: bool = True,
                  dtype: str = "f32", device: Optional[int] = None,
-                 params: Optional[Dict[str, List[np.ndarray]]] = None, seed: int = 0,
+                 params: Optional[Dict[str, List[np.ndarray]]] = None, seed: int = 0, pool_commute: bool = True,
                  _backend=None, _num_cu: Optional[int] = None) -> None:
         # pycaffe accepts Net(model, phase) and Net(model, weights, phase)
         if isinstance(weights, int) and not isinstance(weights, bool):
@@ -177,7 +177,10 @@ class Net:
         # bf16 MFMA with fp32 accumulation (BASELINE configs[4]); "f32x3" = fp32 storage, operands split exactly
         # into three bf16 terms on the bf16 matrix cores.  The last two keep activations channel-blocked internally;
         # .data still hands out N,C,... fp32 arrays.
+        # pool_commute=False keeps AVE pool -> 1x1 conv in the reference's order (default: conv first, on the block's
+        # input inside the sibling launch; the average then runs on the conv's channels -- engine.pool_commute)
         self._engine = Engine(self._spec, lib, alloc, fuse=fuse, winograd=winograd, num_cu=_num_cu, dtype=dtype)
+        self._engine.pool_commute = bool(pool_commute)
         self._pending_input_shapes: Dict[str, tuple] = {}
         self._engine.set_params(params if params is not None else fillers.filler_params(self._spec, seed))
         self._engine.build()

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 14
+#define ECO_ABI_VERSION 15
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -128,11 +128,12 @@ typedef struct eco_view {
  * double_3x3_reduce convs of an Inception block (models_ECO_Lite/kinetics/deploy.prototxt:130-330), a residual
  * block's first conv and its projection shortcut (res4a_1 / res4a_down, res5a_1 / res5a_down) -- can run as ONE
  * conv whose weights, bias and folded BN vectors are the members' concatenated along the output channel:
- * nseg = members - 1 (0 = plain).  Channels [0, seg_begin[0]) go to `act` with `relu` as usual; channels
+ * nseg = members - 1 (0 = plain, at most ECO_MAX_SEG).  Channels [0, seg_begin[0]) go to `act` with `relu` as usual; channels
  * [seg_begin[s], seg_begin[s+1] or cout) go to seg_act[s] at channel (c - seg_begin[s]) with seg_relu[s].  A member
  * that wants its raw value gets scale 1 / shift 0 / no ReLU.  Boundaries are multiples of 32; segmented launches
  * take act-style destinations only (no residual / raw / act2), plain views (t = 1), the direct kernels
  * (eco_conv_forward, eco_convb_forward; the Winograd output transforms refuse them). */
+#define ECO_MAX_SEG 3   /* extra output segments of a sibling launch: up to four member convolutions */
 typedef struct eco_conv_epilogue {
   const float* bias;
   eco_view residual; /* read-only */
@@ -143,9 +144,9 @@ typedef struct eco_conv_epilogue {
   eco_view act;
   eco_view act2;
   int32_t nseg;
-  int32_t seg_begin[2];
-  int32_t seg_relu[2];
-  eco_view seg_act[2];
+  int32_t seg_begin[ECO_MAX_SEG];
+  int32_t seg_relu[ECO_MAX_SEG];
+  eco_view seg_act[ECO_MAX_SEG];
 } eco_conv_epilogue;
 
 /* Validates `g` (fills nothing) and chooses the tiling for the calling thread's current device (its
@@ -211,6 +212,16 @@ typedef struct eco_pool_geom {
   int32_t method; /* ECO_POOL_MAX | ECO_POOL_AVE */
 } eco_pool_geom;
 int eco_pool_forward(const eco_pool_geom* g, const float* x, float* y, void* stream);
+
+/* AVE pooling 3x3 / stride 1 / pad 1 (divisor 9 everywhere: pooling_layer.cpp:247-262) of x[n,c,h,w], followed by
+ * y = relu ? max(a, 0) : a with a = (avg + bias[c]) * bn_scale[c] + bn_shift[c], written through the strided view
+ * `dst` (e.g. a channel slice of a Concat top).  bias / bn_scale+bn_shift may be NULL.  With the 1x1 convolution that
+ * follows such a pool in an Inception block applied to the pool's INPUT instead (both maps are linear and the pool's
+ * coefficients constant, so they commute), this kernel finishes  pool -> conv -> BN -> ReLU
+ * (models_ECO_Lite/kinetics/deploy.prototxt:330-400; pooling_layer.cpp, conv_layer.cpp:28-43, bn_layer.cpp:93-207)
+ * on cout instead of cin channels. */
+int eco_avgpool_affine_forward(const float* x, const float* bias, const float* bn_scale, const float* bn_shift,
+                               int32_t relu, const eco_view* dst, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
 
 /* BNLayer TEST/frozen forward with folded statistics (+ optional in-place ReLU):
  * y = x*scale[c] + shift[c]; relu -> max(y,0).  x,y: [n,c,inner]; y may alias x.
