@@ -59,6 +59,9 @@ def main() -> None:
                     help="replay the step as one hipGraph (launch-bound small batches: --clips-per-gpu 1 online latency)")
     ap.add_argument("--cpu-clips", type=int, default=0, help="clips per CPU-baseline variant (0 = auto, bounded by time)")
     ap.add_argument("--profile-iters", type=int, default=3)
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the configs[3] / configs[4] legs a default single-GPU run appends as `extra_configs`")
+    ap.add_argument("--extra-steps", type=int, default=10)
     args = ap.parse_args()
 
     import numpy as np
@@ -72,6 +75,19 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    # N processes share the host: give every local rank its own slice of the cores (Python launch loop, BLAS / OpenMP
+    # pools of torch) so that eight ranks do not oversubscribe each other
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world > 1:
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            per = max(1, len(cores) // max(local_world, 1))
+            mine = cores[(local_rank % local_world) * per:(local_rank % local_world + 1) * per] or cores
+            os.sched_setaffinity(0, mine)
+            torch.set_num_threads(max(1, min(len(mine), 16)))
+        except (AttributeError, OSError):
+            pass
 
     import eco_amd as caffe
     from eco_amd import models, fillers, hip
@@ -135,6 +151,7 @@ def main() -> None:
     ms_per_step = 1e3 * elapsed / args.steps
     clips_per_s = world * B * args.steps / elapsed
     ranks_seen = dist.get_world_size() if world > 1 else 1   # what the communicator itself reports
+    logits = logits.detach().clone()                          # (the extra-config legs below free the net)
 
     if rank != 0:
         dist.barrier()  # keep the communicator alive until rank 0 has finished reporting
@@ -166,15 +183,24 @@ def main() -> None:
                     "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
     # HBM traffic of that kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate passes, gfx950 FETCH half-count corrected; tools/summarize_profiles.py) -- bench.py cannot run
-    # the profiler on itself, so this is the figure of the last profiled build, or null.
+    # the profiler on itself, so this is the figure of the last profiled build: reported only when that build is
+    # the library running now (sha256 of libeco_hip.so recorded next to the counters), else null with the reason.
+    roofline["traffic"] = None
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")) as f:
             tr = json.load(f)
+        lib_sha = _sha256(hip.LIB_PATH)
         cand = [v for k, v in tr["kernels"].items() if k == dom_name or k.startswith(dom_name + "<")]
-        roofline["traffic"] = round(sum(c["hbm_bytes_per_launch"] for c in cand) / len(cand) / 1e9, 4)
-        roofline["traffic_unit"] = "GB per launch (PMC, " + tr["source"] + ")"
-    except Exception:
-        roofline["traffic"] = None
+        if tr.get("lib_sha256") != lib_sha:
+            roofline["traffic_unit"] = ("null: profiles/hbm_traffic_latest.json was collected on another build of libeco_hip.so "
+                                        f"({str(tr.get('lib_sha256'))[:12]} != {lib_sha[:12]}); re-run tools/profile_round.sh")
+        elif cand:
+            roofline["traffic"] = round(sum(c["hbm_bytes_per_launch"] for c in cand) / len(cand) / 1e9, 4)
+            roofline["traffic_unit"] = "GB per launch (PMC, " + tr["source"] + ", same libeco_hip.so)"
+        else:
+            roofline["traffic_unit"] = f"null: no PMC row for {dom_name} in {tr['source']}"
+    except Exception as e:  # no summary committed, unreadable file, ...
+        roofline["traffic_unit"] = f"null: {type(e).__name__}: {e}"
     executed = sum(p["flops"] for p in prof)
     roofline.update({
         "kernel": dom_name, "launches_per_step": dom["launches"],
@@ -203,11 +229,37 @@ def main() -> None:
                        for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])},
     })
 
+    # ---- the other single-GPU BASELINE configurations, in front of the driver: configs[3] (ECO-Full) and configs[4]
+    # (ECO-Lite N=32 bf16) for --extra-steps steps each, after the configs[1] timed region and before the CPU leg ----
+    extra = None
+    is_headline = (world == 1 and args.variant == "lite" and N == 16 and B == 32 and args.dtype == "f32" and
+                   not args.graph and not args.no_winograd)
+    if is_headline and not args.no_extra_configs:
+        del net
+        torch.cuda.empty_cache()
+        extra = {}
+        for key, kw in (("configs3", dict(variant="full", N=16, dtype="f32")),
+                        ("configs4", dict(variant="lite", N=32, dtype="bf16"))):
+            try:
+                extra[key] = extra_config(kw["variant"], kw["N"], B, kw["dtype"], args.extra_steps, dev)
+            except Exception as e:  # the headline line must survive a failing side leg
+                extra[key] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+
     # ---- CPU baseline: the reference's cost structure on this box's host cores ----
     cpu = None
     parity = None
     if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
         cpu, parity = cpu_baseline(args, gen, N, frames, params, logits)
+    elif world > 1:
+        # an N > 1 line still carries a parity field: rank 0's first clip against the CPU reference (the CPU baseline
+        # itself is reported at N = 1 only)
+        try:
+            ref = reference_logits(gen, N, frames, params, clips=1, blas_threads=False)
+            parity = parity_record(gathered[:1].detach().float().cpu().numpy(), ref, args.dtype,
+                                   "rank 0's first clip, read back from the all-gathered logits")
+        except Exception as e:
+            parity = {"error": f"{type(e).__name__}: {e}"}
 
     cfg = baseline_config(args.variant, N, B, args.dtype, world)
     name = "Lite" if args.variant == "lite" else "Full"
@@ -228,6 +280,8 @@ def main() -> None:
                    "device": f"cuda:{dev_index} {dev_info['name']}, {dev_info['num_cu']} CUs"},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
     }
+    if extra is not None:
+        line["extra_configs"] = extra
     print(json.dumps(line))
     sys.stdout.flush()
     if world > 1:
@@ -238,6 +292,92 @@ def main() -> None:
         # contract is ONE json line: leave without running library destructors
         sys.stderr.flush()
         os._exit(0)
+
+
+def _sha256(path: str) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def reference_logits(gen, N, frames, params, clips: int = 1, blas_threads: bool = True):
+    """fp32 CPU reference logits of the first `clips` clips of `frames`: the oracle's layer sequence with the
+    reference's own compiled im2col + OpenBLAS sgemm where oracle/_ref is present (checker only)."""
+    import numpy as np
+    from eco_amd.netspec import NetSpec
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import eco_oracle  # checker only; never on the product path
+    import eco_ref
+    spec1 = NetSpec.from_prototxt(gen(num_segments=N, num_clips=1))
+    conv = None
+    if eco_ref.available():
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count()
+        if blas_threads:   # (N > 1: torch.distributed.run exports OMP_NUM_THREADS=1 and OpenBLAS sizes its buffers by it
+            eco_ref.set_blas_threads(min(cores, 64))   # when it loads; raising the count afterwards crashed it -- one clip
+        conv = lambda *a: eco_ref.convolution(*a, image_threads=1)   # on one thread takes a few seconds)
+    outs = [eco_oracle.forward(spec1, params, {"data": frames[c * N:(c + 1) * N]}, conv_impl=conv)[spec1.outputs[0]]
+            for c in range(clips)]
+    return np.concatenate(outs, 0)
+
+
+def parity_record(got, ref, dtype: str, what: str) -> dict:
+    import numpy as np
+    denom = float(np.abs(ref).max())
+    per_class = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3 * denom)
+    return {"clips_checked": int(ref.shape[0]), "max_rel_err": float(np.abs(got - ref).max() / denom),
+            "max_per_logit_rel_err": float(per_class.max()), "max_abs_logit": denom,
+            "top1_agree": bool((got.argmax(1) == ref.argmax(1)).all()), "reference": what,
+            "tolerance": 3e-2 if dtype == "bf16" else 1e-3}
+
+
+def extra_config(variant: str, N: int, B: int, dtype: str, steps: int, dev) -> dict:
+    """One of the other single-GPU BASELINE.json configurations on the same device: `steps` timed steps between
+    device synchronisations, the per-launch floors of Engine.profile, and one clip against the CPU reference."""
+    import torch
+    import eco_amd as caffe
+    from eco_amd import fillers, models
+    from eco_amd.netspec import NetSpec
+    gen = models.eco_lite_deploy if variant == "lite" else models.eco_full_deploy
+    proto = gen(num_segments=N, num_clips=B)
+    spec = NetSpec.from_prototxt(proto)
+    params = fillers.synthetic_params(spec)
+    kw = {} if dtype == "f32" else {"dtype": dtype}
+    net = caffe.Net(proto, caffe.TEST, params=params, **kw)
+    frames = fillers.synthetic_frames(B * N, seed=1234)
+    net.set_input_device("data", torch.from_numpy(frames).to(dev))
+    for _ in range(3):
+        net.forward_device()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        net.forward_device()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    peak = PEAK_MFMA_TFLOPS[dtype]
+    prof = net._engine.profile(2)
+    floor_ms = sum(1e3 * max(p["flops"] / (peak * 1e12), p["bytes"] / (PEAK_HBM_GBS * 1e9)) for p in prof)
+    executed = sum(p["flops"] for p in prof)
+    fam = {}
+    for p in prof:
+        fam[p["kernel"]] = fam.get(p["kernel"], 0.0) + p["ms"]
+    dom = max(fam.items(), key=lambda kv: kv[1])
+    got = net.blobs[spec.outputs[0]].tensor[:1].detach().float().cpu().numpy()
+    ref = reference_logits(gen, N, frames, params, clips=1)
+    name = "Lite" if variant == "lite" else "Full"
+    out = {"workload": "ECO-%s num_segments=%d batch=%d %s (%s)" % (name, N, B, dtype, baseline_config(variant, N, B, dtype, 1)),
+           "steps": steps, "ms_per_step": round(ms, 3), "clips_per_s": round(B * 1e3 / ms, 1), "dtype": dtype,
+           "launches_per_step": len(prof), "step_frac": round(floor_ms / ms, 4),
+           "executed_frac_of_mfma_peak": round(executed / (ms * 1e-3) / 1e12 / peak, 4),
+           "largest_kernel": {"name": dom[0], "ms_per_step": round(dom[1], 3)},
+           "parity": parity_record(got, ref, dtype, "the oracle over the compiled reference im2col + OpenBLAS sgemm, clip 0")}
+    del net
+    return out
 
 
 def cpu_baseline(args, gen, N, frames, params, logits):

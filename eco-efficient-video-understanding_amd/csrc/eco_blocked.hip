@@ -35,6 +35,20 @@
 
 namespace eco {
 
+#ifndef ECO_EMU
+__device__ __attribute__((aligned(256))) const uint4 g_zero_page[16] = {};
+#endif
+// The all-zero DMA source (see device_zero_page below): the device symbol, or the page the emulator build passes in.
+__device__ __forceinline__ const uint4* zero_page_ptr(const uint4* host_given) {
+#ifdef ECO_EMU
+  return host_given;
+#else
+  (void)host_given;
+  return g_zero_page;
+#endif
+}
+
+
 constexpr int kCbs = 4;   // channel blocks (of 8) per reduction stage: 32 reduction elements, two MFMA k-steps
 
 struct ConvBArgs {
@@ -547,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void convb_dma_kernel(const ConvBArgs a, co
   }
   const uint4* const xv = (const uint4*)a.x;
   // out-of-image taps read the zero page: one integer select per piece (no divergent second instruction)
-  const long zoff = (long)(((intptr_t)zero_page - (intptr_t)xv) / 16);
+  const long zoff = (long)(((intptr_t)zero_page_ptr(zero_page) - (intptr_t)xv) / 16);
 
   // the stage whose DMA is issued next: uniform (cg, tap) walk
   int l_cg = s_begin / a.taps, l_tap = s_begin - l_cg * a.taps;
@@ -691,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
     }
   }
   const uint4* const xv = (const uint4*)a.x;
-  const long zoff = (long)(((intptr_t)zero_page - (intptr_t)xv) / 16);
+  const long zoff = (long)(((intptr_t)zero_page_ptr(zero_page) - (intptr_t)xv) / 16);
 
   // ---- in-plane tap masks of this lane's TN fragment positions: bit y*3 + x ----
   unsigned fmask[TN];
@@ -1069,7 +1083,7 @@ extern "C" int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t
   clear_error();
   if (int rc = validate_convb_geom(g, dt)) return rc;
   ECO_REQUIRE(plan != nullptr && num_cu >= 0, "convb: bad argument");
-  if (num_cu == 0) num_cu = 256;
+  if (num_cu == 0) num_cu = current_device_num_cu();   // as eco_conv_plan_create does
   const int ns = ns_of(dt);
   int bm;
   if (g->cout <= 32) bm = 32;
@@ -1171,23 +1185,18 @@ extern "C" int eco_convb_pack_weights(const eco_conv_geom* g, const eco_convb_pl
   return ECO_OK;
 }
 
-// 16 bytes of zeros in device memory: the DMA source of out-of-image taps (one per device, never freed).
+// 16 bytes of zeros in device memory, the DMA source of out-of-image taps: a zero-initialised __device__ variable of
+// this code object (eco::g_zero_page) -- present on every device the library is loaded on, no allocation, no memset, no
+// synchronisation at launch time (round 2 allocated a page per thread and device inside eco_convb_forward, which broke
+// the header's "entry points never allocate or synchronise" contract and could not run under stream capture).  The
+// emulator build hands the kernels a registered host page instead.
 static const uint4* device_zero_page() {
 #ifdef ECO_EMU
   alignas(16) static const uint4 z = {0u, 0u, 0u, 0u};
   emu_register_buffer(&z, sizeof(z));   // the test harness clears its registry between tests
   return &z;
 #else
-  static thread_local const uint4* page[64] = {nullptr};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  if (!page[dev]) {
-    void* p = nullptr;
-    if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
-    page[dev] = (const uint4*)p;
-  }
-  return page[dev];
+  return nullptr;                       // the kernels use the device symbol
 #endif
 }
 
@@ -1195,7 +1204,6 @@ template <int TM, int TN, int WM, int WN>
 static int launch_convb_dma(const ConvBArgs& a, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, BMP = (BM + 63) / 64 * 64;
   const uint4* zp = device_zero_page();
-  if (!zp) return fail(ECO_ERR_RUNTIME, "convb: cannot allocate the zero page");
   ECO_REQUIRE((((uintptr_t)a.x | (uintptr_t)a.wp) & 15) == 0, "convb: input and packed weights must be 16-byte aligned");
   const int grid = a.nblk_m * a.nblk_n * a.ksplit;
   static_assert(3 * kCbs * (BMP + BN) * 16 <= 160 * 1024, "three stage buffers must fit the CU's LDS");
@@ -1207,21 +1215,10 @@ template <int TM, int TN, int WM, int WN>
 static int launch_convb_span(const ConvBArgs& a, int span_pieces, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BMP = (BM + 63) / 64 * 64;
   const uint4* zp = device_zero_page();
-  if (!zp) return fail(ECO_ERR_RUNTIME, "convb: cannot allocate the zero page");
   ECO_REQUIRE((((uintptr_t)a.x | (uintptr_t)a.wp) & 15) == 0, "convb: input and packed weights must be 16-byte aligned");
   const int grid = a.nblk_m * a.nblk_n * a.ksplit;
   const size_t lds = (size_t)(3 * kCbs * BMP + 2 * kCbs * span_pieces * 64) * 16;
-#ifndef ECO_EMU
-  if (lds > 64 * 1024) {
-    static thread_local bool raised = false;
-    if (!raised) {
-      hipError_t e = hipFuncSetAttribute((const void*)convb_span_kernel<TM, TN, WM, WN>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return fail(ECO_ERR_RUNTIME, "convb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      raised = true;
-    }
-  }
-#endif
+  if (lds > 64 * 1024) ECO_RAISE_DYNAMIC_LDS((convb_span_kernel<TM, TN, WM, WN>), "convb");
   hipLaunchKernelGGL((convb_span_kernel<TM, TN, WM, WN>), dim3(grid), dim3(256), lds, stream, a, zp, span_pieces);
   return check_launch("eco_convb_forward");
 }
@@ -1234,16 +1231,8 @@ static int launch_convb(const ConvBArgs& a, int ns, hipStream_t stream) {
   if (ns == 1) {
     return launch_convb_dma<TM, TN, WM, WN>(a, stream);
   } else {
-#ifndef ECO_EMU
     // the split form stages three operand planes: 96-135 KB of the CU's 160 KB, above the default dynamic-LDS cap
-    static thread_local bool raised = false;
-    if (!raised) {
-      hipError_t e = hipFuncSetAttribute((const void*)convb_kernel<TM, TN, WM, WN, 3>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return fail(ECO_ERR_RUNTIME, "convb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      raised = true;
-    }
-#endif
+    ECO_RAISE_DYNAMIC_LDS((convb_kernel<TM, TN, WM, WN, 3>), "convb");
     hipLaunchKernelGGL((convb_kernel<TM, TN, WM, WN, 3>), dim3(grid), dim3(256), lds, stream, a);
   }
   return check_launch("eco_convb_forward");

@@ -22,6 +22,18 @@ inline int check_launch(const char* what) {
 
 inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
 
+// Compute units of the calling thread's current device (plans with num_cu = 0 are sized for it).
+inline int current_device_num_cu() {
+#ifdef ECO_EMU
+  return 256;
+#else
+  int dev = 0, cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) return 256;
+  return cu;
+#endif
+}
+
 // Element offset of (image, channel 0, spatial index sp) in a strided output view (include/eco_hip.h).
 __device__ __forceinline__ long view_base(const eco_view& v, int img, int sp) {
   const int b = img / v.t, t = img - b * v.t;
@@ -29,6 +41,28 @@ __device__ __forceinline__ long view_base(const eco_view& v, int img, int sp) {
 }
 
 }  // namespace eco
+
+// Launches that need more than the default 64 KB of dynamic LDS opt in with hipFuncSetAttribute -- which applies to the
+// CURRENT DEVICE only.  The macro remembers, per call site (= per kernel instantiation), thread and device ordinal,
+// that the limit was raised: a thread that moves to another device (caffe.set_device, Net(device=...)) raises it there
+// too (round-2 advisor finding: a per-thread flag left the second device at the default and its launches failed).
+#ifdef ECO_EMU
+#define ECO_RAISE_DYNAMIC_LDS(kernel, who) do { } while (0)
+#else
+#define ECO_RAISE_DYNAMIC_LDS(kernel, who)                                                                           \
+  do {                                                                                                               \
+    static thread_local unsigned long long eco_raised_ = 0;   /* one bit per device ordinal < 64 */                   \
+    int eco_dev_ = -1;                                                                                               \
+    if (hipGetDevice(&eco_dev_) != hipSuccess) eco_dev_ = -1;                                                        \
+    if (eco_dev_ < 0 || eco_dev_ >= 64 || !((eco_raised_ >> eco_dev_) & 1ull)) {                                     \
+      hipError_t eco_e_ = hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                              160 * 1024);                                                           \
+      if (eco_e_ != hipSuccess)                                                                                      \
+        return eco::fail(ECO_ERR_RUNTIME, "%s: cannot raise the dynamic LDS limit: %s", who, hipGetErrorString(eco_e_)); \
+      if (eco_dev_ >= 0 && eco_dev_ < 64) eco_raised_ |= 1ull << eco_dev_;                                           \
+    }                                                                                                                \
+  } while (0)
+#endif
 
 #define ECO_REQUIRE(cond, ...)                                   \
   do {                                                           \

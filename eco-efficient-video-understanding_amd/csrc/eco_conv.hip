@@ -88,20 +88,9 @@ __device__ __forceinline__ ConvKernelArgs batch_args(const ConvKernelArgs& a0) {
 constexpr int kKoffBits = 26;
 constexpr int kKoffMask = (1 << kKoffBits) - 1;
 constexpr int kNeverTap = 63;  // validity-mask bit that is never set (used by K padding)
-constexpr int kNumCU = 256;    // MI355X; used when the device cannot be asked (emulator build, query failure)
 
 // Compute units of the calling thread's current device (hipDeviceProp_t::multiProcessorCount, what
 // eco_device_info reports); plans are sized against this unless the caller names a count.
-static int current_device_num_cu() {
-#ifdef ECO_EMU
-  return kNumCU;
-#else
-  int dev = 0, cu = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return kNumCU;
-  if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) return kNumCU;
-  return cu;
-#endif
-}
 
 
 // Output position n -> (image, spatial index) under the launch's position order.
@@ -1254,17 +1243,7 @@ template <int TM, int TN, int WM, int WN>
 static int launch_conv_point(const ConvKernelArgs& a, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, BMP = (BM + 63) / 64 * 64;
   const size_t lds_bytes = sizeof(float) * 3 * 16 * (size_t)(BMP + BN);
-#ifndef ECO_EMU
-  if (lds_bytes > 64 * 1024) {
-    static thread_local bool raised = false;
-    if (!raised) {
-      hipError_t e = hipFuncSetAttribute((const void*)conv_point_kernel<TM, TN, WM, WN>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return fail(ECO_ERR_RUNTIME, "conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      raised = true;
-    }
-  }
-#endif
+  if (lds_bytes > 64 * 1024) ECO_RAISE_DYNAMIC_LDS((conv_point_kernel<TM, TN, WM, WN>), "conv");
   hipLaunchKernelGGL((conv_point_kernel<TM, TN, WM, WN>), dim3(a.nblk_m * a.nblk_n), dim3(256), lds_bytes, stream, a);
   return check_launch("eco_conv_forward");
 }

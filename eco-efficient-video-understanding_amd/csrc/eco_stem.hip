@@ -347,18 +347,6 @@ extern "C" int eco_stem_pack_weights(const float* w, int32_t cout, float* wp) {
   return ECO_OK;
 }
 
-// Compute units of the current device (two workgroups fit on each: 70 KB of LDS, <= 256 VGPRs).
-static int stem_num_cu() {
-#ifdef ECO_EMU
-  return 256;
-#else
-  int dev = 0, cu = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 256;
-  if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) return 256;
-  return cu;
-#endif
-}
-
 extern "C" int eco_stem_forward(const float* x, const float* wp, const float* bias, const float* bn_scale,
                                 const float* bn_shift, int32_t relu, float* y, int32_t n, int32_t h, int32_t w,
                                 int32_t cout, int32_t max_workgroups, void* stream) {
@@ -377,22 +365,12 @@ extern "C" int eco_stem_forward(const float* x, const float* wp, const float* bi
   ECO_REQUIRE(total < 2147483647l, "stem: too many patches for one launch");
   a.total = (int)total;
   // persistent workgroups, two per CU: the weights are loaded once per workgroup, not once per patch
-  const long cap = max_workgroups ? max_workgroups : 2l * stem_num_cu();
+  const long cap = max_workgroups ? max_workgroups : 2l * current_device_num_cu();
   const long grid = total < cap ? total : cap;
   const size_t lds = sizeof(float) * (size_t)(16 * (kStemNPos + 3) + kStemKP * cout * 2 + 3 * cout);
   hipStream_t s = (hipStream_t)stream;
-#ifndef ECO_EMU
-  {
-    static thread_local bool raised[2] = {false, false};
-    const int idx = cout == 64;
-    if (!raised[idx]) {
-      hipError_t e = cout == 64 ? hipFuncSetAttribute((const void*)stem_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                                : hipFuncSetAttribute((const void*)stem_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return fail(ECO_ERR_RUNTIME, "stem: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      raised[idx] = true;
-    }
-  }
-#endif
+  if (cout == 64) ECO_RAISE_DYNAMIC_LDS(stem_kernel<2>, "stem");
+  else ECO_RAISE_DYNAMIC_LDS(stem_kernel<1>, "stem");
   if (cout == 64) hipLaunchKernelGGL((stem_kernel<2>), dim3((unsigned)grid), dim3(256), lds, s, a);
   else hipLaunchKernelGGL((stem_kernel<1>), dim3((unsigned)grid), dim3(256), lds, s, a);
   return check_launch("eco_stem_forward");

@@ -652,7 +652,7 @@ extern "C" int eco_wgemm_plan_create(int32_t n, int32_t cin, int32_t cout, int32
                                      int32_t points, int32_t num_cu, eco_wgemm_plan* plan) {
   clear_error();
   ECO_REQUIRE(plan != nullptr && num_cu >= 0, "wgemm: bad argument");
-  if (num_cu == 0) num_cu = 256;
+  if (num_cu == 0) num_cu = current_device_num_cu();   // as eco_conv_plan_create does
   memset(plan, 0, sizeof(*plan));
   plan->n = n; plan->cin = cin; plan->cout = cout; plan->d = d; plan->th = th; plan->tw = tw; plan->kd = kd;
   plan->points = points;
@@ -798,17 +798,7 @@ template <int TM, int TN, int WM, int WN>
 static int launch_wgemm(const WGemmArgs& a, int points, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, BMP = (BM + 63) / 64 * 64;
   const size_t lds = (size_t)3 * kWgKp * (BMP + BN) * 8;
-#ifndef ECO_EMU
-  if (lds > 64 * 1024) {
-    static thread_local bool raised = false;
-    if (!raised) {
-      hipError_t e = hipFuncSetAttribute((const void*)wgemm_kernel<TM, TN, WM, WN>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return fail(ECO_ERR_RUNTIME, "wgemm: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      raised = true;
-    }
-  }
-#endif
+  if (lds > 64 * 1024) ECO_RAISE_DYNAMIC_LDS((wgemm_kernel<TM, TN, WM, WN>), "wgemm");
   const int grid = a.mblocks * a.nblk_n * a.ksplit;
   hipLaunchKernelGGL((wgemm_kernel<TM, TN, WM, WN>), dim3(grid, points), dim3(256), lds, stream, a);
   return check_launch("eco_wgemm_forward");
@@ -969,20 +959,7 @@ extern "C" int eco_wfused_forward(const eco_wgemm_plan* plan, const float* v, co
     ECO_WFUSED_RAISE(KP, VEC);                                                                                             \
     hipLaunchKernelGGL((wfused_kernel<KP, VEC>), dim3((unsigned)grid), dim3(256), lds, s, a);                              \
   } while (0)
-#ifdef ECO_EMU
-#define ECO_WFUSED_RAISE(KP, VEC)
-#else
-#define ECO_WFUSED_RAISE(KP, VEC)                                                                                          \
-  do {                                                                                                                     \
-    static thread_local bool raised = false;                                                                               \
-    if (!raised) {                                                                                                         \
-      hipError_t e = hipFuncSetAttribute((const void*)wfused_kernel<KP, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                         160 * 1024);                                                                      \
-      if (e != hipSuccess) return fail(ECO_ERR_RUNTIME, "wfused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); \
-      raised = true;                                                                                                       \
-    }                                                                                                                      \
-  } while (0)
-#endif
+#define ECO_WFUSED_RAISE(KP, VEC) ECO_RAISE_DYNAMIC_LDS((wfused_kernel<KP, VEC>), "wfused")
 #define ECO_WFUSED_KP(KP)                                                                                                  \
   case 2 * KP:                                                                                                             \
     if (vec == 4) ECO_WFUSED_LAUNCH(KP, 4); else if (vec == 2) ECO_WFUSED_LAUNCH(KP, 2); else ECO_WFUSED_LAUNCH(KP, 1);    \

@@ -48,7 +48,14 @@ def shard_range(total_clips: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def all_gather_logits(local, out=None):
-    """[B/W, C] per rank -> [B, C] on every rank, rank-major (Gather layer semantics)."""
+    """[B/W, C] per rank -> [B, C] on every rank, rank-major (Gather layer semantics).
+
+    Ordering on the GPU: the collective runs on the communicator's own stream.  It is issued asynchronously and
+    ``work.wait()`` then makes the CURRENT stream -- the one the engine launches on -- wait for it (a stream-side
+    wait, the host does not block): the next step's launches, which overwrite ``local`` (the engine's logits
+    buffer), are ordered behind the all-gather that reads it, and the collective itself was ordered behind this
+    step's launches when it was enqueued.  At 15 ms steps the window was never hit; at the 1.3 ms online step with
+    N > 1 it could be."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -56,5 +63,6 @@ def all_gather_logits(local, out=None):
     world = dist.get_world_size()
     if out is None:
         out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous())
+    work = dist.all_gather_into_tensor(out, local.contiguous(), async_op=True)
+    work.wait()
     return out

@@ -785,6 +785,13 @@ class Engine:
             for b in L.bottoms:
                 consumers.setdefault(self._resolve(b), []).append(i)
         outputs = set(spec.outputs)
+        # last layer that writes each blob (in-place layers included).  A fused group is emitted at its first layer's
+        # position, never later than any layer it absorbs, so "producer index < position" means "written by then".
+        self._producer: Dict[str, int] = {}
+        for i, L in enumerate(layers):
+            for t in L.tops:
+                self._producer[self._resolve(t)] = i
+        self._emit_pos: Optional[int] = None
 
         def sole_consumer(blob: str, typ: str) -> Optional[int]:
             cs = consumers.get(blob, [])
@@ -852,6 +859,16 @@ class Engine:
                 self._emit_concat(i, L, skip=concat_skip.get(i, ()))
             else:
                 self._emit_unfused(i, L)
+        # layers each launch stands for: its own and the ones its group absorbed (partial forwards, Engine.forward)
+        index_of = {L.name: k for k, L in enumerate(layers)}
+        cover: Dict[int, set] = {}
+        for k in absorbed:
+            lead = k
+            while lead in absorbed and index_of[absorbed[lead]] != lead:   # a member's BN -> the member -> the group's first conv
+                lead = index_of[absorbed[lead]]
+            cover.setdefault(lead, set()).add(k)
+        for idx, _label, _fn, meta in self.ops:
+            meta["layers"] = {idx} | cover.get(idx, set())
 
     def _fuse_conv(self, i, L, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed, concat_skip) -> None:
         ep, label = self._conv_epilogue(i, L, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed,
@@ -879,8 +896,12 @@ class Engine:
         if ei is not None and ei not in absorbed:
             E = layers[ei]
             others = [b for b in E.bottoms if self._resolve(b) != value]
+            pos = i if self._emit_pos is None else self._emit_pos   # a sibling member runs at its group's position
+            # the other operand must have been written by then: storage alone is not enough (Concat / Permute
+            # destinations are materialised before all their producers have run -- round-2 advisor finding)
             if len(E.bottoms) == 2 and len(others) == 1 and all(c == 1.0 for c in E.geom["coeff"]) \
-                    and self._resolve(others[0]) in self.tensors:
+                    and self._resolve(others[0]) in self.tensors \
+                    and self._producer.get(self._resolve(others[0]), -1) < pos:
                 r = self._resolve(others[0])
                 ep.residual = self._view(r, cout, S)
                 self.fused_away[value] = f"summed into {E.tops[0]} inside the epilogue of {L.name}"
@@ -971,8 +992,12 @@ class Engine:
         for j in members:
             Lj = layers[j]
             br = bn_relu_after(Lj.tops[0])
-            ep, label = self._conv_epilogue(j, Lj, layers, consumers, outputs, sole_consumer, bn_relu_after,
-                                            absorbed, concat_skip)
+            self._emit_pos = i
+            try:
+                ep, label = self._conv_epilogue(j, Lj, layers, consumers, outputs, sole_consumer, bn_relu_after,
+                                                absorbed, concat_skip)
+            finally:
+                self._emit_pos = None
             if j != i:
                 absorbed[j] = L.name
             if ep is None:
@@ -1334,8 +1359,10 @@ class Engine:
         end = len(self.spec.layers) - 1 if end is None else end
         if stream is None and hasattr(self.alloc, "stream"):
             stream = self.alloc.stream()
-        for idx, _label, fn, _meta in self.ops:
-            if start <= idx <= end:
+        # A launch runs when any layer it stands for lies in [start, end]: starting at a layer that was absorbed into an
+        # earlier group (a sibling conv, a fused BN) re-runs that group instead of silently skipping the layer.
+        for idx, _label, fn, meta in self.ops:
+            if any(start <= k <= end for k in meta.get("layers", (idx,))):
                 fn(stream)
 
     def op_labels(self) -> List[str]:

@@ -61,6 +61,52 @@ def test_two_rank_clip_sharding_gloo(tmp_path):
     assert np.abs(g0 - ref).max() < 2e-5 * np.abs(ref).max()  # sharded == unsharded == oracle
 
 
+def _worker8(rank, world, port, out_dir, clips, n_seg):
+    """One of eight ranks of BASELINE.json configs[2]'s sharding (B = 256 clips, 32 per rank) on the reduced net."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      ECO_EMU_THREADS="1", OMP_NUM_THREADS="1")
+    torch.set_num_threads(1)
+    from eco_amd.net import Net
+    from tests.emu.backend import emu_backend
+    eco_dist.init_process_group("gloo")
+    lo, hi = eco_dist.shard_range(clips, rank, world)
+    proto = models.eco_lite_deploy(num_segments=n_seg, num_clips=hi - lo, num_classes=10, input_size=32, width_div=16)
+    spec = NetSpec.from_prototxt(proto)
+    params = fillers.synthetic_params(spec, seed=7)
+    # every rank draws its own clips from the global batch's generator state: frames of clip c are seeded by c
+    frames = np.concatenate([fillers.synthetic_frames(n_seg, 32, 32, seed=1000 + c) for c in range(lo, hi)], 0)
+    net = Net(proto, params=params, _backend=emu_backend())
+    local = net.forward(data=frames)["fc8"]
+    full = eco_dist.all_gather_logits(torch.from_numpy(local.copy()))
+    assert full.shape == (clips, 10) and torch.equal(full[lo:hi], torch.from_numpy(local))
+    if rank in (0, world - 1):
+        np.save(os.path.join(out_dir, f"rank{rank}.npy"), full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_configs2_sharding_gloo(tmp_path):
+    """BASELINE.json configs[2]: 256 clips sharded 32 per rank over 8 ranks (gloo stands in for RCCL), on the
+    reduced net (32x32 frames, channels / 16) so that eight emulated engines finish in about a minute.  The
+    rank-major gather equals the unsharded batch equals the oracle; bench.py labels the run configs[2]."""
+    import eco_oracle as orc
+    import bench
+    world, clips, n_seg = 8, 256, 4
+    assert bench.baseline_config("lite", 16, 32, "f32", 8) == "BASELINE.json configs[2]"
+    assert [eco_dist.shard_range(clips, r, world) for r in (0, 7)] == [(0, 32), (224, 256)]
+    port = _free_port()
+    mp.spawn(_worker8, args=(world, port, str(tmp_path), clips, n_seg), nprocs=world, join=True)
+    g0, g7 = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank7.npy")
+    assert np.array_equal(g0, g7) and g0.shape == (clips, 10)
+    # unsharded reference: the oracle over a sample of clips from every rank's shard (the first, one in the middle, the last)
+    spec1 = NetSpec.from_prototxt(models.eco_lite_deploy(num_segments=n_seg, num_clips=1, num_classes=10, input_size=32,
+                                                         width_div=16))
+    params = fillers.synthetic_params(spec1, seed=7)
+    for c in sorted({32 * r + o for r in range(world) for o in (0, 13, 31)}):
+        ref = orc.forward(spec1, params, {"data": fillers.synthetic_frames(n_seg, 32, 32, seed=1000 + c)})["fc8"]
+        assert np.abs(g0[c] - ref[0]).max() < 2e-5 * max(np.abs(ref).max(), 1e-6), c
+
+
 def test_shard_range():
     assert [eco_dist.shard_range(256, r, 8) for r in (0, 3, 7)] == [(0, 32), (96, 128), (224, 256)]
     assert eco_dist.shard_range(5, 0, 1) == (0, 5)
@@ -94,6 +140,29 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 4
     assert line["config"]["collective_ranks"] == 2 and line["config"]["collective_backend"] == "gloo"
     assert line["value"] > 0 and line["cpu_baseline"] is None and "step_frac" in line["roofline"]
+    # an N > 1 line still carries a parity field (rank 0's first clip against the CPU reference)
+    assert line["parity"]["clips_checked"] == 1 and line["parity"]["max_rel_err"] < 1e-3, line["parity"]
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_dry_launch_on_one_gpu(tmp_path):
+    """`bench.py --gpus 8` launched as the driver launches it, all eight ranks on cuda:0 over gloo, one clip per rank
+    (the 8-GPU node is not ours to run on: this is the N = 8 code path -- rendezvous, per-rank affinity, sharded
+    seeds, gather of 8 x B logits, max-over-ranks timing, rank 0's parity clip -- end to end)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ECO_BENCH_DEVICE="0", ECO_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--clips-per-gpu", "1", "--segments", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 8 and line["config"]["collective_ranks"] == 8
+    assert line["parity"]["max_rel_err"] < 1e-3 and line["parity"]["top1_agree"]
 
 
 _RCCL_SCRIPT = r"""

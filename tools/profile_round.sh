@@ -6,7 +6,8 @@ set -u
 OUT=gpurun_out/${1:-prof}
 mkdir -p $OUT
 export TMPDIR=/tmp
-B="python $PWD/bench.py --no-cpu-baseline"
+B="python $PWD/bench.py --no-cpu-baseline --no-extra-configs"
+sha256sum eco-efficient-video-understanding_amd/libeco_hip.so | cut -d' ' -f1 > $OUT/lib.sha256   # bench.py reports PMC traffic only for this build
 rocprofv3 --kernel-trace --stats -d $PWD/$OUT/trace -o bench --output-format csv -- $B --steps 10 --warmup 3 > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $PWD/$OUT/pmc_fetch -o bench --output-format csv -- $B --steps 2 --warmup 1 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $PWD/$OUT/pmc_write -o bench --output-format csv -- $B --steps 2 --warmup 1 > $OUT/pmc_write.log 2>&1
@@ -14,6 +15,11 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_
 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 # the other BASELINE configurations: configs[4] (bf16, N=32) with its kernel trace, configs[3] (ECO-Full)
 rocprofv3 --kernel-trace --stats -d $PWD/$OUT/trace_bf16 -o bench --output-format csv -- $B --segments 32 --dtype bf16 --steps 10 --warmup 3 > $OUT/trace_bf16.log 2>&1
+# ... and its counters: SQ (MFMA busy, LDS bank conflicts, wait / active shares), FETCH_SIZE, WRITE_SIZE in separate passes
+BB="$B --segments 32 --dtype bf16 --steps 2 --warmup 1"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA -d $PWD/$OUT/pmc_sq_bf16 -o bench --output-format csv -- $BB > $OUT/pmc_sq_bf16.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $PWD/$OUT/pmc_fetch_bf16 -o bench --output-format csv -- $BB > $OUT/pmc_fetch_bf16.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $PWD/$OUT/pmc_write_bf16 -o bench --output-format csv -- $BB > $OUT/pmc_write_bf16.log 2>&1
 python bench.py --segments 32 --dtype bf16 > $OUT/bench_line_bf16.json 2> $OUT/bench_line_bf16.err
 python bench.py --variant full > $OUT/bench_line_full.json 2> $OUT/bench_line_full.err
 # online recognition: one clip per step, the launch list replayed as a hipGraph and submitted call by call

@@ -49,8 +49,29 @@ def main():
         if os.path.exists(p) and os.path.getsize(p):
             with open(p) as fi, open(os.path.join(out_dir, f"{tag}_{nm}"), "w") as fo:
                 fo.write("".join(l for l in fi if "amdgpu.ids" not in l))
+    summary = summarize_traffic(src, "", os.path.join(out_dir, f"{tag}_pmc_hbm_traffic.csv"), "python bench.py")
+    sha = os.path.join(src, "lib.sha256")
+    with open(os.path.join(out_dir, "hbm_traffic_latest.json"), "w") as f:
+        json.dump({"source": f"profiles/{tag}_pmc_hbm_traffic.csv",
+                   # the build the counters belong to: bench.py reports `roofline.traffic` only while it still runs it
+                   "lib_sha256": open(sha).read().strip() if os.path.exists(sha) else None,
+                   "kernels": summary}, f, indent=1)
+    sq = os.path.join(src, "pmc_sq", "bench_counter_collection.csv")
+    if os.path.exists(sq):
+        summarize_sq(sq, os.path.join(out_dir, f"{tag}_pmc_sq.csv"))
+    # configs[4] (bf16, N=32): the same three counter passes
+    if os.path.exists(os.path.join(src, "pmc_fetch_bf16")):
+        summarize_traffic(src, "_bf16", os.path.join(out_dir, f"{tag}_bf16_pmc_hbm_traffic.csv"),
+                          "python bench.py --segments 32 --dtype bf16")
+    sqb = os.path.join(src, "pmc_sq_bf16", "bench_counter_collection.csv")
+    if os.path.exists(sqb):
+        summarize_sq(sqb, os.path.join(out_dir, f"{tag}_bf16_pmc_sq.csv"), "python bench.py --segments 32 --dtype bf16")
+    print("wrote", os.listdir(out_dir))
+
+
+def summarize_traffic(src, suffix, out_path, cmd):
     traffic = collections.defaultdict(dict)
-    for nm, key in (("pmc_fetch", "fetch_kib"), ("pmc_write", "write_kib")):
+    for nm, key in (("pmc_fetch" + suffix, "fetch_kib"), ("pmc_write" + suffix, "write_kib")):
         p = os.path.join(src, nm, "bench_counter_collection.csv")
         if not os.path.exists(p):
             continue
@@ -61,8 +82,8 @@ def main():
             traffic[k][key] = sum(v) / len(v)
             traffic[k][key + "_launches"] = len(v)
     summary = {}
-    with open(os.path.join(out_dir, f"{tag}_pmc_hbm_traffic.csv"), "w") as f:
-        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1\n")
+    with open(out_path, "w") as f:
+        f.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- {cmd} --steps 2 --warmup 1\n")
         f.write("# hbm_bytes_per_launch = 2*FETCH_SIZE*1024 (gfx950 half-count correction) + WRITE_SIZE*1024\n")
         f.write("kernel,avg_FETCH_SIZE_KiB,avg_WRITE_SIZE_KiB,hbm_MB_per_launch_corrected\n")
         for k, v in sorted(traffic.items(), key=lambda kv: -kv[1].get("fetch_kib", 0)):
@@ -70,19 +91,14 @@ def main():
             hbm = 2 * fk * 1024 + wk * 1024
             summary[k] = {"fetch_kib": fk, "write_kib": wk, "hbm_bytes_per_launch": hbm}
             f.write("%s,%.1f,%.1f,%.2f\n" % (k.replace(",", ";"), fk, wk, hbm / 1e6))
-    with open(os.path.join(out_dir, "hbm_traffic_latest.json"), "w") as f:
-        json.dump({"source": f"profiles/{tag}_pmc_hbm_traffic.csv", "kernels": summary}, f, indent=1)
-    sq = os.path.join(src, "pmc_sq", "bench_counter_collection.csv")
-    if os.path.exists(sq):
-        summarize_sq(sq, os.path.join(out_dir, f"{tag}_pmc_sq.csv"))
-    print("wrote", os.listdir(out_dir))
+    return summary
 
 
 SQ_COUNTERS = ("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY "
                "SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA")
 
 
-def summarize_sq(path, out_path):
+def summarize_sq(path, out_path, cmd="python bench.py"):
     """Per-kernel shader-engine counters of one `rocprofv3 --pmc <SQ_COUNTERS>` pass.  Derived columns:
     clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time; MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (per-XCD cycles * 1024
     SIMDs); wait / active = share of SQ_WAVE_CYCLES; avg waves per SIMD = 4 * SQ_WAVE_CYCLES / (cycles * 1024)
@@ -100,7 +116,7 @@ def summarize_sq(path, out_path):
             seen.add((k, did))
             dur[k] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6
     with open(out_path, "w") as f:
-        f.write(f"# rocprofv3 --pmc {SQ_COUNTERS} -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline\n")
+        f.write(f"# rocprofv3 --pmc {SQ_COUNTERS} -- {cmd} --steps 2 --warmup 1 --no-cpu-baseline\n")
         f.write("# clock = GRBM_GUI_ACTIVE/8 XCDs / kernel time; MfmaUtil = MFMA_BUSY / (cycles * 1024 SIMDs); "
                 "wait/active = fraction of wave cycles\n")
         f.write("kernel,dispatches,total_ms,clock_GHz,MfmaUtil,wait_inst_frac,wait_any_frac,active_frac,"
