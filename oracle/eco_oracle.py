@@ -125,6 +125,26 @@ def convolution_naive(x, w, b, kernel, stride, pad) -> np.ndarray:
 # --------------------------------------------------------------------------
 # BN (inference / frozen branch)
 # --------------------------------------------------------------------------
+def _powf(a: np.ndarray, b: float) -> np.ndarray:
+    """Elementwise C ``powf(a[i], b)``: what ``caffe_powx`` is (mkl_alternate.hpp:56, ``y[i] = pow(a[i], b)`` on floats
+    under <math.h>).  numpy's float32 power loop is a SIMD approximation that differs from libm in the last bit for a
+    few percent of inputs, and the correctly rounded double power still differs for ~2 % -- so libm itself is called
+    (tests/test_oracle_ref.py pins bn_inference bit for bit against the compiled bn_layer.cpp)."""
+    import ctypes
+    import ctypes.util
+    global _LIBM
+    if "_LIBM" not in globals():
+        _LIBM = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+        _LIBM.powf.restype = ctypes.c_float
+        _LIBM.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    a = np.asarray(a, F32)
+    out = np.empty(a.shape, F32)
+    flat, of = a.reshape(-1), out.reshape(-1)
+    for i in range(flat.size):
+        of[i] = _LIBM.powf(float(flat[i]), float(b))
+    return out
+
+
 def bn_inference(x, scale, shift, mean, var, eps) -> np.ndarray:
     """``BNLayer::Forward_cpu`` TEST branch (layers/bn_layer.cpp:93-207): per
     channel (axis 1) ``top = x - mean; top *= (var+eps)^-0.5; top *= scale;
@@ -134,7 +154,7 @@ def bn_inference(x, scale, shift, mean, var, eps) -> np.ndarray:
     x = np.asarray(x, dtype=F32)
     C = x.shape[1]
     bshape = (1, C) + (1,) * (x.ndim - 2)
-    inv_std = np.power(np.asarray(var, F32).reshape(C) + F32(eps), F32(-0.5)).astype(F32)
+    inv_std = _powf(np.asarray(var, F32).reshape(C) + F32(eps), -0.5)
     y = x - np.asarray(mean, F32).reshape(bshape)
     y *= inv_std.reshape(bshape)
     y *= np.asarray(scale, F32).reshape(bshape)
@@ -346,7 +366,7 @@ def video_transform(frames_hwc_u8, crop_h, crop_w, h_off, w_off, mean, scale=1.0
 # whole-net forward (Net::ForwardFromTo, net.cpp:566-583)
 # --------------------------------------------------------------------------
 def forward(spec, params, inputs, keep=None, fast_pool=True, timings=None, conv_impl=None, store_hook=None,
-            input_hook=None):
+            input_hook=None, layer_impl=None):
     """Run ``spec`` (an ``eco_amd.netspec.NetSpec``) layer by layer in file order.
 
     ``params``: {layer name: [ndarray, ...]} in the reference's blob order
@@ -356,6 +376,9 @@ def forward(spec, params, inputs, keep=None, fast_pool=True, timings=None, conv_
     In-place layers overwrite their blob exactly as the reference does.
     ``conv_impl(x, w, b, kernel, stride, pad)`` replaces the NumPy convolution (bench.py's CPU baselines plug in
     the compiled reference im2col + OpenBLAS path of oracle/eco_ref.py, or torch-CPU).
+    ``layer_impl``: {layer type: fn(L, bottoms, params_of_layer) -> list of tops or None} replaces the restatement
+    of a layer type (None = fall through to it); tests/test_oracle_ref.py runs a whole net through the COMPILED
+    reference layer code that way.
     ``store_hook(blob name, array)`` / ``input_hook`` transform a top / an input before it is stored: the
     bf16-storage comparisons round there exactly where the blocked path rounds (tests/test_blocked.py)."""
     import time
@@ -377,7 +400,12 @@ def forward(spec, params, inputs, keep=None, fast_pool=True, timings=None, conv_
         t0 = time.perf_counter()
         bt = [blobs[b] for b in L.bottoms]
         g = L.geom
-        if L.type == "Convolution":
+        top = None
+        if layer_impl is not None and L.type in layer_impl:
+            top = layer_impl[L.type](L, bt, params.get(L.name))
+        if top is not None:
+            pass
+        elif L.type == "Convolution":
             p = params[L.name]
             top = [conv_fn(bt[0], p[0], p[1] if g["bias_term"] else None, g["kernel"], g["stride"], g["pad"])]
         elif L.type == "BN":

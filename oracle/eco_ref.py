@@ -1,9 +1,10 @@
 """ctypes binding of oracle/_ref/libeco_ref.so -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
 ``libeco_ref.so`` is built by oracle/Makefile from the reference's own, unmodified sources
-(caffe_3d/src/caffe/util/im2col.cpp, layers/pooling_layer.cpp) behind the stand-in headers of
-oracle/ref_shim/, plus ``ref_conv_forward`` = the reference's ConvolutionLayer::Forward_cpu call sequence
-(per image: reference im2col -> cblas_sgemm -> bias sgemm; conv_layer.cpp:28-43, base_conv_layer.cpp:264-287).
+(caffe_3d/src/caffe/util/im2col.cpp and layers/{pooling,bn,permute,eltwise,concat,inner_product,reshape,relu}_layer.cpp)
+behind the stand-in headers of oracle/ref_shim/, plus ``ref_conv_forward`` = the reference's
+ConvolutionLayer::Forward_cpu call sequence (per image: reference im2col -> cblas_sgemm -> bias sgemm;
+conv_layer.cpp:28-43, base_conv_layer.cpp:264-287).
 The GEMM is SciPy's bundled OpenBLAS (``scipy_cblas_sgemm``), the class of library the reference links.
 
 Only tests/ and bench.py's cpu_baseline leg may import this; it pins oracle/eco_oracle.py against compiled
@@ -73,8 +74,28 @@ def lib():
         d.ref_conv_forward.restype = C.c_int
         d.ref_pool_forward.argtypes = [C.c_void_p, ip, C.c_int, C.c_int, ip, ip, ip, C.c_void_p, ip]
         d.ref_pool_forward.restype = C.c_int
+        if hasattr(d, "ref_bn_forward"):   # (a .so of round 2 shipped to an old box lacks the layer entry points)
+            fp, pp = C.c_void_p, C.POINTER(C.c_void_p)
+            d.ref_set_sgemm.argtypes = [C.c_void_p]
+            d.ref_set_sgemm.restype = None
+            d.ref_bn_forward.argtypes = [fp, ip, C.c_int, fp, fp, fp, fp, C.c_float, C.c_int, fp]
+            d.ref_permute_forward.argtypes = [fp, ip, C.c_int, ip, C.c_int, fp, ip]
+            d.ref_eltwise_forward.argtypes = [pp, C.c_int, ip, C.c_int, C.c_int, fp, fp]
+            d.ref_concat_forward.argtypes = [pp, C.c_int, ip, C.c_int, C.c_int, fp, ip]
+            d.ref_inner_product_forward.argtypes = [fp, ip, C.c_int, fp, fp, C.c_int, C.c_int, fp]
+            d.ref_reshape_shape.argtypes = [ip, C.c_int, C.POINTER(C.c_longlong), C.c_int, C.c_int, C.c_int, ip]
+            d.ref_relu_forward.argtypes = [fp, C.c_long, C.c_float, fp]
+            for f in ("ref_bn_forward", "ref_permute_forward", "ref_eltwise_forward", "ref_concat_forward",
+                      "ref_inner_product_forward", "ref_reshape_shape", "ref_relu_forward"):
+                getattr(d, f).restype = C.c_int
+            d.ref_set_sgemm(C.cast(_openblas()[1], C.c_void_p))   # every caffe_cpu_gemm<float> of the compiled layers
         _lib = d
     return _lib
+
+
+def has_layers() -> bool:
+    """True when the loaded library carries the compiled layer files (BN, Permute, Eltwise, Concat, InnerProduct, ...)."""
+    return hasattr(lib(), "ref_bn_forward")
 
 
 def _ia(v):
@@ -137,4 +158,88 @@ def pooling(x, method, kernel, stride, pad) -> np.ndarray:
     rc = lib().ref_pool_forward(x.ctypes.data, _ia(x.shape), 4, 0 if method == "MAX" else 1,
                                 None if kernel is None else _ia(kernel), _ia(stride), _ia(pad), y.ctypes.data, out)
     assert rc == 0
+    return y
+
+
+# ---- the other layer types of the deploy graphs, through their compiled reference Forward_cpu ------------------------
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def bn_inference(x, slope, bias, mean, var, eps, frozen: bool = False) -> np.ndarray:
+    """BNLayer::Forward_cpu, TEST phase (bn_layer.cpp:93-207).  Blobs of at most 4 axes -- the reference's CPU code
+    CHECK-fails beyond (LegacyShape); a 5-D blob [n,c,d,h,w] is evaluated as [n,c,d*h,w] (the arithmetic is per
+    channel; the eps rule of the cuDNN path the reference takes for 5-D blobs is the CALLER's business)."""
+    x = _f32(x)
+    shp = x.shape if x.ndim <= 4 else (x.shape[0], x.shape[1], int(np.prod(x.shape[2:-1])), x.shape[-1])
+    y = np.empty(shp, np.float32)
+    ps = [_f32(p).reshape(-1) for p in (slope, bias, mean, var)]
+    rc = lib().ref_bn_forward(x.ctypes.data, _ia(shp), len(shp), ps[0].ctypes.data, ps[1].ctypes.data, ps[2].ctypes.data,
+                              ps[3].ctypes.data, float(eps), int(frozen), y.ctypes.data)
+    assert rc == 0
+    return y.reshape(x.shape)
+
+
+def permute(x, order) -> np.ndarray:
+    """PermuteLayer::Forward_cpu (permute_layer.cpp:98-114)."""
+    x = _f32(x)
+    out = (C.c_int * x.ndim)()
+    lib().ref_permute_forward(None, _ia(x.shape), x.ndim, _ia(order), len(order), None, out)
+    y = np.empty(tuple(out), np.float32)
+    assert lib().ref_permute_forward(x.ctypes.data, _ia(x.shape), x.ndim, _ia(order), len(order), y.ctypes.data, out) == 0
+    return y
+
+
+def _ptrs(arrs):
+    return (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+
+
+def eltwise(xs, op="SUM", coeffs=None) -> np.ndarray:
+    """EltwiseLayer::Forward_cpu (eltwise_layer.cpp:49-119)."""
+    xs = [_f32(x) for x in xs]
+    y = np.empty(xs[0].shape, np.float32)
+    cf = None if coeffs is None else _f32(coeffs)
+    rc = lib().ref_eltwise_forward(_ptrs(xs), len(xs), _ia(xs[0].shape), xs[0].ndim, {"PROD": 0, "SUM": 1, "MAX": 2}[op],
+                                   None if cf is None else cf.ctypes.data, y.ctypes.data)
+    assert rc == 0
+    return y
+
+
+def concat(xs, axis=1) -> np.ndarray:
+    """ConcatLayer::Reshape + Forward_cpu (concat_layer.cpp:17-70)."""
+    xs = [_f32(x) for x in xs]
+    nd = xs[0].ndim
+    shapes = _ia([d for x in xs for d in x.shape])
+    out = (C.c_int * nd)()
+    lib().ref_concat_forward(_ptrs(xs), len(xs), shapes, nd, int(axis), None, out)
+    y = np.empty(tuple(out), np.float32)
+    assert lib().ref_concat_forward(_ptrs(xs), len(xs), shapes, nd, int(axis), y.ctypes.data, out) == 0
+    return y
+
+
+def inner_product(x, w, b, axis=1) -> np.ndarray:
+    """InnerProductLayer::Forward_cpu (inner_product_layer.cpp:81-93) over OpenBLAS sgemm."""
+    x, w = _f32(x), _f32(w)
+    n_out = w.shape[0]
+    y = np.empty(x.shape[:axis] + (n_out,), np.float32)
+    bb = None if b is None else _f32(b)
+    rc = lib().ref_inner_product_forward(x.ctypes.data, _ia(x.shape), x.ndim, w.reshape(n_out, -1).ctypes.data,
+                                         None if bb is None else bb.ctypes.data, n_out, int(axis), y.ctypes.data)
+    assert rc == 0
+    return y
+
+
+def reshape_shape(shape, dims, axis=0, num_axes=-1):
+    """ReshapeLayer::LayerSetUp + Reshape (reshape_layer.cpp:9-90): the top shape for bottom `shape`."""
+    out = (C.c_int * 16)()
+    d = (C.c_longlong * len(dims))(*[int(v) for v in dims])
+    n = lib().ref_reshape_shape(_ia(shape), len(shape), d, len(dims), int(axis), int(num_axes), out)
+    return tuple(out[:n])
+
+
+def relu(x, negative_slope=0.0) -> np.ndarray:
+    """ReLULayer::Forward_cpu (relu_layer.cpp:10-20)."""
+    x = _f32(x)
+    y = np.empty(x.shape, np.float32)
+    assert lib().ref_relu_forward(x.ctypes.data, x.size, float(negative_slope), y.ctypes.data) == 0
     return y

@@ -1,6 +1,9 @@
 // oracle/ref_shim: declaration of PoolingLayer with the data members layers/pooling_layer.cpp defines its
 // methods over (include/caffe/vision_layers.hpp:468-519).  Every method BODY comes from the reference .cpp.
+// (The reference's vision_layers.hpp pulls in common_layers.hpp / neuron_layers.hpp, which eltwise_layer.cpp,
+// concat_layer.cpp, inner_product_layer.cpp and relu_layer.cpp rely on: same here.)
 #pragma once
+#include "caffe/common_layers.hpp"
 #include "caffe/layer.hpp"
 namespace caffe {
 template <typename Dtype>

@@ -1,7 +1,14 @@
 // oracle/ref_shim/ref_api.cpp -- TEST INFRASTRUCTURE.  C entry points over the reference sources that are
 // compiled, unmodified, from /root/reference into oracle/_ref/libeco_ref.so (see oracle/Makefile):
-//   caffe_3d/src/caffe/util/im2col.cpp            im2col_cpu / im2col_nd_cpu
-//   caffe_3d/src/caffe/layers/pooling_layer.cpp   PoolingLayer::LayerSetUp / Reshape / Forward_cpu
+//   caffe_3d/src/caffe/util/im2col.cpp                  im2col_cpu / im2col_nd_cpu
+//   caffe_3d/src/caffe/layers/pooling_layer.cpp         PoolingLayer::LayerSetUp / Reshape / Forward_cpu
+//   caffe_3d/src/caffe/layers/bn_layer.cpp              BNLayer (4-D blobs: the only ones its CPU code takes)
+//   caffe_3d/src/caffe/layers/permute_layer.cpp         PermuteLayer + Permute()
+//   caffe_3d/src/caffe/layers/eltwise_layer.cpp         EltwiseLayer
+//   caffe_3d/src/caffe/layers/concat_layer.cpp          ConcatLayer
+//   caffe_3d/src/caffe/layers/inner_product_layer.cpp   InnerProductLayer
+//   caffe_3d/src/caffe/layers/reshape_layer.cpp         ReshapeLayer (shape rules)
+//   caffe_3d/src/caffe/layers/relu_layer.cpp            ReLULayer
 // plus a convolution forward that performs exactly the call sequence of ConvolutionLayer::Forward_cpu
 // (layers/conv_layer.cpp:28-43 -> BaseConvolutionLayer::forward_cpu_gemm / forward_cpu_bias,
 // layers/base_conv_layer.cpp:264-287 -> caffe_cpu_gemm, util/math_functions.cpp:12-21): per image, the
@@ -18,7 +25,145 @@
 
 using namespace caffe;
 
+namespace ref_shim { sgemm_fn g_sgemm = nullptr; }
+
+namespace {
+typedef std::vector<Blob<float>*> BlobVec;
+void fill(Blob<float>& b, const std::vector<int>& shape, const float* src) {
+  b.Reshape(shape);
+  if (src) caffe_copy(b.count(), src, b.mutable_cpu_data());
+}
+std::vector<int> shape_of(const int* shape, int naxes) { return std::vector<int>(shape, shape + naxes); }
+}  // namespace
+
 extern "C" {
+
+// The cblas_sgemm every caffe_cpu_gemm<float> of the compiled layer files goes through (SciPy's OpenBLAS).
+void ref_set_sgemm(void* fn) { ref_shim::g_sgemm = (ref_shim::sgemm_fn)fn; }
+
+// BNLayer::LayerSetUp / Reshape / Forward_cpu, TEST phase (bn_layer.cpp:10-207).  x: [n,c,h,w] (<= 4 axes: LegacyShape
+// CHECK-fails beyond, bn_layer.cpp:70-73 via blob.hpp); blobs = slope, bias, running mean, running variance [1,c].
+int ref_bn_forward(const float* x, const int* shape, int naxes, const float* slope, const float* bias, const float* mean,
+                   const float* var, float eps, int frozen, float* y) {
+  if (naxes < 2 || naxes > 4) return -1;
+  LayerParameter lp;
+  lp.bn_param_.eps_ = eps;
+  lp.bn_param_.frozen_ = frozen != 0;
+  BNLayer<float> layer(lp);
+  Blob<float> bottom, top;
+  fill(bottom, shape_of(shape, naxes), x);
+  BlobVec bv(1, &bottom), tv(1, &top);
+  layer.LayerSetUp(bv, tv);                       // creates the four [1,c] parameter blobs through the fillers
+  const float* src[4] = {slope, bias, mean, var};
+  for (int i = 0; i < 4; ++i) caffe_copy(layer.blobs()[i]->count(), src[i], layer.blobs()[i]->mutable_cpu_data());
+  layer.Reshape(bv, tv);
+  layer.Forward_cpu(bv, tv);
+  caffe_copy(top.count(), top.cpu_data(), y);
+  return 0;
+}
+
+// PermuteLayer (permute_layer.cpp:9-114).  out_shape receives the permuted shape; y may be NULL to query it.
+int ref_permute_forward(const float* x, const int* shape, int naxes, const int* order, int norder, float* y, int* out_shape) {
+  LayerParameter lp;
+  for (int i = 0; i < norder; ++i) lp.permute_param_.order_.push_back((unsigned)order[i]);
+  PermuteLayer<float> layer(lp);
+  Blob<float> bottom, top;
+  fill(bottom, shape_of(shape, naxes), y ? x : nullptr);
+  BlobVec bv(1, &bottom), tv(1, &top);
+  layer.LayerSetUp(bv, tv);
+  layer.Reshape(bv, tv);
+  for (int i = 0; i < naxes; ++i) out_shape[i] = top.shape(i);
+  if (!y) return 0;
+  layer.Forward_cpu(bv, tv);
+  caffe_copy(top.count(), top.cpu_data(), y);
+  return 0;
+}
+
+// EltwiseLayer (eltwise_layer.cpp:10-119).  op: 0 PROD, 1 SUM, 2 MAX; coeffs may be NULL (all ones).
+int ref_eltwise_forward(const float* const* xs, int nbottom, const int* shape, int naxes, int op, const float* coeffs, float* y) {
+  LayerParameter lp;
+  lp.eltwise_param_.operation_ = (EltwiseParameter_EltwiseOp)op;
+  if (coeffs) lp.eltwise_param_.coeff_.assign(coeffs, coeffs + nbottom);
+  EltwiseLayer<float> layer(lp);
+  std::vector<Blob<float> > bottoms(nbottom);
+  Blob<float> top;
+  BlobVec bv, tv(1, &top);
+  for (int i = 0; i < nbottom; ++i) { fill(bottoms[i], shape_of(shape, naxes), xs[i]); bv.push_back(&bottoms[i]); }
+  layer.LayerSetUp(bv, tv);
+  layer.Reshape(bv, tv);
+  layer.Forward_cpu(bv, tv);
+  caffe_copy(top.count(), top.cpu_data(), y);
+  return 0;
+}
+
+// ConcatLayer (concat_layer.cpp:9-70).  shapes: nbottom rows of naxes ints; out_shape receives the top shape; y may be NULL.
+int ref_concat_forward(const float* const* xs, int nbottom, const int* shapes, int naxes, int axis, float* y, int* out_shape) {
+  LayerParameter lp;
+  lp.concat_param_.axis_ = axis;
+  lp.concat_param_.has_axis_ = true;
+  ConcatLayer<float> layer(lp);
+  std::vector<Blob<float> > bottoms(nbottom);
+  Blob<float> top;
+  BlobVec bv, tv(1, &top);
+  for (int i = 0; i < nbottom; ++i) { fill(bottoms[i], shape_of(shapes + i * naxes, naxes), y ? xs[i] : nullptr); bv.push_back(&bottoms[i]); }
+  layer.LayerSetUp(bv, tv);
+  layer.Reshape(bv, tv);
+  for (int i = 0; i < naxes; ++i) out_shape[i] = top.shape(i);
+  if (!y) return 0;
+  layer.Forward_cpu(bv, tv);
+  caffe_copy(top.count(), top.cpu_data(), y);
+  return 0;
+}
+
+// InnerProductLayer (inner_product_layer.cpp:13-93): w [num_output, K], b [num_output] or NULL; y [M, num_output].
+int ref_inner_product_forward(const float* x, const int* shape, int naxes, const float* w, const float* b, int num_output,
+                              int axis, float* y) {
+  LayerParameter lp;
+  lp.inner_product_param_.num_output_ = (unsigned)num_output;
+  lp.inner_product_param_.bias_term_ = b != nullptr;
+  lp.inner_product_param_.axis_ = axis;
+  InnerProductLayer<float> layer(lp);
+  Blob<float> bottom, top;
+  fill(bottom, shape_of(shape, naxes), x);
+  BlobVec bv(1, &bottom), tv(1, &top);
+  layer.LayerSetUp(bv, tv);
+  caffe_copy(layer.blobs()[0]->count(), w, layer.blobs()[0]->mutable_cpu_data());
+  if (b) caffe_copy(layer.blobs()[1]->count(), b, layer.blobs()[1]->mutable_cpu_data());
+  layer.Reshape(bv, tv);
+  layer.Forward_cpu(bv, tv);
+  caffe_copy(top.count(), top.cpu_data(), y);
+  return 0;
+}
+
+// ReshapeLayer::LayerSetUp / Reshape (reshape_layer.cpp:9-90): the 0 / -1 rules.  Returns the number of top axes.
+int ref_reshape_shape(const int* shape, int naxes, const long long* dims, int ndims, int axis, int num_axes, int* out_shape) {
+  LayerParameter lp;
+  lp.reshape_param_.shape_.dim_.assign(dims, dims + ndims);
+  lp.reshape_param_.axis_ = axis;
+  lp.reshape_param_.num_axes_ = num_axes;
+  ReshapeLayer<float> layer(lp);
+  Blob<float> bottom, top;
+  fill(bottom, shape_of(shape, naxes), nullptr);
+  BlobVec bv(1, &bottom), tv(1, &top);
+  layer.LayerSetUp(bv, tv);
+  layer.Reshape(bv, tv);
+  for (int i = 0; i < top.num_axes(); ++i) out_shape[i] = top.shape(i);
+  return top.num_axes();
+}
+
+// ReLULayer::Forward_cpu (relu_layer.cpp:10-20)
+int ref_relu_forward(const float* x, long count, float negative_slope, float* y) {
+  LayerParameter lp;
+  lp.relu_param_.negative_slope_ = negative_slope;
+  ReLULayer<float> layer(lp);
+  Blob<float> bottom, top;
+  fill(bottom, std::vector<int>(1, (int)count), x);
+  BlobVec bv(1, &bottom), tv(1, &top);
+  layer.Reshape(bv, tv);
+  layer.Forward_cpu(bv, tv);
+  caffe_copy(top.count(), top.cpu_data(), y);
+  return 0;
+}
 
 typedef void (*sgemm_fn)(int order, int transa, int transb, int m, int n, int k, float alpha, const float* a, int lda,
                          const float* b, int ldb, float beta, float* c, int ldc);
