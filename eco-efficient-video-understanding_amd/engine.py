@@ -792,6 +792,7 @@ class Engine:
             for t in L.tops:
                 self._producer[self._resolve(t)] = i
         self._emit_pos: Optional[int] = None
+        self._index_of = {L.name: k for k, L in enumerate(layers)}
 
         def sole_consumer(blob: str, typ: str) -> Optional[int]:
             cs = consumers.get(blob, [])
@@ -860,7 +861,7 @@ class Engine:
             else:
                 self._emit_unfused(i, L)
         # layers each launch stands for: its own and the ones its group absorbed (partial forwards, Engine.forward)
-        index_of = {L.name: k for k, L in enumerate(layers)}
+        index_of = self._index_of
         cover: Dict[int, set] = {}
         for k in absorbed:
             lead = k
@@ -899,9 +900,11 @@ class Engine:
             pos = i if self._emit_pos is None else self._emit_pos   # a sibling member runs at its group's position
             # the other operand must have been written by then: storage alone is not enough (Concat / Permute
             # destinations are materialised before all their producers have run -- round-2 advisor finding)
+            prod = self._producer.get(self._resolve(others[0]), -1) if len(others) == 1 else -1
+            while prod in absorbed and self._index_of[absorbed[prod]] != prod:
+                prod = self._index_of[absorbed[prod]]   # a layer absorbed into a group is written where the group runs
             if len(E.bottoms) == 2 and len(others) == 1 and all(c == 1.0 for c in E.geom["coeff"]) \
-                    and self._resolve(others[0]) in self.tensors \
-                    and self._producer.get(self._resolve(others[0]), -1) < pos:
+                    and self._resolve(others[0]) in self.tensors and prod < pos:
                 r = self._resolve(others[0])
                 ep.residual = self._view(r, cout, S)
                 self.fused_away[value] = f"summed into {E.tops[0]} inside the epilogue of {L.name}"
