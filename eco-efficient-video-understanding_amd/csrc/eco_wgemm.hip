@@ -113,24 +113,37 @@ __global__ __launch_bounds__(256, 2) void wgemm_kernel(const WGemmArgs a) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) { ib[j] = half * BN + (wn * TN + j) * 32 + l31; ECO_OPAQUE(ib[j]); }
 
+  // One stage = four steps t of two pair-rows (2t for lanes 0-31, 2t+1 for lanes 32-63: four k per step).  The
+  // fragments of step t+1 are read while the 2*TM*TN MFMAs of step t issue (double-buffered registers, order pinned
+  // with sched_fence): the compiler's own schedule fetched two steps at once with ds_read2st64_b64 -- which the LDS
+  // serves at half the rate of two ds_read_b64 -- one MFMA ahead of their first use, and waited for them.
   auto compute = [&](int buf) {
     const float2* Ab = (const float2*)(Aw + buf * A_VEC);
     const float2* Bb = (const float2*)(Bw + buf * B_VEC);
+    float2 af[2][TM], bf[2][TN];
 #pragma unroll
-    for (int t = 0; t < kWgKp / 2; ++t) {     // pair-rows 2t (lanes 0-31) and 2t+1 (lanes 32-63): four k per t
-      float2 af[TM], bf[TN];
+    for (int i = 0; i < TM; ++i) af[0][i] = Ab[ia[i]];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = Ab[2 * t * BMP + ia[i]];
+    for (int j = 0; j < TN; ++j) bf[0][j] = Bb[ib[j]];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = Bb[2 * t * BN + ib[j]];
+    for (int t = 0; t < kWgKp / 2; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < kWgKp / 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[cur ^ 1][i] = Ab[2 * (t + 1) * BMP + ia[i]];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[cur ^ 1][j] = Bb[2 * (t + 1) * BN + ib[j]];
+      }
+      sched_fence();
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(af[i].x, bf[j].x, acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(af[cur][i].x, bf[cur][j].x, acc[i][j]);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(af[i].y, bf[j].y, acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(af[cur][i].y, bf[cur][j].y, acc[i][j]);
+      sched_fence();
     }
   };
 
@@ -139,8 +152,15 @@ __global__ __launch_bounds__(256, 2) void wgemm_kernel(const WGemmArgs a) {
     if (s_begin + 1 < s_end) issue_stage(1);
     int buf = 0;
     for (int s = s_begin; s < s_end; ++s) {
+#if defined(ECO_WGEMM_PROBE) && (ECO_WGEMM_PROBE & 2)   // probe builds (tools/exp): bit 1 = no barrier / DMA wait per stage
+      if (s == s_begin) { wait_dma_all_but<0>(); wg_barrier_nodrain(); }
+#else
       if (s + 1 < s_end) wait_dma_all_but<P>(); else wait_dma_all_but<0>();
       wg_barrier_nodrain();
+#endif
+#if defined(ECO_WGEMM_PROBE) && (ECO_WGEMM_PROBE & 1)   // bit 0 = no operand DMA after the first two stages
+      if (false)
+#endif
       if (s + 2 < s_end) issue_stage(buf == 0 ? 2 : buf - 1);   // (buf + 2) % 3: last read before this barrier
       sched_fence();
       compute(buf);
