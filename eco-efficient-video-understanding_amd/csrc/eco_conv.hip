@@ -26,6 +26,7 @@
 // Output tile: lane = output position (32 consecutive positions per half-wave), register =
 // output channel -> each store instruction writes 128 contiguous bytes per half-wave into
 // the N,C,[D,]H,W destination.
+#include <stdlib.h>
 #include <string.h>
 
 #include "eco_common.h"
@@ -65,6 +66,13 @@ struct ConvKernelArgs {
   // ns_short <= ns_long.  Gather kernels: every split tile has ksplit slices (ns_short = ns_long = ksplit).
   int col_long0, col_long1, ns_short, ns_long;
   float* ws;
+  // Stream-K launches (conv_streamk_kernel): sk_wgs persistent workgroups share sk_units = stages of all tiles;
+  // sk_cum[col] = stages of one M-block's tiles in columns < col (int32 behind the packed gather table);
+  // sk_flags[w] = 1 once workgroup w's partial block ws[w][BM*BN] is in memory.
+  int sk_wgs;
+  long sk_units;
+  const int32_t* sk_cum;
+  int* sk_flags;
   // Batched launches (gridDim.y = batch; the (M+2)^2 transform points of the Winograd path): element strides of
   // the input, the packed weights, the output views and the split-K workspace between batch entries.
   long bstride_x, bstride_w, bstride_out, bstride_ws;
@@ -345,14 +353,18 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKerne
 //
 // Register budget: 64 accumulators per 2x2 wave tile leave ~100 VGPRs for four workgroups per CU;
 // the second launch-bound argument (waves per SIMD) holds the allocator to that.
+// The reduction of stages [c_begin, c_end) of the output tile at (m0, n0) into `acc` (cleared here unless keep_acc: the
+// stream-K kernel starts a shared tile's last segment from the other workgroups' partial sums): everything of
+// conv_mfma_kernel between "which tile, which stages" and "what to do with the sums", so that the one-tile-per-workgroup
+// kernel and the persistent stream-K kernel below share it.  zlo / zhi / tap_lo / taps_live: the tile's live depth taps.
 template <int TM, int TN, int WM, int WN, int KC, int MODE>
-__global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(const ConvKernelArgs a0) {
-  const ConvKernelArgs a = batch_args(a0);
+__device__ __forceinline__ void conv_reduce_segment(const ConvKernelArgs& a, int m0, int n0, int c_begin, int c_end, int zlo,
+                                                    int zhi, int nstages_all, float (&As)[2][KC][32 * TM * WM],
+                                                    float (&Bs)[2][KC][32 * TN * WN], f32x16 (&acc)[TM][TN],
+                                                    bool keep_acc = false) {
   constexpr bool CTAP = MODE == ECO_CONV_MODE_CTAP;
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
-  static_assert(WM * WN == 4, "4 waves per workgroup");
-  static_assert(BN == 128 || BN == 256, "");
   constexpr int KG = 256 / BN;         // threads sharing one output position in the gather
   constexpr int EPT = KC / KG;         // gathered elements per thread per stage
   constexpr int KSTEPS = KC / 2;       // MFMA k-pair steps per stage
@@ -361,56 +373,14 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(
   constexpr int A_F4 = KC * BM / 4;
   constexpr int A_ITERS = (A_F4 + 255) / 256;
   static_assert(A_ITERS <= KSTEPS, "");
-
-  __shared__ __attribute__((aligned(16))) float As[2][KC][BM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][KC][BN];
-
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   const int wave = uniform(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, l31 = lane & 31;
-
-  // Hardware blocks [0, n_main) are whole tiles; the rest are (slice, tile) pairs of the split-K region,
-  // slice-major so neighbours share the K range.  Each range gets its own XCD-contiguous remap, and the
-  // split region comes last in dispatch order so its short blocks fill the tail of the launch.
-  int tile, slice, nslices;
-  if ((int)blockIdx.x < a.n_main) {
-    tile = xcd_remap((int)blockIdx.x, a.n_main);
-    slice = 0;
-    nslices = 1;
-  } else {
-    // (slice, tile) pairs that exist, slice-major: slices [0, ns_short) of every split tile, then slices
-    // [ns_short, ns_long) of the long columns only (depth-major launches: tiles of the first / last depth
-    // plane have fewer live taps and fewer slices) -- numbered densely so that the XCD remap deals every
-    // XCD the same number of live workgroups.  Other launches: ns_short = ns_long = ksplit.
-    const int c0 = a.n_main / a.nblk_m;
-    const int cl0 = a.col_long0 > c0 ? a.col_long0 : c0;
-    const int n_long = (a.col_long1 > cl0 ? a.col_long1 - cl0 : 0) * a.nblk_m;
-    const int n_all = a.n_split * a.ns_short;
-    const int lid = xcd_remap((int)blockIdx.x - a.n_main, n_all + n_long * (a.ns_long - a.ns_short));
-    if (lid < n_all) {
-      slice = lid / a.n_split;
-      tile = a.n_main + (lid - slice * a.n_split);
-    } else {
-      const int r = lid - n_all;
-      slice = a.ns_short + r / n_long;
-      tile = cl0 * a.nblk_m + r % n_long;
-    }
-    nslices = col_slices(a, tile / a.nblk_m);
-  }
-  const bool sliced = (int)blockIdx.x >= a.n_main;
-  const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
-  const int m0 = mblk * BM, n0 = nblk * BN;
-  // Reduction work list: stages (channel tile cc, tap) with the tap's depth index in the live range of this
-  // tile (depth-major launches skip the depth taps that see only padding; otherwise every tap), cc-major.
   const int taps = a.kd * a.kh * a.kw, khw = a.kh * a.kw;
-  int zlo, zhi;
-  live_depth_taps(a, n0, BN, zlo, zhi);
   const int tap_lo = zlo * khw, taps_live = (zhi - zlo + 1) * khw;
-  const int nstages_all = CTAP ? (a.cin / KC) * taps_live : a.kpad / KC;
-  const int c_begin = (int)((long)slice * nstages_all / nslices);
-  const int c_end = (int)((long)(slice + 1) * nstages_all / nslices);
+  (void)nstages_all;
 
   // ---- gather role of this thread: one output position, EPT of the stage's KC rows ----
   const int pos_l = tid % BN;
@@ -520,13 +490,14 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(
     for (int j = 0; j < EPT; ++j) Bs[buf][kg + j * KG][pos_l] = ((l_ok >> j) & 1u) ? breg[j] : 0.0f;
   };
 
-  f32x16 acc[TM][TN];
+  if (!keep_acc) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  }
 
   // Fragment registers are double-buffered across k-pair steps: the ds_reads of step kk+1 are issued
   // before the MFMAs of step kk, so a wave does not sit on LDS latency between MFMA groups.
@@ -585,10 +556,222 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(
       sched_fence();
     }
   }
+}
+
+template <int TM, int TN, int WM, int WN, int KC, int MODE>
+__global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(const ConvKernelArgs a0) {
+  const ConvKernelArgs a = batch_args(a0);
+  constexpr bool CTAP = MODE == ECO_CONV_MODE_CTAP;
+  constexpr int BM = 32 * TM * WM;
+  constexpr int BN = 32 * TN * WN;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(BN == 128 || BN == 256, "");
+  constexpr int KG = 256 / BN;         // threads sharing one output position in the gather
+  constexpr int EPT = KC / KG;         // gathered elements per thread per stage
+  constexpr int KSTEPS = KC / 2;       // MFMA k-pair steps per stage
+  constexpr int BPS = EPT / KSTEPS;    // gather loads issued per k-pair step (1 or 2)
+  static_assert(EPT % KSTEPS == 0 && BPS >= 1, "");
+  constexpr int A_F4 = KC * BM / 4;
+  constexpr int A_ITERS = (A_F4 + 255) / 256;
+  static_assert(A_ITERS <= KSTEPS, "");
+
+  __shared__ __attribute__((aligned(16))) float As[2][KC][BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][KC][BN];
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  // Hardware blocks [0, n_main) are whole tiles; the rest are (slice, tile) pairs of the split-K region,
+  // slice-major so neighbours share the K range.  Each range gets its own XCD-contiguous remap, and the
+  // split region comes last in dispatch order so its short blocks fill the tail of the launch.
+  int tile, slice, nslices;
+  if ((int)blockIdx.x < a.n_main) {
+    tile = xcd_remap((int)blockIdx.x, a.n_main);
+    slice = 0;
+    nslices = 1;
+  } else {
+    // (slice, tile) pairs that exist, slice-major: slices [0, ns_short) of every split tile, then slices
+    // [ns_short, ns_long) of the long columns only (depth-major launches: tiles of the first / last depth
+    // plane have fewer live taps and fewer slices) -- numbered densely so that the XCD remap deals every
+    // XCD the same number of live workgroups.  Other launches: ns_short = ns_long = ksplit.
+    const int c0 = a.n_main / a.nblk_m;
+    const int cl0 = a.col_long0 > c0 ? a.col_long0 : c0;
+    const int n_long = (a.col_long1 > cl0 ? a.col_long1 - cl0 : 0) * a.nblk_m;
+    const int n_all = a.n_split * a.ns_short;
+    const int lid = xcd_remap((int)blockIdx.x - a.n_main, n_all + n_long * (a.ns_long - a.ns_short));
+    if (lid < n_all) {
+      slice = lid / a.n_split;
+      tile = a.n_main + (lid - slice * a.n_split);
+    } else {
+      const int r = lid - n_all;
+      slice = a.ns_short + r / n_long;
+      tile = cl0 * a.nblk_m + r % n_long;
+    }
+    nslices = col_slices(a, tile / a.nblk_m);
+  }
+  const bool sliced = (int)blockIdx.x >= a.n_main;
+  const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
+  const int m0 = mblk * BM, n0 = nblk * BN;
+  // Reduction work list: stages (channel tile cc, tap) with the tap's depth index in the live range of this
+  // tile (depth-major launches skip the depth taps that see only padding; otherwise every tap), cc-major.
+  const int khw = a.kh * a.kw;
+  int zlo, zhi;
+  live_depth_taps(a, n0, BN, zlo, zhi);
+  const int taps_live = (zhi - zlo + 1) * khw;
+  const int nstages_all = CTAP ? (a.cin / KC) * taps_live : a.kpad / KC;
+  const int c_begin = (int)((long)slice * nstages_all / nslices);
+  const int c_end = (int)((long)(slice + 1) * nstages_all / nslices);
+
+  f32x16 acc[TM][TN];
+  conv_reduce_segment<TM, TN, WM, WN, KC, MODE>(a, m0, n0, c_begin, c_end, zlo, zhi, nstages_all, As, Bs, acc);
   if (sliced)
     conv_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
   else
     conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+}
+
+// ------------------------------------------------------------------------------------------
+// Stream-K form of the gather kernel (round 3; the strided 3x3x3 convs res4a_1 / res4a_down / res5a_1 / res5a_down).
+// One tile per workgroup leaves these launches with 392 (100) tiles for 256 CUs; cutting every tile's reduction into
+// 4 (5) slices, as rounds 1-2 did, balances them to 6.1 -> 7 workgroups on the fullest CU (87 %), writes and re-reads
+// every partial sum (205 MB per res4a launch) and needs a second launch to reduce them.  Here sk_wgs persistent
+// workgroups (two per CU) each take an equal share of the launch's STAGES -- unit u = (tile, stage), tiles in
+// (column, M-block) order with the column's own live stage count (depth-major launches skip dead depth taps) --
+// wherever the tile boundaries fall.  A workgroup walks its range from the END.  Whole tiles go straight to the
+// epilogue.  A tile shared with other workgroups leaves as a partial block in the workspace (16-byte write-through
+// stores): block 2w+1 with a published flag when the tile's last stage lies in a later workgroup (always the range's
+// first segment, so it is out early), block 2w when it lies here (always the last segment).  After its loop the
+// workgroup that owns a shared tile's last stage rebuilds the sum from memory -- its own block, then the hand-off blocks
+// of the earlier workgroups, nearest first down to the one with the tile's first stage: an order fixed by the geometry,
+// not by timing -- and runs the epilogue.  (Adding the others' partials to the live accumulators instead, before or
+// after the main loop, either serialised the finisher behind its neighbours or spilled 330 registers.)  Waits only ever
+// point at lower-numbered workgroups, which the hardware dispatches first.  No second launch.
+//
+// MEASURED (profiles/r03_notes.md): correct, balanced -- and no faster than the split launches (2.39 against 2.42 ms for
+// the four convs).  Workgroups at different reduction stages of different tiles read different rows of the packed weights
+// and different input planes at the same time: L2 hit rate 0.65 against 0.93, 6.7x the HBM reads, 16 % more time per
+// stage -- what the even shares win, the lost locality spends.  The planner therefore keeps the split launches
+// (slice-major order: every resident workgroup is in the same part of the reduction); ECO_STREAMK=1 selects this kernel.
+template <int TM, int TN, int WM, int WN, int KC>
+__global__ __launch_bounds__(256, 2) void conv_streamk_kernel(const ConvKernelArgs a) {
+  constexpr int BM = 32 * TM * WM;
+  constexpr int BN = 32 * TN * WN;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) float As[2][KC][BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][KC][BN];
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+#ifdef ECO_EMU
+  const int w = (int)blockIdx.x;        // the emulator runs blocks in index order, possibly on one host thread
+#else
+  const int w = xcd_remap((int)blockIdx.x, a.sk_wgs);   // neighbouring tiles on one XCD
+#endif
+  const long U = a.sk_units;
+  const long u0 = U * w / a.sk_wgs, u1 = U * (w + 1) / a.sk_wgs;
+
+  int fin_m0 = -1, fin_n0 = 0;       // the shared tile this workgroup finishes (if any) and the unit of its first stage
+  long fin_first = 0;
+  long u_hi = u1;
+  while (u_hi > u0) {
+    // the tile that holds unit u_hi - 1: column by bisection over the prefix table (scaled by the M-blocks)
+    int lo = 0, hi = a.nblk_n;           // invariant: cum[lo] * nblk_m <= u_hi - 1 < cum[hi] * nblk_m
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((long)ld(a.sk_cum + mid) * a.nblk_m <= u_hi - 1) lo = mid; else hi = mid;
+    }
+    const int col = lo;
+    const long col_u0 = (long)ld(a.sk_cum + col) * a.nblk_m;
+    const int ns = ld(a.sk_cum + col + 1) - ld(a.sk_cum + col);        // stages of a tile of this column
+    const int mblk = (int)((u_hi - 1 - col_u0) / ns);
+    const long tile_u0 = col_u0 + (long)mblk * ns;
+    const long seg_lo = u0 > tile_u0 ? u0 : tile_u0;
+    const int c_begin = (int)(seg_lo - tile_u0), c_end = (int)(u_hi - tile_u0);
+    const int m0 = mblk * BM, n0 = col * BN;
+    int zlo, zhi;
+    live_depth_taps(a, n0, BN, zlo, zhi);
+
+    f32x16 acc[TM][TN];
+    conv_reduce_segment<TM, TN, WM, WN, KC, ECO_CONV_MODE_CTAP>(a, m0, n0, c_begin, c_end, zlo, zhi, ns, As, Bs, acc);
+
+    if (c_begin == 0 && c_end == ns) {
+      conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);      // a whole tile
+    } else {
+      // A shared tile: this range's stages go to the workspace as a partial block -- block 2w + 1 if the tile's last
+      // stage lies in a later workgroup (always this range's first segment: handed off, flag published), block 2w if
+      // it lies here (always the last segment: this workgroup finishes the tile below, once the others are in).
+      const bool handoff = c_end < ns;
+      float* pb = a.ws + (((long)(2 * w + (handoff ? 1 : 0))) * 4 + wave) * (TM * TN * 16 * 64) + 4 * lane;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {   // one address register pair per 32x32 tile, the four register groups by immediate
+          st_writethrough16<0>(pb, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+          st_writethrough16<1024>(pb, make_float4(acc[i][j][4], acc[i][j][5], acc[i][j][6], acc[i][j][7]));
+          st_writethrough16<2048>(pb, make_float4(acc[i][j][8], acc[i][j][9], acc[i][j][10], acc[i][j][11]));
+          st_writethrough16<3072>(pb, make_float4(acc[i][j][12], acc[i][j][13], acc[i][j][14], acc[i][j][15]));
+          pb += 1024;
+          ECO_OPAQUE64(pb);
+        }
+      wait_own_stores();
+      __syncthreads();
+      if (handoff) {
+        if (tid == 0) flag_publish(a.sk_flags + w, 1);
+      } else {
+        fin_m0 = m0; fin_n0 = n0; fin_first = tile_u0;      // finish it after the loop
+      }
+    }
+    __syncthreads();   // As / Bs are reused by the next segment
+    u_hi = seg_lo;
+  }
+  if (fin_m0 < 0) return;
+  // Finish the shared tile: own block + the hand-off blocks of the earlier workgroups that hold its other stages (nearest
+  // first, down to the one with the tile's first stage: an order fixed by the geometry), then the epilogue.  The
+  // accumulators are rebuilt from memory here -- with nothing of the reduction live any more -- instead of being carried
+  // out of the main loop and merged with a second definition (that merge cost the kernel 330 spilled registers).
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  for (int w2 = w; w2 >= 0; --w2) {
+    if (w2 < w) {
+      if (tid == 0) flag_wait(a.sk_flags + w2, 1);
+      __syncthreads();
+    }
+    const float* blk = a.ws + (((long)(2 * w2 + (w2 < w ? 1 : 0))) * 4 + wave) * (TM * TN * 16 * 64) + 4 * lane;
+#pragma unroll
+    for (int t0 = 0; t0 + 4 <= TM * TN; t0 += 4) {   // four 32x32 tiles = sixteen 16-byte loads per round trip
+      float4 q[4][4];
+      ld_partial_tiles4(blk + t0 * 1024, q);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x16& c = acc[(t0 + t) / TN][(t0 + t) % TN];
+          c[4 * g] += q[t][g].x; c[4 * g + 1] += q[t][g].y; c[4 * g + 2] += q[t][g].z; c[4 * g + 3] += q[t][g].w;
+        }
+      sched_fence();
+    }
+#pragma unroll
+    for (int t = (TM * TN) / 4 * 4; t < TM * TN; ++t) {   // 2- and 6-tile waves: the rest one tile at a time
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = ld_device_scope(blk + t * 1024 + (r >> 2) * 256 + (r & 3));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t / TN][t % TN][r] += v[r];
+      sched_fence();
+    }
+    if (w2 < w && U * w2 / a.sk_wgs <= fin_first) break;       // w2's range holds the tile's first stage
+  }
+  conv_epilogue<TM, TN>(a, acc, fin_m0 + wm * TM * 32, fin_n0 + wn * TN * 32, half, l31);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1136,6 +1319,7 @@ extern "C" int eco_conv_plan_create_batched(const eco_conv_geom* g, int32_t num_
   plan->ksplit = 1;
   plan->split_tiles = 0;
   plan->ws_bytes = 0;
+  plan->streamk_wgs = 0;
   if (plan->mode != ECO_CONV_MODE_POINT) {
     const long s_out = (long)g->out[0] * g->out[1] * g->out[2];
     const long ntot = (long)g->n * s_out;
@@ -1186,6 +1370,21 @@ extern "C" int eco_conv_plan_create_batched(const eco_conv_geom* g, int32_t num_
         if (sp >= 2 && rem < tiles) { plan->ksplit = (int)sp; plan->split_tiles = (int)rem; }
       }
     }
+    // Stream-K (conv_streamk_kernel), opt-in (ECO_STREAMK=1 in the environment when the plan is made), where the few-tile
+    // rule above would cut EVERY tile of a single CTAP launch: two persistent workgroups per CU share the launch's
+    // stages evenly across tile boundaries -- no quantisation, at most two partial blocks per workgroup instead of one
+    // per (tile, slice), no reduce launch; measured no faster than the split it replaces (lost L2 locality, see the
+    // kernel).  The column prefix table rides behind the gather table.
+    plan->streamk_wgs = 0;
+    static const bool want_streamk = getenv("ECO_STREAMK") != nullptr;   // opt-in: measured no faster (see the kernel)
+    if (want_streamk && plan->ksplit > 1 && plan->split_tiles == tiles && plan->mode == ECO_CONV_MODE_CTAP && batch == 1 &&
+        (long)nstages * tiles >= 16L * 2 * num_cu) {
+      plan->streamk_wgs = 2 * num_cu;
+      plan->ksplit = 1;
+      plan->split_tiles = 0;
+      plan->ws_bytes = ((int64_t)2 * plan->streamk_wgs * bm * plan->bn * 4 + 255) / 256 * 256 + (int64_t)plan->streamk_wgs * 4;
+      plan->ktab_elems = plan->kpad + ncols + 1;
+    }
     if (plan->ksplit > 1) {
       const long split_cols = plan->split_tiles / mblocks;   // N-blocks in the split region
       long split_pos = split_cols * plan->bn;
@@ -1235,6 +1434,18 @@ extern "C" int eco_conv_pack_weights(const eco_conv_geom* g, const eco_conv_plan
     const int mstep = paired ? 2 : 1;
     const long wk = (long)c * taps + tap;  // column of w[cout][cin*taps]
     for (int m = 0; m < g->cout; ++m) row[(long)m * mstep] = w[(long)m * K + wk];
+  }
+  if (plan->streamk_wgs > 0) {
+    // stream-K: stages of one M-block's tiles in the columns ahead of each column (dead depth taps skipped as the kernel
+    // skips them), ncols + 1 entries behind the gather table
+    const long ntot = (long)g->n * g->out[0] * g->out[1] * g->out[2];
+    const long ncols = ceil_div(ntot, plan->bn);
+    ECO_REQUIRE(plan->ktab_elems >= plan->kpad + ncols + 1, "conv pack: plan has no room for the stream-K table");
+    int32_t cum = 0;
+    for (long c = 0; c <= ncols; ++c) {
+      ktab[plan->kpad + c] = cum;
+      if (c < ncols) cum += (g->cin / plan->kc) * host_col_nz(g, plan->mode, plan->bn, c) * g->kernel[1] * g->kernel[2];
+    }
   }
   return ECO_OK;
 }
@@ -1361,6 +1572,7 @@ static int conv_forward_impl(const eco_conv_geom* g, const eco_conv_plan* plan, 
   ECO_REQUIRE(plan->ksplit == 1 || (int64_t)plan->ksplit * a.cout * (a.ntot - a.n_split0) * 4 <= plan->ws_bytes,
               "conv: plan workspace too small");
   a.ws = (float*)workspace;
+  a.sk_wgs = 0; a.sk_units = 0; a.sk_cum = nullptr; a.sk_flags = nullptr;
   a.batch = batch;
   a.bstride_x = stride_x; a.bstride_w = stride_wp; a.bstride_out = stride_out;
   a.bstride_ws = plan->ws_bytes / 4;
@@ -1377,6 +1589,30 @@ static int conv_forward_impl(const eco_conv_geom* g, const eco_conv_plan* plan, 
       case 32: return launch_conv_point<1, 2, 1, 4>(a, s);
       default: return fail(ECO_ERR_INVALID, "conv: unsupported point-kernel tile bm=%d", plan->bm);
     }
+  }
+  if (plan->streamk_wgs > 0) {
+    ECO_REQUIRE(mode == ECO_CONV_MODE_CTAP && batch == 1 && plan->ksplit == 1 && workspace != nullptr && ktab != nullptr,
+                "conv: bad stream-K plan (CTAP single launches with a workspace)");
+    const int64_t blocks = ((int64_t)2 * plan->streamk_wgs * plan->bm * plan->bn * 4 + 255) / 256 * 256;   // two per workgroup
+    ECO_REQUIRE(blocks + (int64_t)plan->streamk_wgs * 4 <= plan->ws_bytes && plan->ktab_elems >= plan->kpad + a.nblk_n + 1,
+                "conv: stream-K plan workspace / table too small");
+    a.sk_wgs = plan->streamk_wgs;
+    a.sk_cum = ktab + plan->kpad;
+    a.sk_flags = (int*)((char*)workspace + blocks);
+    // total stages: the prefix table's last entry x M-blocks, recomputed here (host side) from the geometry
+    long cum = 0;
+    for (long c = 0; c < a.nblk_n; ++c) cum += (long)(g->cin / plan->kc) * host_col_nz(g, mode, plan->bn, c) * g->kernel[1] * g->kernel[2];
+    a.sk_units = cum * a.nblk_m;
+    if (hipMemsetAsync(a.sk_flags, 0, (size_t)a.sk_wgs * 4, s) != hipSuccess)
+      return fail(ECO_ERR_RUNTIME, "conv: cannot clear the stream-K flags");
+    const dim3 grid((unsigned)a.sk_wgs), block(256);
+    if (plan->bm == 128 && plan->bn == 256) hipLaunchKernelGGL((conv_streamk_kernel<2, 4, 2, 2, 16>), grid, block, 0, s, a);
+    else if (plan->bm == 128 && plan->bn == 128) hipLaunchKernelGGL((conv_streamk_kernel<2, 2, 2, 2, 16>), grid, block, 0, s, a);
+    else if (plan->bm == 96) hipLaunchKernelGGL((conv_streamk_kernel<3, 2, 1, 4, 16>), grid, block, 0, s, a);
+    else if (plan->bm == 64) hipLaunchKernelGGL((conv_streamk_kernel<2, 2, 1, 4, 16>), grid, block, 0, s, a);
+    else if (plan->bm == 32) hipLaunchKernelGGL((conv_streamk_kernel<1, 2, 1, 4, 16>), grid, block, 0, s, a);
+    else return fail(ECO_ERR_INVALID, "conv: unsupported stream-K tile %dx%d", plan->bm, plan->bn);
+    return check_launch("eco_conv_forward(stream-K)");
   }
   switch (plan->bm) {
     case 128:

@@ -6,6 +6,8 @@
 #pragma once
 
 #ifdef ECO_EMU
+#include <sched.h>
+
 #include "hip_emu.h"
 #else
 #include <hip/hip_runtime.h>
@@ -202,6 +204,87 @@ __device__ __forceinline__ void st(T* p, T v) {
 template <typename T>
 __device__ __forceinline__ T ld_su(const void* uniform_base, unsigned lane_byte_offset) {
   return ld((const T*)((const char*)uniform_base + lane_byte_offset));
+}
+
+// ---- hand-offs between workgroups of ONE launch (stream-K partial sums) -------------------------------------------
+// Per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by other CUs' stores
+// (MI355X_MICROARCH.md, "inter-workgroup visibility").  The payload therefore leaves as 16-byte WRITE-THROUGH stores
+// (sc0 sc1: reaches memory, leaves no dirty line), the producing waves wait for theirs (vmcnt(0)), a workgroup barrier,
+// then one lane publishes a flag with a device-scope store; the consumer polls the flag with device-scope loads and
+// reads the payload with device-scope (sc1: L1-bypassing) loads.  No agent-scope release / acquire fences: a release
+// writes back every dirty line of the XCD's L2 and an acquire invalidates L1 and the L2's non-coherent lines -- one per
+// workgroup cost more than the whole kernel (profiles/r03_notes.md).
+// (OFF: compile-time byte offset < 4096, the instruction's immediate: four stores off one address register pair)
+template <int OFF>
+__device__ __forceinline__ void st_writethrough16(float* p, float4 v) {
+#ifdef ECO_EMU
+  st((float4*)((char*)p + OFF), v);
+#else
+  static_assert(OFF >= 0 && OFF < 4096, "");
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  const f32x4_t q = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc0 sc1" ::"v"(p), "v"(q), "n"(OFF) : "memory");
+#endif
+}
+__device__ __forceinline__ void wait_own_stores() {
+#ifndef ECO_EMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ float ld_device_scope(const float* p) {
+#ifdef ECO_EMU
+  return ld(p);
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// Sixteen 16-byte device-scope loads issued together and waited for once: four 32x32 tiles of a partial block (tile t
+// at p + t*1024 floats, its four register groups 1 KB apart by immediate).  The wait's asm statement carries every
+// destination as an in/out operand, so no use can move above it.  (With 4-byte device-scope loads, 16 in flight, the
+// 128 KB of one workgroup's partial took ~16 us -- on the critical path of the workgroup that finishes the tile.)
+__device__ __forceinline__ void ld_partial_tiles4(const float* p, float4 (&q)[4][4]) {
+#ifdef ECO_EMU
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) q[t][g] = ld((const float4*)(p + t * 1024 + g * 256));
+#else
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  f32x4_t r[16];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float* pt = p + t * 1024;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r[4 * t]) : "v"(pt) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024 sc1" : "=v"(r[4 * t + 1]) : "v"(pt) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:2048 sc1" : "=v"(r[4 * t + 2]) : "v"(pt) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:3072 sc1" : "=v"(r[4 * t + 3]) : "v"(pt) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]),
+                 "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])
+               :
+               : "memory");
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) q[t][g] = make_float4(r[4 * t + g][0], r[4 * t + g][1], r[4 * t + g][2], r[4 * t + g][3]);
+#endif
+}
+
+__device__ __forceinline__ void flag_publish(int* flag, int value) {
+#ifdef ECO_EMU
+  __atomic_store_n(flag, value, __ATOMIC_SEQ_CST);
+#else
+  __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// Spin (one lane, with s_sleep between polls) until *flag == value.
+__device__ __forceinline__ void flag_wait(const int* flag, int value) {
+#ifdef ECO_EMU
+  while (__atomic_load_n(flag, __ATOMIC_SEQ_CST) != value) sched_yield();   // (the producer block runs on another host thread)
+#else
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != value) __builtin_amdgcn_s_sleep(8);
+#endif
 }
 
 // Dynamic LDS of the launch as a float array (16-byte aligned; no static __shared__ may precede it).

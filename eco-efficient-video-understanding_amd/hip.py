@@ -48,7 +48,7 @@ class ConvPlan(C.Structure):
                 ("kpad", C.c_int32), ("mpad", C.c_int32),
                 ("wp_elems", C.c_int64), ("ktab_elems", C.c_int64),
                 ("mode", C.c_int32), ("ksplit", C.c_int32), ("ws_bytes", C.c_int64),
-                ("split_tiles", C.c_int32), ("reserved", C.c_int32)]
+                ("split_tiles", C.c_int32), ("streamk_wgs", C.c_int32)]
 
 
 class ConvBPlan(C.Structure):
@@ -111,6 +111,8 @@ def conv_kernel_name(plan: ConvPlan) -> str:
     tm, tn, wm, wn = _CONV_TILES[(plan.bm, plan.bn)]
     if plan.mode == 2:
         return f"eco::conv_span_kernel<{tm}, {tn}, {wm}, {wn}>"
+    if plan.streamk_wgs > 0:
+        return f"eco::conv_streamk_kernel<{tm}, {tn}, {wm}, {wn}, {plan.kc}>"
     return f"eco::conv_mfma_kernel<{tm}, {tn}, {wm}, {wn}, {plan.kc}, {plan.mode}>"
 
 

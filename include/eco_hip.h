@@ -87,12 +87,14 @@ typedef struct eco_conv_plan {
   int32_t kpad;       /* k rounded up to a multiple of kc               */
   int32_t mpad;       /* cout rounded up to a multiple of 128           */
   int64_t wp_elems;   /* floats in the packed weight buffer  (kpad*mpad) */
-  int64_t ktab_elems; /* int32 entries in the gather table   (kpad)      */
+  int64_t ktab_elems; /* int32 entries in the gather table (kpad; stream-K plans: + columns + 1 for the stage prefix table) */
   int32_t mode;       /* ECO_CONV_MODE_*: reduction order of the packed weights / kernel family */
   int32_t ksplit;     /* >1: the last split_tiles output tiles have their reduction cut into ksplit slices */
   int64_t ws_bytes;   /* bytes of device scratch eco_conv_forward needs for this plan (0 if none) */
   int32_t split_tiles; /* 0 (no split-K), all tiles (few-tile layers) or the tail of a many-tile launch */
-  int32_t reserved;
+  int32_t streamk_wgs; /* >0: stream-K -- that many persistent workgroups share the launch's reduction stages evenly
+                        * across tile boundaries (ksplit = 1, split_tiles = 0; ws_bytes = two bm x bn blocks and one
+                        * flag per workgroup); chosen where every tile of a single launch would otherwise be split */
 } eco_conv_plan;
 
 /* Strided view of an N,C,[D,]H,W output (or residual) tensor.  Element

@@ -540,3 +540,42 @@ def test_conv_point_kernel_eligibility(backend):
     # plane size not a multiple of 4 (a lane's four positions would straddle images), strided 1x1: gather kernel
     assert lib.conv_plan(hip.conv_geom(64, 32, 64, (7, 7), (1, 1), (1, 1), (0, 0), (7, 7)), 1).mode == 1
     assert lib.conv_plan(hip.conv_geom(64, 32, 64, (8, 8), (1, 1), (2, 2), (0, 0), (4, 4)), 1).mode == 1
+
+
+# ---- stream-K form of the gather kernel (csrc/eco_conv.hip, conv_streamk_kernel) --------------------------------------
+def _force_streamk(wgs, bn=None):
+    def tweak(plan):
+        if bn:
+            plan.bn = bn
+        plan.ksplit, plan.split_tiles, plan.streamk_wgs = 1, 0, wgs
+        plan.ws_bytes = (2 * wgs * plan.bm * plan.bn * 4 + 255) // 256 * 256 + 4 * wgs      # two partial blocks + a flag per workgroup
+        plan.ktab_elems = plan.kpad + 4096
+    return tweak
+
+
+@pytest.mark.parametrize("mode", ["plain", "fused"])
+@pytest.mark.parametrize("wgs", [1, 2, 3, 5, 7, 16])
+def test_conv_streamk_shares_stages_across_tile_boundaries(backend, mode, wgs):
+    """A strided 3x3x3 conv (res4a_1's shape, scaled down: 2 M-blocks x 4 columns of 128 positions, depth-major with dead
+    depth taps in the first plane's columns) with its stages dealt to 1 .. 16 persistent workgroups: whole tiles, tiles
+    shared by two workgroups, a tile spread over three and more (16 workgroups on 8 tiles), a workgroup whose whole range
+    lies inside one tile -- every split the hand-off protocol knows."""
+    cfg = (2, 32, 256, (8, 8, 8), (3, 3, 3), (2, 2, 2), (1, 1, 1))        # out 4x4x4: ntot = 2*64 = 128 -> bn 128: 1 column
+    plan = run_conv(backend, *cfg, mode=mode, seed=wgs, tweak=_force_streamk(wgs, bn=128))
+    assert plan.mode == 1 and plan.streamk_wgs == wgs
+    cfg = (8, 32, 256, (8, 8, 8), (3, 3, 3), (2, 2, 2), (1, 1, 1))        # ntot = 512: four columns, one per depth plane
+    plan = run_conv(backend, *cfg, mode=mode, seed=10 + wgs, tweak=_force_streamk(wgs, bn=128))
+    assert (plan.bm, plan.bn) == (128, 128)
+
+
+def test_conv_streamk_plan_is_opt_in(backend, monkeypatch):
+    """The planner keeps the two-launch split for few-tile launches (stream-K measured no faster: the even shares lose
+    the split order's L2 locality); a stream-K plan made by hand is what `eco_conv_forward` runs, with the workspace
+    and table sizes the header states."""
+    lib = backend.lib
+    g = hip.conv_geom(32, 128, 256, (16, 28, 28), (3, 3, 3), (2, 2, 2), (1, 1, 1), (8, 14, 14))      # res4a_1: 392 tiles
+    p = lib.conv_plan(g, 256)
+    assert p.mode == 1 and (p.bm, p.bn) == (128, 256) and p.streamk_wgs == 0 and p.ksplit > 1 and p.split_tiles == 392
+    _force_streamk(512)(p)
+    assert hip.conv_kernel_name(p) == "eco::conv_streamk_kernel<2, 4, 2, 2, 16>"
+    assert p.ws_bytes == 2 * 512 * 128 * 256 * 4 + 4 * 512
