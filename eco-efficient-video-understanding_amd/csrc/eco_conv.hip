@@ -26,6 +26,7 @@
 // Output tile: lane = output position (32 consecutive positions per half-wave), register =
 // output channel -> each store instruction writes 128 contiguous bytes per half-wave into
 // the N,C,[D,]H,W destination.
+#include <float.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -139,9 +140,9 @@ __device__ __forceinline__ int col_slices(const ConvKernelArgs& a, int col) {
 // Work is ordered tile-row (i) -> 4-channel register group (g) -> tile-column (j) so that only
 // 12 per-channel parameters and 8 values are live at a time (keeps the kernel at the main
 // loop's register budget), and every batch of loads is issued before the stores that follow.
-template <int TM, int TN>
-__device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw,
-                                              int half, int l31) {
+template <int TM, int TN, bool PLAIN>
+__device__ __forceinline__ void conv_epilogue_impl(const ConvKernelArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw,
+                                                   int half, int l31) {
   long e_res[TN], e_raw[TN], e_act[TN], e_act2[TN];
   int e_img[TN], e_sp[TN];
   bool e_ok[TN];
@@ -195,9 +196,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&
         ps[q] = has_bn ? ld(a.bn_scale + chs) : 1.0f;
         ph[q] = has_bn ? ld(a.bn_shift + chs) : 0.0f;
       }
+      // Beside f32 MFMAs every VALU instruction is matrix-pipe time (profiles/r03_notes.md), and the 1x1 convolutions
+      // have one output per 100-160 MFMA k-steps: when the value v = acc + bias is not itself needed (no raw store, no
+      // residual) the bias goes into the shift once per channel -- (acc + b)*s + h = acc*s + (b*s + h) -- and ReLU is one
+      // v_max against 0 or -FLT_MAX instead of a compare-and-select.
+      constexpr bool plain_act = PLAIN;          // (!has_res && !has_raw, decided once per kernel: conv_epilogue below)
+      const float floor_v = relu ? 0.0f : -FLT_MAX;
+      float ph2[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ph2[q] = pb[q] * ps[q] + ph[q];
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if (!e_ok[j]) continue;
+        if constexpr (plain_act) {
+          if (has_act) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float y = fmaxf(acc[i][j][4 * g + q] * ps[q] + ph2[q], floor_v);
+              if (chg + q < a.cout) {
+                st(aptr + e_act[j] + (long)(chg + q) * astride_c, y);
+                if (has_act2) st(a.act2.ptr + e_act2[j] + (long)(chg + q) * a.act2.stride_c, y);
+              }
+            }
+          }
+          continue;
+        }
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q] + pb[q];
@@ -218,8 +241,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&
         if (has_act) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            float y = v[q] * ps[q] + ph[q];
-            if (relu) y = fmaxf(y, 0.0f);
+            const float y = fmaxf(v[q] * ps[q] + ph[q], floor_v);
             if (chg + q < a.cout) {
               st(aptr + e_act[j] + (long)(chg + q) * astride_c, y);
               if (has_act2) st(a.act2.ptr + e_act2[j] + (long)(chg + q) * a.act2.stride_c, y);
@@ -229,6 +251,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&
       }
     }
   }
+}
+
+// The two forms as separate code (one run-time branch per kernel; as one loop nest the unroller gave up on the doubled
+// body and the accumulators went to scratch memory).
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw, int half,
+                                              int l31) {
+  if (a.residual.ptr == nullptr && a.raw.ptr == nullptr) conv_epilogue_impl<TM, TN, true>(a, acc, mw, nw, half, l31);
+  else conv_epilogue_impl<TM, TN, false>(a, acc, mw, nw, half, l31);
 }
 
 // Split-K: a workgroup that only covered a slice of the reduction stores its raw accumulators to

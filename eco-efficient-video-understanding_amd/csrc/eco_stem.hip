@@ -183,8 +183,20 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
   const float* wl = Ws + half * COUT + l31;               // A[m = l31 (+32 i)][k = 2 kp + half]
   // pooling threads: 14 x 8 pooled positions x 2 channel phases = 224 of the 256
   const int pw = tid % kStemPW, ph = (tid / kStemPW) % kStemPH, clo = tid / (kStemPW * kStemPH);
-  const float* const sp0 = Ss + clo * STAGE_LD + 2 * ph * kStemCQ + 2 * pw;
-  float* const sw0 = Ss + 4 * half * STAGE_LD + wave * 128 + l31;
+  // The pooling stage keeps a conv row's 29 columns parity split as well (15 even, then 14 odd): the 3x3 stride-2 windows
+  // of consecutive pooled columns then read consecutive words (conflict-free ds_read_b32; plain order read them at a
+  // two-word lane stride), at the price of 2-way conflicted ds_write_b32 in the epilogue -- which the LDS serves at
+  // full rate (MI355X_MICROARCH.md, LDS).
+  const float* const sp0 = Ss + clo * STAGE_LD + 2 * ph * kStemCQ + pw;
+  int soff[4];                                            // stage word of this lane's four conv positions
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int p = wave * 128 + j * 32 + l31;
+    if (p >= kStemNPos) p = kStemNPos - 1;
+    const int r = p / kStemCQ, q = p - r * kStemCQ;
+    soff[j] = r * kStemCQ + (q & 1) * ((kStemCQ + 1) / 2) + (q >> 1);
+  }
+  float* const sw0 = Ss + 4 * half * STAGE_LD;
   const long ych = (long)a.PHo * a.PWo;
   const float relu_floor = a.relu ? 0.0f : -FLT_MAX;
 
@@ -268,7 +280,8 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx)
-        woff[dy * 3 + dx] = (r0 + 2 * ph + dy < a.Ho && q0 + 2 * pw + dx < a.Wo) ? dy * kStemCQ + dx : 0;
+        woff[dy * 3 + dx] = (r0 + 2 * ph + dy < a.Ho && q0 + 2 * pw + dx < a.Wo)
+                                ? dy * kStemCQ + (dx & 1) * ((kStemCQ + 1) / 2) + (dx >> 1) : 0;
     float* const yp0 = a.y + (((long)f * a.cout + clo) * a.PHo + gph) * a.PWo + gpw;
 #if defined(ECO_STEM_PROBE) && (ECO_STEM_PROBE & 2)   // bit 1 drops the epilogue (the accumulators stay live)
     if (a.total < 0) {
@@ -291,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
           const int cl0 = (rr & 3) + 8 * (rr >> 2);        // + 4*half: this lane's channel within the 16
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (j < 3 || last_col_ok) sw0[cl0 * STAGE_LD + j * 32] = acc[i][j][r];
+            if (j < 3 || last_col_ok) sw0[cl0 * STAGE_LD + soff[j]] = acc[i][j][r];
         }
         __syncthreads();
         if (pool_thread) {
