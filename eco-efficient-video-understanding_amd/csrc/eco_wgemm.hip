@@ -391,6 +391,8 @@ __device__ __forceinline__ void wino_output_store(const WinoOutDmArgs& a, const 
   const float b = a.bias ? ld_su<float>(a.bias, cho) : 0.0f;
   const float sc = a.bn_scale ? ld_su<float>(a.bn_scale, cho) : 1.0f, sh = a.bn_scale ? ld_su<float>(a.bn_shift, cho) : 0.0f;
   const float floor_v = a.relu ? 0.0f : -3.402823466e38f;   // one v_max instead of v_max + v_cndmask per output
+  const bool plain = a.act.ptr && !a.residual.ptr && !a.raw.ptr;
+  const float sh2 = b * sc + sh;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int h = 4 * th + p;
@@ -402,10 +404,18 @@ __device__ __forceinline__ void wino_output_store(const WinoOutDmArgs& a, const 
     for (int q0 = 0; q0 < 4; q0 += VEC) {
       const int w0 = 4 * tw + q0;
       if (w0 >= a.W) continue;  // W % VEC == 0: the VEC outputs are inside or outside together
+      const int sp = (d * a.H + h) * a.W + w0;
+      if (plain) {   // only the activated value is wanted: (y + b)*sc + sh = y*sc + (b*sc + sh), one FMA and one max per output
+        vec_t ov;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) ((float*)&ov)[e] = fmaxf(yrow[q0 + e] * sc + sh2, floor_v);
+        st((vec_t*)(a.act.ptr + o.act + sp), ov);
+        if (a.act2.ptr) st((vec_t*)(a.act2.ptr + o.act2 + sp), ov);
+        continue;
+      }
       float val[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) val[e] = yrow[q0 + e] + b;
-      const int sp = (d * a.H + h) * a.W + w0;
       if (a.residual.ptr) {
         const vec_t rv = ld((const vec_t*)((const float*)a.residual.ptr + o.res + sp));
 #pragma unroll

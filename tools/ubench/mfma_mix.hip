@@ -1,4 +1,4 @@
-// What does one extra instruction of each class cost the f32 MFMA stream of the SAME wave on gfx950?
+// What does one extra instruction of each class cost the f32 (and, MF16 = 2, the bf16 32x32x16) MFMA stream of the SAME wave on gfx950?
 // One wave per SIMD (256-thread workgroup per CU, launch_bounds(256,1)) or two (512 threads); per iteration 16
 // v_mfma_f32_32x32x2_f32 (= 1024 cycles of matrix pipe) or 32 v_mfma_f32_16x16x4_f32, plus N fillers issued from
 // inline asm between them.  Reports cycles per iteration at the measured time (assuming 2.3 GHz) and the cost per filler.
@@ -7,6 +7,7 @@
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 enum { F_NONE, F_VFMA, F_VMOV, F_DS32, F_DS64, F_DS128, F_SALU, F_DSW32, F_VFMA_DEP };
 
@@ -21,6 +22,8 @@ __global__ __launch_bounds__(512) void k(float* out, const float* in, int iters)
   for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   for (int j = 0; j < 8; ++j) for (int r = 0; r < 4; ++r) acc4[j][r] = 0.f;
   const float a = in[tid], b = in[tid + 64];
+  bf16x8 ab, bb;
+  for (int e = 0; e < 8; ++e) { ab[e] = (__bf16)in[tid + e]; bb[e] = (__bf16)in[tid + 8 + e]; }
   float v[8];
   for (int j = 0; j < 8; ++j) v[j] = in[tid + j];
   const float m = in[tid + 100], c = in[tid + 101];
@@ -30,7 +33,9 @@ __global__ __launch_bounds__(512) void k(float* out, const float* in, int iters)
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      if (MF16) {
+      if (MF16 == 2) {
+        acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, acc[u & 3], 0, 0, 0);
+      } else if (MF16) {
         acc4[(2 * u) & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc4[(2 * u) & 7], 0, 0, 0);
         acc4[(2 * u + 1) & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc4[(2 * u + 1) & 7], 0, 0, 0);
       } else {
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(512) void k(float* out, const float* in, int iters)
   if (res == 12345.678f) out[blockIdx.x * 512 + tid] = res + d0 + d2.x + d4.x;
 }
 
-static float g_base[2][2];
+static float g_base[3][2];
 template <int FILL, int NF, int MF16>
 void run(const char* name, float* out, const float* in, int threads) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -73,7 +78,7 @@ void run(const char* name, float* out, const float* in, int threads) {
   const double cyc = ms * 1e-3 * 2.3e9 / iters;   // cycles per iteration per SIMD (both waves of a SIMD together)
   const double per = NF ? (ms - g_base[MF16][w]) * 1e-3 * 2.3e9 / iters / (NF * (threads / 256)) : 0.0;
   printf("%-12s %s waves/SIMD %d  fillers/iter %2d: %.3f ms  %7.1f cyc/iter  -> %5.1f cycles per filler\n",
-         MF16 ? "16x16x4" : "32x32x2", name, threads / 256, NF, ms, cyc, per);
+         MF16 == 2 ? "bf16 32x32x16" : MF16 ? "16x16x4" : "32x32x2", name, threads / 256, NF, ms, cyc, per);
 }
 
 template <int MF16>
@@ -96,6 +101,6 @@ int main() {
   hipMalloc(&in, 8192 * 4); hipMalloc(&out, 256 * 512 * 4);
   float h[8192]; for (int i = 0; i < 8192; ++i) h[i] = (rand() / (float)RAND_MAX) * 2 - 1;
   hipMemcpy(in, h, 8192 * 4, hipMemcpyHostToDevice);
-  for (int threads = 256; threads <= 512; threads += 256) { all<0>(out, in, threads); all<1>(out, in, threads); }
+  for (int threads = 256; threads <= 512; threads += 256) { all<0>(out, in, threads); all<1>(out, in, threads); all<2>(out, in, threads); }
   return 0;
 }
