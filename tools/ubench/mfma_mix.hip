@@ -9,7 +9,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-enum { F_NONE, F_VFMA, F_VMOV, F_DS32, F_DS64, F_DS128, F_SALU, F_DSW32, F_VFMA_DEP };
+enum { F_NONE, F_VFMA, F_VMOV, F_DS32, F_DS64, F_DS128, F_SALU, F_DSW32, F_VFMA_DEP, F_PKFMA, F_PKADD, F_VADD, F_GLD16, F_2VADD, F_4VADD };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int FILL, int NF, int MF16>
 __global__ __launch_bounds__(512) void k(float* out, const float* in, int iters) {
@@ -30,6 +31,10 @@ __global__ __launch_bounds__(512) void k(float* out, const float* in, int iters)
   unsigned addr = (unsigned)(tid & 63) * 16u;
   float d0, d1; float2 d2; float4 d4;
   int sacc = iters;
+  f32x2 pv[8], pm = {m, c}, pc = {c, m};
+  for (int j = 0; j < 8; ++j) { pv[j][0] = in[tid + j]; pv[j][1] = in[tid + j + 9]; }
+  f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
+  const float* gp = in + (tid & 63) * 4;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
@@ -49,16 +54,24 @@ __global__ __launch_bounds__(512) void k(float* out, const float* in, int iters)
         if (FILL == F_DS64) asm volatile("ds_read_b64 %0, %1" : "=v"(d2) : "v"(addr));
         if (FILL == F_DS128) asm volatile("ds_read_b128 %0, %1" : "=v"(d4) : "v"(addr));
         if (FILL == F_DSW32) asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(m));
+        if (FILL == F_PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pv[u & 7]) : "v"(pm), "v"(pc));
+        if (FILL == F_PKADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pv[u & 7]) : "v"(pm));
+        if (FILL == F_VADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[u & 7]) : "v"(m));
+        if (FILL == F_2VADD) asm volatile("v_add_f32 %0, %0, %2\n v_add_f32 %1, %1, %2" : "+v"(v[u & 7]), "+v"(v[(u + 1) & 7]) : "v"(m));
+        if (FILL == F_4VADD) asm volatile("v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %4" : "+v"(v[u & 7]), "+v"(v[(u + 1) & 7]), "+v"(v[(u + 2) & 7]), "+v"(v[(u + 3) & 7]) : "v"(m));
+        if (FILL == F_GLD16) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(g4) : "v"(gp));
         if (FILL == F_SALU) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc));
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (FILL == F_DS32 || FILL == F_DS64 || FILL == F_DS128 || FILL == F_DSW32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (FILL == F_GLD16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   float res = (float)sacc;
   for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) res += acc[j][r];
   for (int j = 0; j < 8; ++j) for (int r = 0; r < 4; ++r) res += acc4[j][r];
-  for (int j = 0; j < 8; ++j) res += v[j];
+  for (int j = 0; j < 8; ++j) res += v[j] + pv[j][0] + pv[j][1];
+  res += g4[0];
   if (res == 12345.678f) out[blockIdx.x * 512 + tid] = res + d0 + d2.x + d4.x;
 }
 
@@ -94,6 +107,13 @@ void all(float* out, const float* in, int threads) {
   run<F_DS128, 8, MF16>("ds_read128", out, in, threads);
   run<F_DSW32, 16, MF16>("ds_write32", out, in, threads);
   run<F_SALU, 16, MF16>("s_add     ", out, in, threads);
+  run<F_VADD, 16, MF16>("v_add     ", out, in, threads);
+  run<F_2VADD, 16, MF16>("2x v_add  ", out, in, threads);
+  run<F_4VADD, 16, MF16>("4x v_add  ", out, in, threads);
+  run<F_4VADD, 4, MF16>("4x v_add  ", out, in, threads);
+  run<F_PKFMA, 16, MF16>("v_pk_fma  ", out, in, threads);
+  run<F_PKADD, 16, MF16>("v_pk_add  ", out, in, threads);
+  run<F_GLD16, 16, MF16>("gload x4  ", out, in, threads);
 }
 
 int main() {
