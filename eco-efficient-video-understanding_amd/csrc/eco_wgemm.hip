@@ -576,7 +576,15 @@ __global__ __launch_bounds__(256, 2) void wfused_kernel(const WFusedArgs a) {
     const int p = 6 * (g == 0 ? 1 + rr : g == 1 ? 3 + rr : 5 * rr) + lp - 6 * rr;
     // wave-uniform bases (SALU) + this lane's constant byte offset: no per-lane address arithmetic per load
     const float* us = a.u + (long)p * a.u_pstride + ((long)mb * KP + c * CH) * 64;
+#if defined(ECO_WFUSED_PROBE) && (ECO_WFUSED_PROBE & 32)   // bit 5 = waves 2k and 2k+1 load the same V rows (does the L1 merge them?)
+    const int lpv = (wave & ~1) + 4 * (pi % 3), rrv = lpv >= 6 ? 1 : 0;
+    const int pv = 6 * (g == 0 ? 1 + rrv : g == 1 ? 3 + rrv : 5 * rrv) + lpv - 6 * rrv;
+    const float* vs = a.v + (long)pv * a.v_pstride + ((long)(c * (CH / 4)) * a.Q + n0) * 8;
+#elif defined(ECO_WFUSED_PROBE) && (ECO_WFUSED_PROBE & 64)   // bit 6 = ... the same U rows
     const float* vs = a.v + (long)p * a.v_pstride + ((long)(c * (CH / 4)) * a.Q + n0) * 8;
+#else
+    const float* vs = a.v + (long)p * a.v_pstride + ((long)(c * (CH / 4)) * a.Q + n0) * 8;
+#endif
 #pragma unroll
     for (int k4 = 0; k4 < CH / 4; ++k4) ra[slot][k4] = ld_su<float4>(us + k4 * 256, a_voff);
 #pragma unroll
@@ -606,6 +614,19 @@ __global__ __launch_bounds__(256, 2) void wfused_kernel(const WFusedArgs a) {
     sched_fence();
     if constexpr (t + R < T) issue(t % R, t + R);
     sched_fence();
+#if defined(ECO_WFUSED_PROBE) && (ECO_WFUSED_PROBE & 8)     // bit 3 = no LDS parking, no barriers, no fold
+    if constexpr (t % NCH == NCH - 1) {
+      asm volatile("" ::"v"(acc));       // the products stay live, nothing is emitted
+      if constexpr (t == T - 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) s4[u][i][j] = acc[(4 * u + i + j) & 15];
+      }
+    }
+#else
     if constexpr (t % NCH == NCH - 1) {
       constexpr int pi = t / NCH;
       const int lp = wave + 4 * (pi % 3);
@@ -637,9 +658,19 @@ __global__ __launch_bounds__(256, 2) void wfused_kernel(const WFusedArgs a) {
         if (g < 2) __syncthreads();
       }
     }
+#endif
   });
   const int tpp = a.o.TH * a.o.TW;
   const int r = n0 + col;
+#if defined(ECO_WFUSED_PROBE) && (ECO_WFUSED_PROBE & 16)   // bit 4 = no second transform half / epilogue / stores
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(s4[u][i][j]));   // the fold stays live
+  if (a.o.NB < 0)
+#endif
   if (r < a.o.NB) {
     const int img = r / tpp, tt = r - img * tpp;
     const int th = tt / a.o.TW, tw = tt - th * a.o.TW;

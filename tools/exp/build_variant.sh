@@ -11,7 +11,7 @@ make -s -C $CSRC -j8 all
 OBJS=""
 for f in eco_api eco_conv eco_ops eco_wino eco_blocked eco_wgemm eco_stem; do
   if [ $f = $SRC ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=default "$@" -c $CSRC/$f.hip -o /tmp/${f}_$NAME.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=default -fno-slp-vectorize "$@" -c $CSRC/$f.hip -o /tmp/${f}_$NAME.o
     OBJS="$OBJS /tmp/${f}_$NAME.o"
   else
     OBJS="$OBJS $CSRC/build/$f.o"
