@@ -545,14 +545,18 @@ struct WFusedArgs {
   long v_pstride, u_pstride;
 };
 
+#ifndef ECO_WFUSED_R
+#define ECO_WFUSED_R 3
+#define ECO_WFUSED_OCC 2
+#endif
 template <int KP, int VEC>
-__global__ __launch_bounds__(256, 2) void wfused_kernel(const WFusedArgs a) {
+__global__ __launch_bounds__(256, ECO_WFUSED_OCC) void wfused_kernel(const WFusedArgs a) {
   const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   constexpr int CH = 16;                 // k-pairs per chunk
   constexpr int NCH = KP / CH;           // chunks per point
   constexpr int NPT = 9;                 // points per wave: three per group
   constexpr int T = NPT * NCH;           // chunks per wave
-  constexpr int R = 3;                   // chunks in flight: 3 x 8 sixteen-byte loads per lane (4 would spill)
+  constexpr int R = ECO_WFUSED_R;        // chunks in flight: 3 x 8 sixteen-byte loads per lane (4 would spill)
   static_assert(KP % CH == 0, "");
   ECO_DYNAMIC_LDS(lds);                  // M[12][32][32]: the group's points, local index lp = 6*(0 | 1: which row of the pair) + column
   const int tid = (int)threadIdx.x;
@@ -645,6 +649,12 @@ __global__ __launch_bounds__(256, 2) void wfused_kernel(const WFusedArgs a) {
           for (int j = 0; j < 6; ++j) {
             const float ma = lds[((j * 32) + mrow0 + 8 * u) * 32 + col];
             const float mb2 = lds[(((6 + j) * 32) + mrow0 + 8 * u) * 32 + col];
+#if defined(ECO_WFUSED_PROBE) && (ECO_WFUSED_PROBE & 128)   // bit 7 = half of the partial transform's registers (timing only)
+            if (g == 0) { s4[u][0][j] = ma + mb2; s4[u][1][j] = ma - mb2; }
+            else if (g == 1) { s4[u][0][j] += ma + mb2; s4[u][1][j] += 2.0f * (ma - mb2); }
+            else { s4[u][2][j] = s4[u][0][j] + 4.0f * ma; s4[u][3][j] = s4[u][1][j] + mb2; }
+            continue;
+#endif
             if (g == 0) {          // rows 1, 2
               const float t1 = ma + mb2, t2 = ma - mb2;
               s4[u][0][j] = t1; s4[u][1][j] = t2; s4[u][2][j] = t1; s4[u][3][j] = t2;
