@@ -1,0 +1,330 @@
+// eco_stemb.hip -- the BN-Inception stem of the channel-blocked bf16 path as ONE kernel: conv1_7x7_s2 (3 -> cout, 7x7,
+// stride 2, pad 3) + bias + folded BN + ReLU + pool1_3x3_s2 (MAX 3x3, stride 2, Caffe ceil rule), fp32 frames in, pooled
+// activations out in the blocked layout Y[n][c/8][h][w][c%8] (bf16).
+//
+//   conv1_7x7_s2 / conv1_7x7_s2_bn / conv1_relu_7x7 / pool1_3x3_s2   models_ECO_Lite/kinetics/deploy.prototxt:8-77
+//   ConvolutionLayer::Forward (conv_layer.cpp:28-43, base_conv_layer.cpp:264-287), BN TEST branch
+//   (bn_layer.cpp:93-207), ReLU (relu_layer.cpp:10-20), PoolingLayer MAX (pooling_layer.cpp:131-147,199-237)
+//
+// Until round 3 the blocked path ran the stem as three launches -- eco_stem_pack_forward (frames -> zero-padded
+// pixel-interleaved bf16 image, 0.23 ms for 1024 frames), conv1 as a blocked convolution with 4 "channel blocks" (1.25 ms,
+// 0.21 of its floor: K = 7 x 32 for 147 real taps and 64 output channels per 16 KB position stage) and pool1 (0.40 ms) --
+// with conv1's 1.64 GB of bf16 output written and read back in between.  This kernel has the structure of the fp32
+// stem (eco_stem.hip): persistent workgroups, two per CU, walk 8 x 14 patches of POOLED outputs;
+//   * the packed weights (11 k-steps x cout x 16 bf16) stay in LDS for the workgroup's lifetime; the 39 x 64 x 3 input
+//     patch a pooled patch depends on is loaded once as fp32 (the next patch's words are in flight in registers under
+//     the current patch's work), rounded to bf16 -- the rounding eco_stem_pack_forward applies -- and stored row-major;
+//   * k is ordered (c, ky | kx): one MFMA k-step (16) = two kernel rows of 8 taps (kx = 7 has zero weights, as has the
+//     22nd row), so the B fragment of v_mfma_f32_32x32x16_bf16 -- eight consecutive k of one position -- is the eight
+//     consecutive patch elements starting at column 2q of row (c, 2r + ky): 16 bytes at a 4-byte aligned LDS address
+//     (two ds_read2_b32), a per-lane base plus a compile-time offset per k-step, no im2col, no masks;
+//   * 17 x 29 conv outputs (one halo row / column) = 512 position columns x cout in 11 x 8 MFMAs per wave -- 2.8 k
+//     cycles where the fp32 reduction takes 38 k -- then bias / BN in fp32 on the accumulators, 16 channels at a time
+//     through an fp32 LDS stage for the 3 x 3 stride-2 max, ReLU, and one 16-byte store per (pooled position, 8-channel
+//     block).  conv1's output never exists in HBM; the kernel is bound by its epilogue's LDS traffic, not by the MFMAs.
+// Arithmetic: bf16 operands (frames and weights rounded to nearest even), fp32 products and sums, fp32 bias / BN, one
+// rounding to bf16 at the store -- the blocked path's convention (eco_blocked.hip).  The MAX window commutes with that
+// rounding (monotonic), so the result equals pooling the rounded conv output.
+#include <float.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "eco_common.h"
+
+namespace eco {
+
+constexpr int kSbPH = 8, kSbPW = 14;                       // pooled patch per workgroup
+constexpr int kSbCR = 2 * kSbPH + 1, kSbCQ = 2 * kSbPW + 1;   // conv patch: 17 x 29
+constexpr int kSbNPos = kSbCR * kSbCQ;                     // 493 conv positions, padded to 512 columns
+constexpr int kSbIR = 2 * (kSbCR - 1) + 7;                 // 39 input rows per channel
+constexpr int kSbIQ = 64;                                  // stored columns per row: 63 + the zero-weight tap's column
+constexpr int kSbRows = 3 * kSbIR;                         // 117 patch rows
+constexpr int kSbSteps = 11;                               // 22 (c, ky) rows of 8 taps = 176 k, 16 per MFMA
+constexpr int kSbRowBytes = kSbIQ * 2;
+
+// byte offset of kernel row rho = c*7 + ky within the patch, relative to a position's base (row 2r, column 2q)
+constexpr int sb_tap(int rho) { return ((rho / 7) * kSbIR + rho % 7) * kSbRowBytes; }
+// k-step s: lanes 0-31 take row 2s, lanes 32-63 row 2s + 1 (the 22nd row has zero weights: it re-reads row 20)
+constexpr int sb_row1(int s) { return 2 * s + 1 < 21 ? 2 * s + 1 : 20; }
+constexpr int sb_delta(int s) { return sb_tap(sb_row1(s)) - sb_tap(2 * s); }
+constexpr int kSbNT = 3;                                   // the three half-wave differences: next row, next channel, none
+constexpr int sb_type(int s) { return sb_delta(s) == kSbRowBytes ? 0 : sb_delta(s) == (kSbIR - 6) * kSbRowBytes ? 1 : sb_delta(s) == 0 ? 2 : -1; }
+constexpr bool sb_types_ok() {
+  for (int s = 0; s < kSbSteps; ++s)
+    if (sb_type(s) < 0) return false;
+  return true;
+}
+static_assert(sb_types_ok(), "every k-step's half-wave offset difference is one of the three known constants");
+
+struct StemBArgs {
+  const float* x;        // [n][3][H][W] fp32 frames
+  const uint4* wp;       // [11][2][cout] x 8 bf16: k-step s, half g, channel m -> w[m][rho = 2s + g][kx = 0..7]
+  const float* bias;
+  const float* bn_scale;
+  const float* bn_shift;
+  uint4* y;              // [n][cout/8][PHo][PWo] x 8 bf16
+  int n, H, W, cout, Ho, Wo, PHo, PWo;
+  int relu, tiles_h, tiles_w;
+  int total;             // patches (n * tiles_h * tiles_w); a workgroup takes patch blockIdx.x, + gridDim.x, ...
+};
+
+// sixteen bytes from a 4-byte aligned LDS address (a position's columns start at an even bf16 index)
+__device__ __forceinline__ uint4 lds_ld16_a4(const unsigned char* p) {
+#ifdef ECO_EMU
+  uint4 v;
+  memcpy(&v, p, 16);
+  return v;
+#else
+  const unsigned* q = (const unsigned*)p;
+  return make_uint4(q[0], q[1], q[2], q[3]);
+#endif
+}
+
+// TMC = cout / 32 (1 or 2 m-tiles; every wave holds all channels of its 128 columns)
+template <int TMC>
+__global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
+  constexpr int COUT = 32 * TMC;
+  constexpr int XS_BYTES = kSbRows * kSbRowBytes;          // 14976
+  constexpr int W_VECS = kSbSteps * 2 * COUT;              // 16-byte vectors of packed weights
+  constexpr int STAGE_LD = kSbNPos + 3;                    // 496: staging row of one channel
+  constexpr int XU = (kSbRows + 3) / 4, WU = (W_VECS + 255) / 256;
+  ECO_DYNAMIC_LDS(lds);
+  unsigned char* const Xs = (unsigned char*)lds;           // bf16 [3][39][64]
+  uint4* const Ws = (uint4*)(Xs + XS_BYTES);               // [11][2][COUT], resident for the workgroup's lifetime
+  float* const Es = (float*)(Ws + W_VECS);                 // [2][COUT]: BN scale, bias * scale + shift
+  float* const Ss = Es + 2 * COUT;                         // staging [16][STAGE_LD] fp32
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tpf = a.tiles_h * a.tiles_w;
+
+#pragma unroll
+  for (int u = 0; u < WU; ++u) {
+    const int i = tid + 256 * u;
+    if (i < W_VECS) Ws[i] = ld(a.wp + i);
+  }
+  if (tid < COUT) {
+    const float b = a.bias ? ld(a.bias + tid) : 0.0f;
+    const float sc = a.bn_scale ? ld(a.bn_scale + tid) : 1.0f, sh = a.bn_scale ? ld(a.bn_shift + tid) : 0.0f;
+    Es[tid] = sc;
+    Es[COUT + tid] = b * sc + sh;
+  }
+
+  // A wave takes whole patch rows (lane = column): the row arithmetic is scalar, a lane's address is base + lane,
+  // and every load is in flight before the first one is waited for.
+  float xv[XU];
+  auto load_patch = [&](int patch) {
+    const int f = patch / tpf, t = patch - f * tpf;
+    const int by = t / a.tiles_w, bx = t - by * a.tiles_w;
+    const int ih0 = 4 * kSbPH * by - 3, iw0 = 4 * kSbPW * bx - 3;     // first input row / column
+    const float* xf = a.x + (long)f * 3 * a.H * a.W;
+    const int w = iw0 + lane;
+    const bool wok = (unsigned)w < (unsigned)a.W;
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const int row = wave + 4 * u;                        // (c, rr), wave-uniform
+      const int c = row / kSbIR, h = ih0 + row - c * kSbIR;
+      const bool ok = wok && row < kSbRows && (unsigned)h < (unsigned)a.H;
+      xv[u] = ok ? ld(xf + ((long)c * a.H + h) * a.W + w) : 0.0f;
+    }
+  };
+  auto store_patch = [&]() {
+    unsigned short* const xs = (unsigned short*)Xs;
+#pragma unroll
+    for (int u = 0; u < XU; ++u)
+      if (wave + 4 * u < kSbRows) xs[(wave + 4 * u) * kSbIQ + lane] = (unsigned short)f32_to_bf16_bits(xv[u]);
+  };
+
+  // ---- this lane's four position columns: conv position p = wave*128 + j*32 + l31 -> patch byte 2r*128 + 4q ----
+  int pbase[4], soff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int p = wave * 128 + j * 32 + l31;
+    if (p >= kSbNPos) p = kSbNPos - 1;                     // padding columns: any valid position (never stored)
+    const int r = p / kSbCQ, q = p - r * kSbCQ;
+    pbase[j] = 2 * r * kSbRowBytes + 4 * q;
+    // the pooling stage keeps a conv row's 29 columns parity split (15 even, then 14 odd): the 3x3 stride-2 windows of
+    // consecutive pooled columns read consecutive words
+    soff[j] = r * kSbCQ + (q & 1) * ((kSbCQ + 1) / 2) + (q >> 1);
+  }
+  const bool last_col_ok = wave * 128 + 96 + l31 < kSbNPos;   // only wave 3's j = 3 has padding columns
+  const uint4* const wl = Ws + half * COUT + l31;          // A[m = l31 (+32 i)][k = 16 s + 8 half + e]
+  // The stage holds one m-tile (32 channels) at a time as bf16 PAIRS -- row = channel pair, one dword per position --:
+  // half the LDS traffic of an fp32 stage on both sides, and one pass per m-tile instead of two.  The values are
+  // already rounded as the store would round them; MAX and ReLU commute with that rounding.
+  // pooling threads: 14 x 8 pooled positions x 2 = 224 of the 256; thread (pos, clo) takes the 8-channel blocks clo, clo + 2
+  const int pw = tid % kSbPW, ph = (tid / kSbPW) % kSbPH, clo = tid / (kSbPW * kSbPH);
+  unsigned* const Su = (unsigned*)Ss;
+  const unsigned* const sp0 = Su + 4 * clo * STAGE_LD + 2 * ph * kSbCQ + pw;
+  unsigned* const sw0 = Su + 2 * half * STAGE_LD;
+  const float relu_floor = a.relu ? 0.0f : -FLT_MAX;
+  const int cblocks = a.cout / 8;
+
+  int patch = (int)blockIdx.x;
+  load_patch(patch);
+  store_patch();
+  __syncthreads();
+
+  while (true) {
+    const int next = patch + (int)gridDim.x;
+    if (next < a.total) load_patch(next);                  // in flight under the reduction below
+
+    f32x16 acc[TMC][4];
+#pragma unroll
+    for (int i = 0; i < TMC; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // fragment addresses: base register of the k-step's type + compile-time immediate; opaque per patch so that the
+    // compiler does not materialise all 11 x 4 addresses outside the patch loop
+    int pb[kSbNT][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pb[0][j] = pbase[j] + (half ? kSbRowBytes : 0);
+      pb[1][j] = pbase[j] + (half ? (kSbIR - 6) * kSbRowBytes : 0);
+      pb[2][j] = pbase[j];
+#pragma unroll
+      for (int t = 0; t < kSbNT; ++t) ECO_OPAQUE(pb[t][j]);
+    }
+    static_for<kSbSteps>([&](auto S) __attribute__((always_inline)) {
+      constexpr int s = decltype(S)::value;
+      constexpr int ty = sb_type(s), imm = sb_tap(2 * s);
+      uint4 af[TMC], bf[4];
+#pragma unroll
+      for (int i = 0; i < TMC; ++i) af[i] = wl[s * 2 * COUT + 32 * i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = lds_ld16_a4(Xs + pb[ty][j] + imm);
+#pragma unroll
+      for (int i = 0; i < TMC; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
+    });
+    __syncthreads();   // every wave is done with Xs: the next patch may land
+    if (next < a.total) store_patch();
+
+    // ---- per 16 channels: bias / BN on the accumulators into the stage, 3x3 stride-2 max over it, ReLU, pooled store.
+    // A thread's nine window offsets are fixed per patch (taps outside the conv image -- the MAX window is clipped to
+    // it, pooling_layer.cpp:207-212 -- re-read tap (0,0), which a stored output always has). ----
+    const int f = patch / tpf, t = patch - f * tpf;
+    const int by = t / a.tiles_w, bx = t - by * a.tiles_w;
+    const int r0 = 2 * kSbPH * by, q0 = 2 * kSbPW * bx;    // first conv row / column of the patch
+    const int gph = kSbPH * by + ph, gpw = kSbPW * bx + pw;
+    const bool pool_thread = clo < 2 && gph < a.PHo && gpw < a.PWo;
+    int woff[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+        woff[dy * 3 + dx] = (r0 + 2 * ph + dy < a.Ho && q0 + 2 * pw + dx < a.Wo)
+                                ? dy * kSbCQ + (dx & 1) * ((kSbCQ + 1) / 2) + (dx >> 1) : 0;
+    uint4* const yp0 = a.y + (((long)f * cblocks + clo) * a.PHo + gph) * a.PWo + gpw;   // block clo of m-tile 0
+    const long yblk = (long)a.PHo * a.PWo;
+#pragma unroll
+    for (int i = 0; i < TMC; ++i) {
+#pragma unroll
+      for (int rp = 0; rp < 8; ++rp) {                     // accumulator registers 2rp, 2rp + 1: two consecutive channels
+        const int row = (rp & 1) + 4 * (rp >> 1);          // + 2*half: this lane's pair row within the 16
+        const int ch = 32 * i + 2 * row + 4 * half;
+        const float2 sc = *(const float2*)(Es + ch), sh2 = *(const float2*)(Es + COUT + ch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < 3 || last_col_ok)
+            sw0[row * STAGE_LD + soff[j]] = pack_bf16x2(acc[i][j][2 * rp] * sc.x + sh2.x, acc[i][j][2 * rp + 1] * sc.y + sh2.y);
+      }
+      __syncthreads();
+      if (pool_thread) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const unsigned* const spb = sp0 + 8 * it * STAGE_LD;   // block clo + 2 it = pair rows 4 (clo + 2 it) ...
+          unsigned o[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned* sp = spb + u * STAGE_LD;
+            unsigned v = sp[woff[0]];
+            float lo = bf16_bits_to_f32(v & 0xffffu), hi = bf16_bits_to_f32(v >> 16);
+#pragma unroll
+            for (int k = 1; k < 9; ++k) {
+              v = sp[woff[k]];
+              lo = fmaxf(lo, bf16_bits_to_f32(v & 0xffffu));
+              hi = fmaxf(hi, bf16_bits_to_f32(v >> 16));
+            }
+            lo = fmaxf(lo, relu_floor);                    // ReLU commutes with the MAX window
+            hi = fmaxf(hi, relu_floor);
+            o[u] = pack_bf16x2(lo, hi);                    // exact: both are bf16 values already
+          }
+          st(yp0 + (4 * i + 2 * it) * yblk, make_uint4(o[0], o[1], o[2], o[3]));
+        }
+      }
+      __syncthreads();
+    }
+    if (next >= a.total) break;
+    patch = next;
+  }
+}
+
+}  // namespace eco
+
+using namespace eco;
+
+static int stemb_dims(int h, int w, int* ho, int* wo, int* pho, int* pwo) {
+  *ho = (h + 6 - 7) / 2 + 1;
+  *wo = (w + 6 - 7) / 2 + 1;
+  // pooling_layer.cpp:131-147 with kernel 3, stride 2, pad 0: ceil((in - 3) / 2) + 1
+  *pho = (*ho - 3 + 1) / 2 + 1;
+  *pwo = (*wo - 3 + 1) / 2 + 1;
+  return *ho >= 3 && *wo >= 3;
+}
+
+static unsigned short stemb_bf16(float f) {   // round to nearest even, as the device conversion
+  unsigned u;
+  memcpy(&u, &f, 4);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+extern "C" int64_t eco_stemb_weight_elems(int32_t cout) { return (int64_t)kSbSteps * 2 * cout * 8; }
+
+extern "C" int eco_stemb_pack_weights(const float* w, int32_t cout, void* wp) {
+  clear_error();
+  ECO_REQUIRE(w && wp && (cout == 32 || cout == 64), "stemb: weights for 32 or 64 output channels (got %d)", cout);
+  unsigned short* o = (unsigned short*)wp;
+  memset(o, 0, sizeof(unsigned short) * (size_t)eco_stemb_weight_elems(cout));
+  // w[m][c][ky][kx] -> wp[s][g][m][e]: kernel row rho = c*7 + ky = 2s + g, tap kx = e (e = 7 and rho = 21 stay zero)
+  for (int m = 0; m < cout; ++m)
+    for (int rho = 0; rho < 21; ++rho)
+      for (int kx = 0; kx < 7; ++kx)
+        o[(((long)(rho / 2) * 2 + rho % 2) * cout + m) * 8 + kx] = stemb_bf16(w[((long)m * 21 + rho) * 7 + kx]);
+  return ECO_OK;
+}
+
+extern "C" int eco_stemb_forward(const float* x, const void* wp, const float* bias, const float* bn_scale,
+                                 const float* bn_shift, int32_t relu, void* y, int32_t n, int32_t h, int32_t w,
+                                 int32_t cout, int32_t max_workgroups, void* stream) {
+  clear_error();
+  ECO_REQUIRE(x && wp && y && n > 0 && h > 0 && w > 0 && max_workgroups >= 0, "stemb: bad argument");
+  ECO_REQUIRE(cout == 32 || cout == 64, "stemb: 32 or 64 output channels (got %d)", cout);
+  ECO_REQUIRE(!bn_scale == !bn_shift, "stemb: bn_scale and bn_shift must be given together");
+  ECO_REQUIRE(((uintptr_t)wp & 15) == 0 && ((uintptr_t)y & 15) == 0, "stemb: packed weights and output must be 16-byte aligned");
+  StemBArgs a;
+  a.x = x; a.wp = (const uint4*)wp; a.bias = bias; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.y = (uint4*)y;
+  a.n = n; a.H = h; a.W = w; a.cout = cout; a.relu = relu;
+  ECO_REQUIRE(stemb_dims(h, w, &a.Ho, &a.Wo, &a.PHo, &a.PWo), "stemb: image %dx%d too small for conv 7x7/2 + pool 3x3/2", h, w);
+  a.tiles_h = (int)ceil_div(a.PHo, kSbPH);
+  a.tiles_w = (int)ceil_div(a.PWo, kSbPW);
+  const long total = (long)n * a.tiles_h * a.tiles_w;
+  ECO_REQUIRE(total < 2147483647l, "stemb: too many patches for one launch");
+  a.total = (int)total;
+  // persistent workgroups, two per CU: the weights are loaded once per workgroup, not once per patch
+  const long cap = max_workgroups ? max_workgroups : 2l * current_device_num_cu();
+  const long grid = total < cap ? total : cap;
+  const size_t lds = (size_t)kSbRows * kSbRowBytes + (size_t)kSbSteps * 2 * cout * 16 + sizeof(float) * (size_t)(2 * cout + 16 * (kSbNPos + 3));
+  hipStream_t s = (hipStream_t)stream;
+  if (cout == 64) ECO_RAISE_DYNAMIC_LDS(stemb_kernel<2>, "stemb");
+  else ECO_RAISE_DYNAMIC_LDS(stemb_kernel<1>, "stemb");
+  if (cout == 64) hipLaunchKernelGGL((stemb_kernel<2>), dim3((unsigned)grid), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((stemb_kernel<1>), dim3((unsigned)grid), dim3(256), lds, s, a);
+  return check_launch("eco_stemb_forward");
+}

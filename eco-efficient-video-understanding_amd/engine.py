@@ -213,6 +213,10 @@ class Engine:
                 self.alloc.upload(st["wp"], wpb)
                 if L.geom["bias_term"]:
                     self.alloc.upload(st["bias"], blobs[1])
+                if "stemb_wp" in st:   # conv1 + pool1 as one launch (csrc/eco_stemb.hip)
+                    swp = np.empty(self.lib.stemb_weight_elems(L.geom["cout"]), np.uint16)
+                    self.lib.stemb_pack_weights(w.ctypes.data, L.geom["cout"], swp.ctypes.data)
+                    self.alloc.upload(st["stemb_wp"], swp)
             elif L.type == "Convolution":
                 g: hip.ConvGeom = st["geom"]
                 plan: hip.ConvPlan = st["plan"]
@@ -628,10 +632,19 @@ class Engine:
                 g["cout"] in (32, 64) and list(g["kernel"]) == [7, 7] and list(g["stride"]) == [2, 2] and
                 list(g["pad"]) == [3, 3] and min(L.top_shapes[0][2:]) >= 3)
 
+    def _stemb_geometry(self, L: LayerSpec) -> bool:
+        """The same stem on the blocked bf16 path (csrc/eco_stemb.hip)."""
+        g = L.geom
+        return (self.fuse and self.dt == hip.DT_BF16 and self.stem and len(L.bottom_shapes[0]) == 4 and g["cin"] == 3 and
+                g["cout"] in (32, 64) and list(g["kernel"]) == [7, 7] and list(g["stride"]) == [2, 2] and
+                list(g["pad"]) == [3, 3] and min(L.top_shapes[0][2:]) >= 3)
+
     def _try_fuse_stem(self, i, L, ep, act_blob, label, layers, consumers, outputs, absorbed) -> bool:
         """conv (stem geometry) + BN + ReLU whose activated blob feeds only a MAX 3x3 stride-2 unpadded Pooling:
         one launch writes the pooled blob; the conv's own output is never stored."""
-        if act_blob is None or act_blob in outputs or ep.raw.ptr or ep.residual.ptr or not self._stem_geometry(L):
+        blocked_stem = self._stemb_geometry(L)
+        if act_blob is None or act_blob in outputs or ep.raw.ptr or ep.residual.ptr or \
+                not (blocked_stem or self._stem_geometry(L)):
             return False
         cs = [c for c in consumers.get(act_blob, []) if absorbed.get(c) != L.name]
         if len(cs) != 1 or layers[cs[0]].type != "Pooling":
@@ -647,10 +660,18 @@ class Engine:
         absorbed[cs[0]] = L.name
         self.fused_away[act_blob] = f"only exists inside the fused stem launch {L.name}+{Lp.name}"
         x, y = self._ptr(L.bottoms[0]), self._ptr(Lp.tops[0])
-        wp = self.alloc.ptr(st["stem_wp"])
         bias, sc, sh, relu = ep.bias, ep.bn_scale, ep.bn_shift, ep.relu
         lib = self.lib
         n_conv = _prod(L.top_shapes[0])
+        if blocked_stem:   # fp32 frames in, pooled blob out in the blocked bf16 layout
+            if self.tensors[L.bottoms[0]].dt:
+                raise NetSpecError(f"{L.name}: the 3-channel stem reads the fp32 frames, got a blocked blob")
+            wp = self.alloc.ptr(st["stemb_wp"])
+            self._add(i, f"{label}+{Lp.name}", lambda s: lib.stemb_forward(x, wp, bias, sc, sh, relu, y, n, H, W, cout, s),
+                      {"kernel": "eco::stemb_kernel", "flops": 2 * n_conv * 147,
+                       "bytes": 4 * _prod(L.bottom_shapes[0]) + 2 * (147 * cout + _prod(Lp.top_shapes[0]))})
+            return True
+        wp = self.alloc.ptr(st["stem_wp"])
         self._add(i, f"{label}+{Lp.name}", lambda s: lib.stem_forward(x, wp, bias, sc, sh, relu, y, n, H, W, cout, s),
                   {"kernel": "eco::stem_kernel", "flops": 2 * n_conv * 147,
                    "bytes": 4 * (_prod(L.bottom_shapes[0]) + 147 * cout + _prod(Lp.top_shapes[0]))})
@@ -665,16 +686,23 @@ class Engine:
             st["wp"] = self.alloc.empty(bp.wp_vecs * 8, np.uint16)
             if g["bias_term"]:
                 st["bias"] = self.alloc.empty(g["cout"], np.float32)
-        if bp.stem:   # zero-padded pixel-interleaved copy of the fp32 frames (eco_stem_pack_forward)
-            n, _, H, W = L.bottom_shapes[0]
-            need = n * (H + 6) * (W + 8) * 4
-            if st.get("stem_elems") != need:
-                st["stem_buf"] = self.alloc.empty(need, self.store_np)
-                st["stem_elems"] = need
+        if bp.stem and self._stemb_geometry(L):   # conv1 + pool1 as one launch (csrc/eco_stemb.hip)
+            if "stemb_wp" not in st:
+                st["stemb_wp"] = self.alloc.empty(self.lib.stemb_weight_elems(g["cout"]), np.uint16)
+        elif bp.stem:
+            self._stem_pack_buffer(L, st)
         st["geom"], st["bplan"] = geom, bp
         st.pop("plan", None)
         st.pop("wino", None)
         self._dirty_params.add(L.name)
+
+    def _stem_pack_buffer(self, L: LayerSpec, st: dict) -> None:
+        """Zero-padded pixel-interleaved copy of the fp32 frames (eco_stem_pack_forward) for the unfused blocked stem."""
+        n, _, H, W = L.bottom_shapes[0]
+        need = n * (H + 6) * (W + 8) * 4
+        if st.get("stem_elems") != need:
+            st["stem_buf"] = self.alloc.empty(need, self.store_np)
+            st["stem_elems"] = need
 
     def _emit_blocked_conv(self, i: int, L: LayerSpec, ep: "hip.ConvEpilogue", label: str) -> None:
         st = self._param_dev[L.name]
@@ -692,6 +720,7 @@ class Engine:
             if src.dt:
                 raise NetSpecError(f"{L.name}: the 3-channel stem reads the fp32 frames, got a blocked blob")
             n, _, H, W = L.bottom_shapes[0]
+            self._stem_pack_buffer(L, st)   # (a stem whose pool could not be fused gets its buffer here)
             x, buf = self._ptr(L.bottoms[0]), self.alloc.ptr(st["stem_buf"])
             self._add(i, f"{label} [stem pack]", lambda s, x=x, buf=buf, n=n, H=H, W=W: lib.stem_pack_forward(x, buf, n, H, W, dt, s),
                       {"kernel": "eco::stem_pack_kernel", "flops": 0, "bytes": 4 * n * 3 * H * W + es * st["stem_elems"]})

@@ -21,7 +21,7 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 15
+ABI_VERSION = 16
 MAX_SEG = 3   # ECO_MAX_SEG: extra output segments of a sibling launch
 DT_BF16 = 1
 DT_F32X3 = 3
@@ -211,6 +211,10 @@ _SIGNATURES = {
     "eco_stem_pack_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "eco_stem_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                    C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "eco_stemb_weight_elems": (C.c_int64, [C.c_int32]),
+    "eco_stemb_pack_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "eco_stemb_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                    C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "eco_wino_input_q4_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "eco_wfused_weight_elems": (C.c_int64, [C.POINTER(WGemmPlan)]),
     "eco_wfused_pack_weights": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p]),
@@ -324,6 +328,18 @@ class EcoLib:
                      max_workgroups: int = 0) -> None:
         self._check(self._dll.eco_stem_forward(x, wp, bias, bn_scale, bn_shift, int(relu), y, n, h, w, cout,
                                                max_workgroups, stream))
+
+    # -- the stem of the blocked bf16 path as one launch (csrc/eco_stemb.hip) ----------
+    def stemb_weight_elems(self, cout: int) -> int:
+        return int(self._dll.eco_stemb_weight_elems(cout))
+
+    def stemb_pack_weights(self, w_host: int, cout: int, wp_host: int) -> None:
+        self._check(self._dll.eco_stemb_pack_weights(w_host, cout, wp_host))
+
+    def stemb_forward(self, x, wp, bias, bn_scale, bn_shift, relu, y, n, h, w, cout, stream=None,
+                      max_workgroups: int = 0) -> None:
+        self._check(self._dll.eco_stemb_forward(x, wp, bias, bn_scale, bn_shift, int(relu), y, n, h, w, cout,
+                                                max_workgroups, stream))
 
     # -- fused transformed-domain GEMM + output transform for the short-reduction 2-D layers --
     def wino_input_q4_forward(self, plan: "WGemmPlan", x: int, v: int, h: int, w: int, stream=None) -> None:

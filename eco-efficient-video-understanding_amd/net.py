@@ -152,7 +152,7 @@ class Net:
     def __init__(self, model, weights=None, phase=TEST, *, fuse: bool = True, winograd: bool = True,
                  dtype: str = "f32", device: Optional[int] = None,
                  params: Optional[Dict[str, List[np.ndarray]]] = None, seed: int = 0, pool_commute: bool = True,
-                 _backend=None, _num_cu: Optional[int] = None) -> None:
+                 stem: bool = True, _backend=None, _num_cu: Optional[int] = None) -> None:
         # pycaffe accepts Net(model, phase) and Net(model, weights, phase)
         if isinstance(weights, int) and not isinstance(weights, bool):
             weights, phase = None, weights
@@ -181,6 +181,7 @@ class Net:
         # input inside the sibling launch; the average then runs on the conv's channels -- engine.pool_commute)
         self._engine = Engine(self._spec, lib, alloc, fuse=fuse, winograd=winograd, num_cu=_num_cu, dtype=dtype)
         self._engine.pool_commute = bool(pool_commute)
+        self._engine.stem = bool(stem)   # False: conv1 and pool1 as separate launches (debug / A-B measurements)
         self._pending_input_shapes: Dict[str, tuple] = {}
         self._engine.set_params(params if params is not None else fillers.filler_params(self._spec, seed))
         self._engine.build()

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 15
+#define ECO_ABI_VERSION 16
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -302,6 +302,18 @@ int eco_stem_pack_weights(const float* w, int32_t cout, float* wp);
 int eco_stem_forward(const float* x, const float* wp, const float* bias, const float* bn_scale, const float* bn_shift,
                      int32_t relu, float* y, int32_t n, int32_t h, int32_t w, int32_t cout, int32_t max_workgroups,
                      void* stream);
+
+/* ---- the same stem for the channel-blocked bf16 path (csrc/eco_stemb.hip, ABI v16) ----------------------------
+ * x: [n,3,h,w] fp32 frames -> y: [n][cout/8][PH][PW][8] bf16 (the blocked layout of eco_convb_forward); operands
+ * rounded to bf16 (nearest even), fp32 products / sums / bias / BN, one rounding at the store.  Replaces the three
+ * launches eco_stem_pack_forward + eco_convb_forward (stem plan) + eco_poolb_forward. */
+int64_t eco_stemb_weight_elems(int32_t cout);   /* bf16 elements of the packed weights: 11 * 2 * cout * 8 */
+/* HOST: w[cout][3][7][7] -> wp[s][g][cout][8] bf16: kernel row rho = c*7 + ky = 2s + g, tap kx = e (kx = 7 and row 21
+ * zero): one v_mfma_f32_32x32x16_bf16 k-step = two kernel rows. */
+int eco_stemb_pack_weights(const float* w, int32_t cout, void* wp);
+int eco_stemb_forward(const float* x, const void* wp, const float* bias, const float* bn_scale, const float* bn_shift,
+                      int32_t relu, void* y, int32_t n, int32_t h, int32_t w, int32_t cout, int32_t max_workgroups,
+                      void* stream);
 
 /* ---- Winograd F(4x4,3x3) route on a dedicated transformed-domain GEMM (csrc/eco_wgemm.hip) -------------------
  *

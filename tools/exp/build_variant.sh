@@ -9,7 +9,7 @@ CSRC=$ROOT/eco-efficient-video-understanding_amd/csrc
 NAME=$1; SRC=$2; shift 2
 make -s -C $CSRC -j8 all
 OBJS=""
-for f in eco_api eco_conv eco_ops eco_wino eco_blocked eco_wgemm eco_stem; do
+for f in eco_api eco_conv eco_ops eco_wino eco_blocked eco_wgemm eco_stem eco_stemb; do
   if [ $f = $SRC ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=default -fno-slp-vectorize "$@" -c $CSRC/$f.hip -o /tmp/${f}_$NAME.o
     OBJS="$OBJS /tmp/${f}_$NAME.o"
