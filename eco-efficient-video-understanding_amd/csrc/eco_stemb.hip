@@ -19,9 +19,14 @@
 //     consecutive patch elements starting at column 2q of row (c, 2r + ky): 16 bytes at a 4-byte aligned LDS address
 //     (two ds_read2_b32), a per-lane base plus a compile-time offset per k-step, no im2col, no masks;
 //   * 17 x 29 conv outputs (one halo row / column) = 512 position columns x cout in 11 x 8 MFMAs per wave -- 2.8 k
-//     cycles where the fp32 reduction takes 38 k -- then bias / BN in fp32 on the accumulators, 16 channels at a time
-//     through an fp32 LDS stage for the 3 x 3 stride-2 max, ReLU, and one 16-byte store per (pooled position, 8-channel
-//     block).  conv1's output never exists in HBM; the kernel is bound by its epilogue's LDS traffic, not by the MFMAs.
+//     cycles where the fp32 reduction takes 38 k -- then bias / BN in fp32 on the accumulators, one m-tile (32 channels)
+//     at a time through an LDS stage of bf16 PAIRS for the 3 x 3 stride-2 max, ReLU, and one 16-byte store per (pooled
+//     position, 8-channel block).  conv1's output never exists in HBM.
+// Measured (1024 frames of 224 x 224): 0.69 ms against 1.88 ms for the three launches; probe builds (-DECO_STEMB_PROBE)
+// put 0.22 ms on the reduction, 0.19 on the pooling reads and stores, 0.28 on everything else (bias / BN + stage
+// writes, patch stores, five barriers per patch).  With an fp32 stage of 16 channels per pass it was 0.80 ms.  Double
+// buffering the fragments and issuing the frame loads a whole epilogue earlier changed nothing: the phases are short
+// and strictly ordered by the barriers, and two workgroups per CU (250 VGPRs: 128 accumulators) is all that overlaps them.
 // Arithmetic: bf16 operands (frames and weights rounded to nearest even), fp32 products and sums, fp32 bias / BN, one
 // rounding to bf16 at the store -- the blocked path's convention (eco_blocked.hip).  The MAX window commutes with that
 // rounding (monotonic), so the result equals pooling the rounded conv output.
@@ -127,7 +132,11 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
       const int row = wave + 4 * u;                        // (c, rr), wave-uniform
       const int c = row / kSbIR, h = ih0 + row - c * kSbIR;
       const bool ok = wok && row < kSbRows && (unsigned)h < (unsigned)a.H;
+#if defined(ECO_STEMB_PROBE) && (ECO_STEMB_PROBE & 8)    // bit 3: no global loads of the frames
+      xv[u] = ok ? (float)row : 0.0f;
+#else
       xv[u] = ok ? ld(xf + ((long)c * a.H + h) * a.W + w) : 0.0f;
+#endif
     }
   };
   auto store_patch = [&]() {
@@ -165,11 +174,11 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
   int patch = (int)blockIdx.x;
   load_patch(patch);
   store_patch();
+  if (patch + (int)gridDim.x < a.total) load_patch(patch + (int)gridDim.x);
   __syncthreads();
 
   while (true) {
-    const int next = patch + (int)gridDim.x;
-    if (next < a.total) load_patch(next);                  // in flight under the reduction below
+    const int next = patch + (int)gridDim.x;               // its words are in flight (or landed) in xv
 
     f32x16 acc[TMC][4];
 #pragma unroll
@@ -190,21 +199,37 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
 #pragma unroll
       for (int t = 0; t < kSbNT; ++t) ECO_OPAQUE(pb[t][j]);
     }
+    uint4 af[2][TMC], bf[2][4];
+#pragma unroll
+    for (int i = 0; i < TMC; ++i) af[0][i] = wl[32 * i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf[0][j] = lds_ld16_a4(Xs + pb[sb_type(0)][j] + sb_tap(0));
+#if !defined(ECO_STEMB_PROBE) || !(ECO_STEMB_PROBE & 1)   // probe builds (tools/exp): bit 0 drops the reduction
     static_for<kSbSteps>([&](auto S) __attribute__((always_inline)) {
       constexpr int s = decltype(S)::value;
-      constexpr int ty = sb_type(s), imm = sb_tap(2 * s);
-      uint4 af[TMC], bf[4];
+      constexpr int cur = s & 1;
+      if constexpr (s + 1 < kSbSteps) {   // step s + 1's fragments are read before step s's products issue
+        constexpr int ty = sb_type(s + 1), imm = sb_tap(2 * (s + 1));
 #pragma unroll
-      for (int i = 0; i < TMC; ++i) af[i] = wl[s * 2 * COUT + 32 * i];
+        for (int i = 0; i < TMC; ++i) af[cur ^ 1][i] = wl[(s + 1) * 2 * COUT + 32 * i];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = lds_ld16_a4(Xs + pb[ty][j] + imm);
+        for (int j = 0; j < 4; ++j) bf[cur ^ 1][j] = lds_ld16_a4(Xs + pb[ty][j] + imm);
+      }
+      sched_fence();
 #pragma unroll
       for (int i = 0; i < TMC; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_32x32x16_bf16(af[cur][i], bf[cur][j], acc[i][j]);
+      sched_fence();
     });
+#endif
     __syncthreads();   // every wave is done with Xs: the next patch may land
-    if (next < a.total) store_patch();
+    if (next < a.total) {
+      store_patch();
+      // the patch after it: its loads have the whole epilogue below and the next reduction to land (xv is free until
+      // then: no register cost at the reduction's peak, where xv is live anyway)
+      if (next + (int)gridDim.x < a.total) load_patch(next + (int)gridDim.x);
+    }
 
     // ---- per 16 channels: bias / BN on the accumulators into the stage, 3x3 stride-2 max over it, ReLU, pooled store.
     // A thread's nine window offsets are fixed per patch (taps outside the conv image -- the MAX window is clipped to
@@ -223,6 +248,13 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
                                 ? dy * kSbCQ + (dx & 1) * ((kSbCQ + 1) / 2) + (dx >> 1) : 0;
     uint4* const yp0 = a.y + (((long)f * cblocks + clo) * a.PHo + gph) * a.PWo + gpw;   // block clo of m-tile 0
     const long yblk = (long)a.PHo * a.PWo;
+#if defined(ECO_STEMB_PROBE) && (ECO_STEMB_PROBE & 2)    // bit 1: no epilogue at all (the accumulators stay live)
+#pragma unroll
+    for (int i = 0; i < TMC; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    if (a.total >= 0) { if (next >= a.total) break; patch = next; continue; }
+#endif
 #pragma unroll
     for (int i = 0; i < TMC; ++i) {
 #pragma unroll
@@ -236,6 +268,9 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
             sw0[row * STAGE_LD + soff[j]] = pack_bf16x2(acc[i][j][2 * rp] * sc.x + sh2.x, acc[i][j][2 * rp + 1] * sc.y + sh2.y);
       }
       __syncthreads();
+#if defined(ECO_STEMB_PROBE) && (ECO_STEMB_PROBE & 4)    // bit 2: stage written, no pooling / stores
+      if (a.total < 0)
+#endif
       if (pool_thread) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
