@@ -659,6 +659,10 @@ __global__ __launch_bounds__(256, 2) void convb_dma_kernel(const ConvBArgs a, co
 // (BMP x 64 B per tap), which is why every plan of this kernel uses 256-position tiles.
 // Pipeline: weights per tap in three buffers exactly as above; the span of group g+1 is issued at the first tap of
 // group g (after its barrier) into the other span buffer and is retired, in order, by the wait of tap 2.
+#ifndef ECO_SPAN_NBUF
+#define ECO_SPAN_NBUF 3        // weight-stage buffers: the weights of tap s + NBUF - 1 are issued at tap s
+#endif
+constexpr int kSpanNbuf = ECO_SPAN_NBUF;
 template <int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, const uint4* zero_page, int span_pieces) {
   constexpr int BM = 32 * TM * WM;
@@ -670,8 +674,8 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
 
   ECO_DYNAMIC_LDS(lds_f);
   const int SPAN = span_pieces * 64;
-  uint4* const Aw = (uint4*)lds_f;              // [3][kCbs][BMP]
-  uint4* const Bsp = Aw + 3 * kCbs * BMP;       // [2][kCbs][SPAN]
+  uint4* const Aw = (uint4*)lds_f;              // [kSpanNbuf][kCbs][BMP]
+  uint4* const Bsp = Aw + kSpanNbuf * kCbs * BMP;   // [2][kCbs][SPAN]
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
@@ -760,9 +764,11 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
 
   const int total = (g_end - g_begin) * T2;   // flat tap stages of this slice
   if (total > 0) {
+    constexpr int D = kSpanNbuf - 1;          // prefetch distance in taps
     issue_span(g_begin, 0);
-    issue_weights(g_begin, 0, 0);
-    if (total > 1) issue_weights(g_begin, 1, 1);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (d < total) issue_weights(g_begin + d / T2, d % T2, d);
     int abuf = 0;
     for (int g = g_begin; g < g_end; ++g) {
       const int sbuf = (g - g_begin) & 1;
@@ -770,16 +776,34 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
 #pragma unroll 1
       for (int t2 = 0; t2 < T2; ++t2) {
         const int s = (g - g_begin) * T2 + t2;
-        // pieces of this wave that may still be in flight once this tap's weights have landed: the next tap's
-        // weights and, at tap 1, the span issued at tap 0
-        if (s + 1 >= total) wait_dma_all_but<0>();
-        else if (t2 == 1 && next_group) { if (nchunks == 2) wait_dma_all_but<A_PER_WAVE + 2 * kCbs>(); else wait_dma_all_but<A_PER_WAVE + kCbs>(); }
-        else wait_dma_all_but<A_PER_WAVE>();
+        // pieces of this wave that may still be in flight once this tap's weights have landed: the weights of the next
+        // D - 1 taps and, at taps 1 .. D - 1, the span issued at tap 0 (issued after this tap's weights)
+        const int ahead = total - 1 - s < D - 1 ? total - 1 - s : D - 1;
+        const bool span_out = next_group && t2 >= 1 && t2 <= D - 1;
+        const int sp_pieces = span_out ? nchunks * kCbs : 0;
+        if (ahead == 0) wait_dma_all_but<0>();
+        else if (ahead == 1) {
+          if (sp_pieces == 0) wait_dma_all_but<A_PER_WAVE>();
+          else if (sp_pieces == kCbs) wait_dma_all_but<A_PER_WAVE + kCbs>();
+          else wait_dma_all_but<A_PER_WAVE + 2 * kCbs>();
+        } else {
+          if (sp_pieces == 0) wait_dma_all_but<2 * A_PER_WAVE>();
+          else if (sp_pieces == kCbs) wait_dma_all_but<2 * A_PER_WAVE + kCbs>();
+          else wait_dma_all_but<2 * A_PER_WAVE + 2 * kCbs>();
+        }
+#if !defined(ECO_SPAN_PROBE) || !(ECO_SPAN_PROBE & 1)   // probe builds (tools/exp): bit 0 = no barrier per tap
         wg_barrier_nodrain();
+#endif
+#if defined(ECO_SPAN_PROBE) && (ECO_SPAN_PROBE & 2)     // bit 1 = no operand DMA after the prologue
+        if (a.ntot < 0)
+#endif
         if (t2 == 0 && next_group) issue_span(g + 1, sbuf ^ 1);
-        if (s + 2 < total) {
-          const int t2n = t2 + 2 < T2 ? t2 + 2 : t2 + 2 - T2;
-          issue_weights(t2 + 2 < T2 ? g : g + 1, t2n, abuf == 0 ? 2 : abuf - 1);   // (abuf + 2) % 3
+#if defined(ECO_SPAN_PROBE) && (ECO_SPAN_PROBE & 2)
+        if (a.ntot < 0)
+#endif
+        if (s + D < total) {
+          const int t2n = (t2 + D) % T2;
+          issue_weights(t2 + D < T2 ? g : g + 1, t2n, (abuf + D) % kSpanNbuf);
         }
         sched_fence();
         const int y = t2 / 3, xx = t2 - 3 * y;
@@ -789,22 +813,36 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
         for (int j = 0; j < TN; ++j) okm[j] = 0u - ((fmask[j] >> t2) & 1u);
         const uint4* Ab = Aw + abuf * kCbs * BMP;
         const uint4* Bb = Bsp + sbuf * kCbs * SPAN + toff;
+        // Fragments double-buffered across the tap's k-steps: left to itself the compiler keeps ONE A fragment's
+        // registers and walks read -> s_waitcnt lgkmcnt(0) -> two MFMAs four times per k-step, a full LDS round trip per
+        // 64 MFMA cycles (seen in the ISA; MfmaUtil 0.36).  Here the six reads of k-step ks + 1 are issued before the
+        // eight MFMAs of k-step ks.
+        uint4 af[2][TM], bf[2][TN];
+        auto read_frags = [&](int slot, int ks) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[slot][i] = Ab[(2 * ks + half) * BMP + (wm * TM + i) * 32 + l31];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[slot][j] = Bb[(2 * ks + half) * SPAN + (wn * TN + j) * 32 + l31];
+        };
+        read_frags(0, 0);
 #pragma unroll
         for (int ks = 0; ks < kCbs / 2; ++ks) {
-          uint4 af[TM], bf[TN];
-#pragma unroll
-          for (int i = 0; i < TM; ++i) af[i] = Ab[(2 * ks + half) * BMP + (wm * TM + i) * 32 + l31];
+          if (ks + 1 < kCbs / 2) read_frags((ks + 1) & 1, ks + 1);
+          sched_fence();
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            const uint4 q = Bb[(2 * ks + half) * SPAN + (wn * TN + j) * 32 + l31];
-            bf[j] = make_uint4(q.x & okm[j], q.y & okm[j], q.z & okm[j], q.w & okm[j]);
+#if !defined(ECO_SPAN_PROBE) || !(ECO_SPAN_PROBE & 4)     // bit 2 = no tap masks on the fragments
+            uint4& q = bf[ks & 1][j];
+            q = make_uint4(q.x & okm[j], q.y & okm[j], q.z & okm[j], q.w & okm[j]);
+#endif
           }
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16_bf16(af[ks & 1][i], bf[ks & 1][j], acc[i][j]);
+          sched_fence();
         }
-        abuf = abuf == 2 ? 0 : abuf + 1;
+        abuf = abuf == kSpanNbuf - 1 ? 0 : abuf + 1;
       }
     }
   }
@@ -1217,7 +1255,7 @@ static int launch_convb_span(const ConvBArgs& a, int span_pieces, hipStream_t st
   const uint4* zp = device_zero_page();
   ECO_REQUIRE((((uintptr_t)a.x | (uintptr_t)a.wp) & 15) == 0, "convb: input and packed weights must be 16-byte aligned");
   const int grid = a.nblk_m * a.nblk_n * a.ksplit;
-  const size_t lds = (size_t)(3 * kCbs * BMP + 2 * kCbs * span_pieces * 64) * 16;
+  const size_t lds = (size_t)(kSpanNbuf * kCbs * BMP + 2 * kCbs * span_pieces * 64) * 16;
   if (lds > 64 * 1024) ECO_RAISE_DYNAMIC_LDS((convb_span_kernel<TM, TN, WM, WN>), "convb");
   hipLaunchKernelGGL((convb_span_kernel<TM, TN, WM, WN>), dim3(grid), dim3(256), lds, stream, a, zp, span_pieces);
   return check_launch("eco_convb_forward");
