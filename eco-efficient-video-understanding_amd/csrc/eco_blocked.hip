@@ -1019,6 +1019,70 @@ constexpr int kTailBThreads = 1024;
 constexpr int kTailBMaxC = 2048;
 constexpr int kTailBOut = 128;
 
+// The AVE 3x3 / stride 1 / pad 1 pool that runs BEHIND its 1x1 projection (the engine's pool_commute pre-pass, as
+// avgpool2d_k3s1p1_affine_kernel in eco_ops.hip does for the fp32 path): z = conv1x1(x) without bias -> window sum / 9
+// (the divisor counts the padding: pooling_layer.cpp:247-262) + bias, folded BN, ReLU, into a blocked view (a Concat
+// slice).  One thread per (image, 8-channel block, position); the nine block loads are issued before the first is used.
+struct PoolBAffArgs {
+  const void* x;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  eco_view dst;
+  long total;   // n * cblocks * H * W
+  int CB, H, W;
+  float floor_v;
+};
+template <int NS>
+__global__ __launch_bounds__(256) void poolb_avg_affine_kernel(const PoolBAffArgs a) {
+  const long plane = (long)a.H * a.W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (long)gridDim.x * 256) {
+    const int w = (int)(i % a.W);
+    const long t = i / a.W;
+    const int h = (int)(t % a.H);
+    const long ncb = t / a.H;
+    const int cb = (int)(ncb % a.CB), img = (int)(ncb / a.CB);
+    const long xb = ncb * plane;
+    BlockVec<NS> v[3][3];
+    bool ok[3][3];
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int hh = h - 1 + dh, ww = w - 1 + dw;
+        ok[dh][dw] = (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+        v[dh][dw] = load_block<NS>(a.x, xb + (ok[dh][dw] ? (long)hh * a.W + ww : 0l));
+      }
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = 0.0f;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        float f[8];
+        block_to_f32<NS>(v[dh][dw], f);
+        if (ok[dh][dw]) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) r[e] += f[e];
+        }
+      }
+    const float inv = 1.0f / 9.0f;
+    float y[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = cb * 8 + e;
+      const float b = a.bias ? ld(a.bias + ch) : 0.0f;
+      const float sc = a.scale ? ld(a.scale + ch) : 1.0f, sh = a.scale ? ld(a.shift + ch) : 0.0f;
+      y[e] = fmaxf((r[e] * inv + b) * sc + sh, a.floor_v);
+    }
+    const long o = view_base(a.dst, img, h * a.W + w) + (long)cb * a.dst.stride_c;
+    const float lo[4] = {y[0], y[1], y[2], y[3]}, hi[4] = {y[4], y[5], y[6], y[7]};
+    store_quad<NS>(a.dst.ptr, o, 0, lo);
+    store_quad<NS>(a.dst.ptr, o, 1, hi);
+  }
+}
+
 template <int NS>
 __global__ __launch_bounds__(1024) void global_avgpool_fc_b_kernel(const void* x, const float* w, const float* bias,
                                                                    float* y, int c, int s, int n_out, int wk, int c0,
@@ -1430,6 +1494,27 @@ extern "C" int eco_poolb_forward(const eco_pool_geom* g, int32_t dt, const void*
   if (ns == 1) hipLaunchKernelGGL((poolb_kernel<1>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((poolb_kernel<3>), grid, block, 0, s, a);
   return check_launch("eco_poolb_forward");
+}
+
+extern "C" int eco_poolb_avg_affine_forward(int32_t dt, const void* x, const float* bias, const float* bn_scale,
+                                            const float* bn_shift, int32_t relu, const eco_view* dst, int64_t n, int32_t c,
+                                            int32_t h, int32_t w, void* stream) {
+  clear_error();
+  const int ns = ns_of(dt);
+  ECO_REQUIRE(ns != 0, "poolb affine: storage type must be ECO_DT_BF16 or ECO_DT_F32X3");
+  ECO_REQUIRE(x && dst && dst->ptr && n > 0 && c > 0 && c % 8 == 0 && h > 0 && w > 0,
+              "poolb affine: bad argument (channels must be a positive multiple of 8, got %d)", c);
+  ECO_REQUIRE(!bn_scale == !bn_shift, "poolb affine: bn_scale and bn_shift must be given together");
+  ECO_REQUIRE(dst->t >= 1 && dst->stride_c >= 1, "poolb affine: view needs t >= 1 and stride_c >= 1");
+  PoolBAffArgs a;
+  a.x = x; a.bias = bias; a.scale = bn_scale; a.shift = bn_shift; a.dst = *dst;
+  a.CB = c / 8; a.H = h; a.W = w;
+  a.total = (long)n * a.CB * h * w;
+  a.floor_v = relu ? 0.0f : -FLT_MAX;
+  const dim3 grid(grid_for_b(a.total)), block(256);
+  if (ns == 1) hipLaunchKernelGGL((poolb_avg_affine_kernel<1>), grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((poolb_avg_affine_kernel<3>), grid, block, 0, (hipStream_t)stream, a);
+  return check_launch("eco_poolb_avg_affine_forward");
 }
 
 extern "C" int eco_global_avgpool_fc_b_forward(const void* x, int32_t dt, const float* w, const float* bias, float* y,

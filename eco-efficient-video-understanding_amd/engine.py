@@ -851,7 +851,7 @@ class Engine:
         # AVE pool 3x3/1/1 whose only consumer is a 1x1 conv seen only through BN + ReLU: conv idx -> (pool idx, source)
         self._commute: Dict[int, Tuple[int, str]] = {}
         self._commute_pools: Dict[int, int] = {}
-        if self.pool_commute and self.siblings and not self.dt:
+        if self.pool_commute and self.siblings:   # (both layouts: eco_avgpool_affine_forward / eco_poolb_avg_affine_forward)
             for pi, P in enumerate(layers):
                 if P.type != "Pooling" or len(P.bottom_shapes[0]) != 4 or P.geom["method"] != "AVE" or \
                         list(P.geom["kernel"]) != [3, 3] or list(P.geom["stride"]) != [1, 1] or list(P.geom["pad"]) != [1, 1] or \
@@ -1067,6 +1067,12 @@ class Engine:
         lib = self.lib
         for zp, ep, label, (n_, c_, h_, w_) in after:
             self._keep.append(ep)
+            if self.dt:
+                dt = self.dt
+                self._add(i, label, lambda s, zp=zp, ep=ep, n_=n_, c_=c_, h_=h_, w_=w_: lib.poolb_avg_affine_forward(
+                    dt, zp, ep.bias, ep.bn_scale, ep.bn_shift, ep.relu, ep.act, n_, c_, h_, w_, s),
+                    {"kernel": "eco::poolb_avg_affine_kernel", "flops": 0, "bytes": 2 * self.esize * n_ * c_ * h_ * w_})
+                continue
             self._add(i, label, lambda s, zp=zp, ep=ep, n_=n_, c_=c_, h_=h_, w_=w_: lib.avgpool_affine_forward(
                 zp, ep.bias, ep.bn_scale, ep.bn_shift, ep.relu, ep.act, n_, c_, h_, w_, s),
                 {"kernel": "eco::avgpool2d_k3s1p1_affine_kernel", "flops": 0, "bytes": 8 * n_ * c_ * h_ * w_})

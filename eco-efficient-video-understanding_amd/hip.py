@@ -232,6 +232,8 @@ _SIGNATURES = {
                                     C.POINTER(ConvEpilogue), C.c_void_p, C.c_void_p]),
     "eco_stem_pack_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "eco_poolb_forward": (C.c_int, [C.POINTER(PoolGeom), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eco_poolb_avg_affine_forward": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                               C.POINTER(View), C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "eco_global_avgpool_fc_b_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                                   C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
                                                   C.c_void_p]),
@@ -391,6 +393,11 @@ class EcoLib:
 
     def poolb_forward(self, g: PoolGeom, dt: int, x: int, y: int, stream=None) -> None:
         self._check(self._dll.eco_poolb_forward(C.byref(g), int(dt), x, y, stream))
+
+    def poolb_avg_affine_forward(self, dt, x, bias, bn_scale, bn_shift, relu, dst: "View", n, c, h, w, stream=None) -> None:
+        """Blocked form of avgpool_affine_forward: x[n][c/8][h][w][8] -> 3x3/1/1 average, + bias, folded BN, ReLU -> view."""
+        self._check(self._dll.eco_poolb_avg_affine_forward(int(dt), x, bias, bn_scale, bn_shift, int(relu), C.byref(dst),
+                                                           n, c, h, w, stream))
 
     def global_avgpool_fc_b_forward(self, x, dt, w, bias, y, b, c, s, n_out, wk, c0=0, accumulate=False, stream=None) -> None:
         self._check(self._dll.eco_global_avgpool_fc_b_forward(x, int(dt), w, bias, y, b, c, s, n_out, wk, c0,

@@ -400,6 +400,12 @@ int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* plan, const 
 int eco_stem_pack_forward(const float* x, void* y, int64_t frames, int32_t h, int32_t w, int32_t dt, void* stream);
 /* PoolingLayer::Forward_gpu on a blocked tensor x[n][c/8][in...][8] -> y[n][c/8][out...][8] (rules of eco_pool_forward). */
 int eco_poolb_forward(const eco_pool_geom* g, int32_t dt, const void* x, void* y, void* stream);
+/* The AVE 3x3 / stride 1 / pad 1 pool behind its 1x1 projection on the blocked path (ABI v16; the fp32 form is
+ * eco_avgpool_affine_forward): x = the projection's raw products [n][c/8][h][w][8] without bias -> window sum / 9 + bias,
+ * folded BN, ReLU -> dst (a blocked view: strides in 8-channel vectors, as every view of eco_convb_forward). */
+int eco_poolb_avg_affine_forward(int32_t dt, const void* x, const float* bias, const float* bn_scale,
+                                 const float* bn_shift, int32_t relu, const eco_view* dst, int64_t n, int32_t c, int32_t h,
+                                 int32_t w, void* stream);
 /* eco_global_avgpool_fc_forward on a blocked volume x[b][c/8][s][8]. */
 int eco_global_avgpool_fc_b_forward(const void* x, int32_t dt, const float* w, const float* bias, float* y,
                                     int64_t b, int64_t c, int64_t s, int64_t n_out, int64_t wk, int64_t c0,
