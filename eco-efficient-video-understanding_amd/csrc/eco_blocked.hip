@@ -158,13 +158,31 @@ __device__ __forceinline__ void decode_out(const ConvBArgs& a, int n, int& img, 
 // channel mw + i*32 + (r&3) + 8*(r>>2) + 4*(l>>5) at position nw + j*32 + (l&31): the four registers of a group
 // g = r>>2 are four consecutive channels = half of one 8-channel block, so lanes l and l+32 together write whole
 // 16-byte (bf16) / 32-byte (fp32) vectors, and consecutive lanes write consecutive vectors.
+// The per-channel epilogue parameters of a workgroup's BM rows, fetched into LDS when the kernel starts: Ep[0] = bias,
+// Ep[1] = BN scale, Ep[2] = BN shift (0 / 1 / 0 where absent or past cout).  The epilogue used to load them from global
+// memory group by group -- twelve dependent round trips of ~400 cycles per tile, behind which the stores waited: on the
+// short reductions (conv2_3x3, the inception 3x3s: 18-27 stages per tile) that chain was 15-20 % of the launch
+// (profiles/r03_notes.md).  Visible to every wave after the main loop's first barrier.
+template <int BMP>
+__device__ __forceinline__ void convb_stage_params(const ConvBArgs& a, int m0, float* Ep) {
+  const int t = (int)threadIdx.x;
+  if (t < BMP) {
+    const int ch = m0 + t;
+    const bool in = ch < a.cout;
+    Ep[t] = (in && a.bias) ? ld(a.bias + ch) : 0.0f;
+    Ep[BMP + t] = (in && a.bn_scale) ? ld(a.bn_scale + ch) : 1.0f;
+    Ep[2 * BMP + t] = (in && a.bn_scale) ? ld(a.bn_shift + ch) : 0.0f;
+  }
+}
+
+// (Ep: convb_stage_params' array for the rows starting at m0; EPS = its row pitch)
 template <int TM, int TN, int NS>
 __device__ __forceinline__ void convb_epilogue(const ConvBArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw, int half,
-                                               int l31) {
+                                               int l31, const float* Ep, int EPS, int m0) {
   long e_res[TN], e_raw[TN], e_act[TN], e_act2[TN];
   int e_img[TN], e_sp[TN];
   bool e_ok[TN];
-  const bool has_bias = a.bias != nullptr, has_bn = a.bn_scale != nullptr, has_res = a.residual.ptr != nullptr;
+  const bool has_res = a.residual.ptr != nullptr;
   const bool has_raw = a.raw.ptr != nullptr, has_act = a.act.ptr != nullptr, has_act2 = has_act && a.act2.ptr != nullptr;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -209,11 +227,12 @@ __device__ __forceinline__ void convb_epilogue(const ConvBArgs& a, f32x16 (&acc)
       if (ch0 >= a.cout) continue;   // cout is a multiple of 8: the quad is inside or outside as a whole
       const int cbk = (mw + i * 32) / 8 + g;
       float pb[4], ps[4], ph[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        pb[q] = has_bias ? ld(a.bias + ch0 + q) : 0.0f;
-        ps[q] = has_bn ? ld(a.bn_scale + ch0 + q) : 1.0f;
-        ph[q] = has_bn ? ld(a.bn_shift + ch0 + q) : 0.0f;
+      {
+        const float4 b4 = *(const float4*)(Ep + (ch0 - m0)), s4 = *(const float4*)(Ep + EPS + (ch0 - m0)),
+                     h4 = *(const float4*)(Ep + 2 * EPS + (ch0 - m0));
+        pb[0] = b4.x; pb[1] = b4.y; pb[2] = b4.z; pb[3] = b4.w;
+        ps[0] = s4.x; ps[1] = s4.y; ps[2] = s4.z; ps[3] = s4.w;
+        ph[0] = h4.x; ph[1] = h4.y; ph[2] = h4.z; ph[3] = h4.w;
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -351,6 +370,9 @@ __global__ __launch_bounds__(256, 2) void convb_kernel(const ConvBArgs a) {
   const int tile = xcd_remap((int)blockIdx.x - slice * ntiles, ntiles);
   const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
   const int m0 = mblk * BM, n0 = nblk * BN;
+  constexpr int BMP_E = (BM + 63) / 64 * 64;
+  __shared__ __attribute__((aligned(16))) float Ep[3 * BMP_E];   // bias / BN scale / BN shift of this workgroup's rows
+  convb_stage_params<BMP_E>(a, m0, Ep);
   const int s_begin = (int)((long)slice * a.nstages / a.ksplit);
   const int s_end = (int)((long)(slice + 1) * a.nstages / a.ksplit);
 
@@ -478,10 +500,11 @@ __global__ __launch_bounds__(256, 2) void convb_kernel(const ConvBArgs a) {
     }
     compute((s_end - 1 - s_begin) & 1);
   }
+  if (!(s_begin < s_end)) __syncthreads();   // (no stage ran: Ep has not been published by a barrier yet)
   if (a.ksplit > 1)
     convb_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
   else
-    convb_epilogue<TM, TN, NS>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+    convb_epilogue<TM, TN, NS>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31, Ep, BMP_E, m0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -534,6 +557,9 @@ __global__ __launch_bounds__(256, 2) void convb_dma_kernel(const ConvBArgs a, co
   const int tile = xcd_remap((int)blockIdx.x - slice * ntiles, ntiles);
   const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
   const int m0 = mblk * BM, n0 = nblk * BN;
+  constexpr int BMP_E = (BM + 63) / 64 * 64;
+  __shared__ __attribute__((aligned(16))) float Ep[3 * BMP_E];   // bias / BN scale / BN shift of this workgroup's rows
+  convb_stage_params<BMP_E>(a, m0, Ep);
   const int s_begin = (int)((long)slice * a.nstages / a.ksplit);
   const int s_end = (int)((long)(slice + 1) * a.nstages / a.ksplit);
 
@@ -638,10 +664,11 @@ __global__ __launch_bounds__(256, 2) void convb_dma_kernel(const ConvBArgs a, co
       if (s + 2 < s_end) stage(s + 2, A2, B2, A1, B1);
     }
   }
+  if (!(s_begin < s_end)) __syncthreads();   // (no stage ran: Ep has not been published by a barrier yet)
   if (a.ksplit > 1)
     convb_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
   else
-    convb_epilogue<TM, TN, 1>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+    convb_epilogue<TM, TN, 1>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31, Ep, BMP_E, m0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -688,6 +715,9 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
   const int tile = xcd_remap((int)blockIdx.x - slice * ntiles, ntiles);
   const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
   const int m0 = mblk * BM, n0 = nblk * BN;
+  constexpr int BMP_E = (BM + 63) / 64 * 64;
+  __shared__ __attribute__((aligned(16))) float Ep[3 * BMP_E];   // bias / BN scale / BN shift of this workgroup's rows
+  convb_stage_params<BMP_E>(a, m0, Ep);
   const int ngroups = (a.nstages / a.taps) * a.kd;          // (channel group, depth tap)
   const int g_begin = (int)((long)slice * ngroups / a.ksplit);
   const int g_end = (int)((long)(slice + 1) * ngroups / a.ksplit);
@@ -846,10 +876,11 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
       }
     }
   }
+  if (total <= 0) __syncthreads();   // (no stage ran: Ep has not been published by a barrier yet)
   if (a.ksplit > 1)
     convb_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
   else
-    convb_epilogue<TM, TN, 1>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+    convb_epilogue<TM, TN, 1>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31, Ep, BMP_E, m0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -46,6 +46,10 @@ __device__ __forceinline__ long view_base(const eco_view& v, int img, int sp) {
 // CURRENT DEVICE only.  The macro remembers, per call site (= per kernel instantiation), thread and device ordinal,
 // that the limit was raised: a thread that moves to another device (caffe.set_device, Net(device=...)) raises it there
 // too (round-2 advisor finding: a per-thread flag left the second device at the default and its launches failed).
+// (the limit leaves 8 KB of the CU's 160 KB to a kernel's static __shared__ arrays -- the blocked kernels' epilogue
+// parameters --: the runtime rejects a dynamic limit that, with the static part, exceeds the hardware's; no launch of
+// this library asks for more than 135 KB)
+constexpr int kEcoMaxDynamicLds = 152 * 1024;
 #ifdef ECO_EMU
 #define ECO_RAISE_DYNAMIC_LDS(kernel, who) do { } while (0)
 #else
@@ -56,7 +60,7 @@ __device__ __forceinline__ long view_base(const eco_view& v, int img, int sp) {
     if (hipGetDevice(&eco_dev_) != hipSuccess) eco_dev_ = -1;                                                        \
     if (eco_dev_ < 0 || eco_dev_ >= 64 || !((eco_raised_ >> eco_dev_) & 1ull)) {                                     \
       hipError_t eco_e_ = hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                              160 * 1024);                                                           \
+                                              kEcoMaxDynamicLds);                                                    \
       if (eco_e_ != hipSuccess)                                                                                      \
         return eco::fail(ECO_ERR_RUNTIME, "%s: cannot raise the dynamic LDS limit: %s", who, hipGetErrorString(eco_e_)); \
       if (eco_dev_ >= 0 && eco_dev_ < 64) eco_raised_ |= 1ull << eco_dev_;                                           \
