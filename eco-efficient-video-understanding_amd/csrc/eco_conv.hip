@@ -140,9 +140,13 @@ __device__ __forceinline__ int col_slices(const ConvKernelArgs& a, int col) {
 // Work is ordered tile-row (i) -> 4-channel register group (g) -> tile-column (j) so that only
 // 12 per-channel parameters and 8 values are live at a time (keeps the kernel at the main
 // loop's register budget), and every batch of loads is issued before the stores that follow.
+// Ep (optional): the workgroup's per-channel parameters staged in LDS by conv_stage_params -- Ep[0..] bias,
+// Ep[EPS..] BN scale, Ep[2 EPS..] BN shift of channels m0 .. (defaults past cout); nullptr = load them from global memory
+// here.  The loads sit at the head of a dependent chain (parameters -> FMA -> store) of twelve round trips per tile: on
+// the 12-stage 1x1 reductions staging them at kernel start is worth 8 % (profiles/r03_notes.md).
 template <int TM, int TN, bool PLAIN>
 __device__ __forceinline__ void conv_epilogue_impl(const ConvKernelArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw,
-                                                   int half, int l31) {
+                                                   int half, int l31, const float* Ep = nullptr, int EPS = 0, int m0 = 0) {
   long e_res[TN], e_raw[TN], e_act[TN], e_act2[TN];
   int e_img[TN], e_sp[TN];
   bool e_ok[TN];
@@ -192,9 +196,13 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvKernelArgs& a, f32x
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int chs = (chg + q) < a.cout ? (chg + q) : 0;
-        pb[q] = has_bias ? ld(a.bias + chs) : 0.0f;
-        ps[q] = has_bn ? ld(a.bn_scale + chs) : 1.0f;
-        ph[q] = has_bn ? ld(a.bn_shift + chs) : 0.0f;
+        if (Ep) {
+          pb[q] = Ep[chg + q - m0]; ps[q] = Ep[EPS + chg + q - m0]; ph[q] = Ep[2 * EPS + chg + q - m0];
+        } else {
+          pb[q] = has_bias ? ld(a.bias + chs) : 0.0f;
+          ps[q] = has_bn ? ld(a.bn_scale + chs) : 1.0f;
+          ph[q] = has_bn ? ld(a.bn_shift + chs) : 0.0f;
+        }
       }
       // Beside f32 MFMAs every VALU instruction is matrix-pipe time (profiles/r03_notes.md), and the 1x1 convolutions
       // have one output per 100-160 MFMA k-steps: when the value v = acc + bias is not itself needed (no raw store, no
@@ -257,9 +265,24 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvKernelArgs& a, f32x
 // body and the accumulators went to scratch memory).
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw, int half,
-                                              int l31) {
-  if (a.residual.ptr == nullptr && a.raw.ptr == nullptr) conv_epilogue_impl<TM, TN, true>(a, acc, mw, nw, half, l31);
-  else conv_epilogue_impl<TM, TN, false>(a, acc, mw, nw, half, l31);
+                                              int l31, const float* Ep = nullptr, int EPS = 0, int m0 = 0) {
+  if (a.residual.ptr == nullptr && a.raw.ptr == nullptr) conv_epilogue_impl<TM, TN, true>(a, acc, mw, nw, half, l31, Ep, EPS, m0);
+  else conv_epilogue_impl<TM, TN, false>(a, acc, mw, nw, half, l31, Ep, EPS, m0);
+}
+
+// bias / BN scale / BN shift of channels m0 .. m0 + BMP - 1 into LDS (0 / 1 / 0 where absent or past cout) when the
+// kernel starts; visible after the caller's next workgroup barrier.  (Plain loads + ds_write: an LDS-DMA form of the
+// same -- no registers, nothing waited for -- measured slower on both paths, profiles/r03_notes.md.)
+template <int BMP>
+__device__ __forceinline__ void conv_stage_params(const ConvKernelArgs& a, int m0, float* Ep) {
+  const int t = (int)threadIdx.x;
+  if (t < BMP) {
+    const int ch = m0 + t;
+    const bool in = ch < a.cout;
+    Ep[t] = (in && a.bias) ? ld(a.bias + ch) : 0.0f;
+    Ep[BMP + t] = (in && a.bn_scale) ? ld(a.bn_scale + ch) : 1.0f;
+    Ep[2 * BMP + t] = (in && a.bn_scale) ? ld(a.bn_shift + ch) : 0.0f;
+  }
 }
 
 // Split-K: a workgroup that only covered a slice of the reduction stores its raw accumulators to
@@ -1139,6 +1162,8 @@ __global__ __launch_bounds__(256, 2) void conv_point_kernel(const ConvKernelArgs
   const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
   const int m0 = mblk * BM, n0 = nblk * BN;
   const int nstages = a.cin / KC;
+  __shared__ __attribute__((aligned(16))) float Ep[3 * BMP];   // bias / BN scale / BN shift of this workgroup's rows
+  conv_stage_params<BMP>(a, m0, Ep);
 
   // this lane's four positions n0 + 4*lane .. +3 (one image: s_out % 4 == 0)
   long lane_base;
@@ -1201,7 +1226,7 @@ __global__ __launch_bounds__(256, 2) void conv_point_kernel(const ConvKernelArgs
     compute(buf);
     buf = buf == 2 ? 0 : buf + 1;
   }
-  conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
+  conv_epilogue<TM, TN>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31, Ep, BMP, m0);
 }
 
 static int validate_geom(const eco_conv_geom* g) {
