@@ -26,6 +26,17 @@ def test_header_matches_binding():
     assert declared_symbols() == sorted(hip.EXPORTED_SYMBOLS)
 
 
+def test_integration_guide_names_every_entry_point():
+    """INTEGRATION.md tells a caffe_3d maintainer which reference interface each entry point replaces: none may be missing
+    (families are written `eco_stemb_*`)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    families = [m[:-1] for m in re.findall(r"\beco_[a-z0-9_]+_\*", text)]
+    missing = [s for s in declared_symbols()
+               if s not in text and s.replace("_ex", "") not in text and not any(s.startswith(f) for f in families)]
+    assert not missing, missing
+    assert f"v{hip.ABI_VERSION}" in text
+
+
 def test_header_compiles_as_plain_c(tmp_path):
     """The boundary is a C ABI: the header must be valid C99 on its own (a cgo / JNI / ctypes-generator user
     compiles it as C, not C++), and a C translation unit that names every entry point must compile."""
