@@ -383,7 +383,13 @@ __device__ __forceinline__ WinoViewOffsets wino_view_offsets(const WinoOutDmArgs
 
 // Second half of an output tile: y = s4 A with s4 = A^T m (4 x 6), then the fused epilogue, for channel `ch` (view
 // offsets `o`), depth `d`, tile (th, tw).
-template <int VEC>
+// PRE (the stand-alone output transform): the tile's residual values are fetched before the first store -- as written
+// below a row's residual load follows the previous row's stores, which may alias it for all the compiler knows: four
+// dependent round trips per tile, visible on the latency-bound res4 / res5 launches (res5b_2 took twice res5b_1's time;
+// output transforms 0.78 -> 0.72 ms per step).  Issuing them, and the parameters, even earlier -- ahead of the 36 loads of
+// M -- was slower again (more registers live across those loads).  wfused_kernel (no residuals in its layers, 246 VGPRs)
+// keeps the in-loop form.
+template <int VEC, bool PRE = false>
 __device__ __forceinline__ void wino_output_store(const WinoOutDmArgs& a, const float (&s4)[4][6], int ch, const WinoViewOffsets& o,
                                                   int d, int th, int tw) {
   typedef typename WgVec<VEC>::type vec_t;
@@ -393,6 +399,15 @@ __device__ __forceinline__ void wino_output_store(const WinoOutDmArgs& a, const 
   const float floor_v = a.relu ? 0.0f : -3.402823466e38f;   // one v_max instead of v_max + v_cndmask per output
   const bool plain = a.act.ptr && !a.residual.ptr && !a.raw.ptr;
   const float sh2 = b * sc + sh;
+  vec_t resv[4][4 / VEC];
+  if (PRE && !plain && a.residual.ptr) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q0 = 0; q0 < 4; q0 += VEC)
+        if (4 * th + p < a.H && 4 * tw + q0 < a.W)
+          resv[p][q0 / VEC] = ld((const vec_t*)((const float*)a.residual.ptr + o.res + (d * a.H + 4 * th + p) * a.W + 4 * tw + q0));
+  }
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int h = 4 * th + p;
@@ -417,7 +432,7 @@ __device__ __forceinline__ void wino_output_store(const WinoOutDmArgs& a, const 
 #pragma unroll
       for (int e = 0; e < VEC; ++e) val[e] = yrow[q0 + e] + b;
       if (a.residual.ptr) {
-        const vec_t rv = ld((const vec_t*)((const float*)a.residual.ptr + o.res + sp));
+        const vec_t rv = PRE ? resv[p][q0 / VEC] : ld((const vec_t*)((const float*)a.residual.ptr + o.res + sp));
 #pragma unroll
         for (int e = 0; e < VEC; ++e) val[e] += ((const float*)&rv)[e];
       }
@@ -441,7 +456,7 @@ __device__ __forceinline__ void wino_output_store(const WinoOutDmArgs& a, const 
 template <int VEC>
 __device__ __forceinline__ void wino_output_from_s4(const WinoOutDmArgs& a, const float (&s4)[4][6], int ch, int img, int d,
                                                     int th, int tw) {
-  wino_output_store<VEC>(a, s4, ch, wino_view_offsets(a, img, ch), d, th, tw);
+  wino_output_store<VEC, true>(a, s4, ch, wino_view_offsets(a, img, ch), d, th, tw);
 }
 
 // One output tile: y = A^T m A, then the fused epilogue.
