@@ -335,6 +335,9 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKerne
     int img, sp;
     decode_pos(a, n, img, sp);
     const float b = a.bias ? ld(a.bias + ch) : 0.0f;
+    // (the BN parameters too, ahead of the raw store: behind it their loads would be a round trip of their own -- the
+    // store may alias them for all the compiler knows)
+    const float sc = (a.act.ptr && a.bn_scale) ? ld(a.bn_scale + ch) : 1.0f, sh = (a.act.ptr && a.bn_scale) ? ld(a.bn_shift + ch) : 0.0f;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v[e] += b;
     if (a.residual.ptr) {
@@ -352,7 +355,6 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKerne
       else st(o, v[0]);
     }
     if (a.act.ptr) {
-      const float sc = a.bn_scale ? ld(a.bn_scale + ch) : 1.0f, sh = a.bn_scale ? ld(a.bn_shift + ch) : 0.0f;
       eco_view av = a.act;       // sibling launches: the channel's own destination (ptr already moved back)
       int relu = a.relu;
       if (a.nseg > 0 && ch >= a.seg_begin[0]) {
