@@ -28,6 +28,11 @@ extern "C" int eco_abi_version(void) { return ECO_ABI_VERSION; }
 
 extern "C" const char* eco_last_error(void) { return error_buffer(); }
 
+#ifndef ECO_SRC_DIGEST
+#define ECO_SRC_DIGEST "unknown"
+#endif
+extern "C" const char* eco_source_digest(void) { return ECO_SRC_DIGEST; }
+
 #ifdef ECO_EMU
 
 extern "C" int eco_is_device_build(void) { return 0; }
@@ -45,6 +50,11 @@ extern "C" int eco_device_info(int device, char* name, size_t name_len, int* num
   clear_error();
   (void)name; (void)name_len; (void)num_cu; (void)hbm_bytes;
   return fail(ECO_ERR_RUNTIME, "device_info(%d): this is the CPU emulator build (tests only); no HIP device", device);
+}
+extern "C" int eco_device_pci_bus_id(int device, char* pci, size_t len) {
+  clear_error();
+  (void)pci; (void)len;
+  return fail(ECO_ERR_RUNTIME, "device_pci_bus_id(%d): this is the CPU emulator build (tests only); no HIP device", device);
 }
 
 #else
@@ -79,6 +89,16 @@ extern "C" int eco_device_info(int device, char* name, size_t name_len, int* num
   }
   if (num_cu) *num_cu = p.multiProcessorCount;
   if (hbm_bytes) *hbm_bytes = (uint64_t)p.totalGlobalMem;
+  return ECO_OK;
+}
+
+extern "C" int eco_device_pci_bus_id(int device, char* pci, size_t len) {
+  clear_error();
+  ECO_REQUIRE(pci != nullptr && len >= 13, "device_pci_bus_id: buffer of at least 13 bytes needed");
+  hipError_t e = hipDeviceGetPCIBusId(pci, (int)len, device);
+  if (e != hipSuccess) return fail(ECO_ERR_RUNTIME, "hipDeviceGetPCIBusId(%d): %s", device, hipGetErrorString(e));
+  for (char* c = pci; *c; ++c)
+    if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');   // sysfs spells the address in lower case
   return ECO_OK;
 }
 

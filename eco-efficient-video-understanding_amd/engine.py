@@ -704,11 +704,13 @@ class Engine:
             st["stem_buf"] = self.alloc.empty(need, self.store_np)
             st["stem_elems"] = need
 
-    def _emit_blocked_conv(self, i: int, L: LayerSpec, ep: "hip.ConvEpilogue", label: str) -> None:
+    def _emit_blocked_conv(self, i: int, L: LayerSpec, ep: "hip.ConvEpilogue", label: str,
+                           src_name: Optional[str] = None) -> None:
         st = self._param_dev[L.name]
         g, bp = st["geom"], st["bplan"]
         lib, dt = self.lib, self.dt
-        src = self.tensors[L.bottoms[0]]
+        in_name = src_name if src_name is not None else L.bottoms[0]   # (src_name: a conv that runs ahead of its AVE pool)
+        src = self.tensors[in_name]
         wp = self.alloc.ptr(st["wp"])
         ws = self.alloc.ptr(self._ws) if bp.ws_bytes else None
         self._keep.append((g, bp, ep))
@@ -729,15 +731,15 @@ class Engine:
                        "bytes": es * st["stem_elems"] + 2 * k * L.geom["cout"] + es * n_out * outs})
             return
         if not src.dt:
-            raise NetSpecError(f"{L.name}: input blob {L.bottoms[0]} is not channel-blocked")
-        x = self._ptr(L.bottoms[0])
+            raise NetSpecError(f"{L.name}: input blob {in_name} is not channel-blocked")
+        x = self._ptr(in_name)
         self._add(i, label, lambda s, g=g, bp=bp, x=x, wp=wp, ep=ep, ws=ws: lib.convb_forward(g, bp, x, wp, ep, ws, s),
                   {"kernel": hip.convb_kernel_name(bp), "flops": 2 * n_out * k,
                    "bytes": es * _prod(L.bottom_shapes[0]) + 2 * k * L.geom["cout"] + es * n_out * outs})
 
     def _emit_conv(self, i: int, L: LayerSpec, ep: "hip.ConvEpilogue", label: str, src: Optional[str] = None) -> None:
         if self.dt:
-            self._emit_blocked_conv(i, L, ep, label)
+            self._emit_blocked_conv(i, L, ep, label, src_name=src)
             return
         st = self._param_dev[L.name]
         g, plan = st["geom"], st["plan"]
@@ -1035,6 +1037,12 @@ class Engine:
             if ep is None:
                 continue                                  # (emitted by _conv_epilogue itself)
             plain = not ep.residual.ptr and not ep.act2.ptr
+            if j in commuted and (ep.act2.ptr or ep.raw.ptr or ep.residual.ptr or not ep.act.ptr):
+                # the pool-affine kernels write ONE activated destination: an epilogue with a second / raw / residual
+                # destination cannot ride on them (the pre-pass only registers convs whose BN+ReLU blob has a single
+                # consumer, so this is a planner invariant, not a user error)
+                raise NetSpecError(f"{Lj.name}: pool_commute cannot express this epilogue (act2 / raw / residual set); "
+                                   f"build the net with pool_commute=False")
             if j in commuted:
                 # conv first, on the pool's input and without its bias, raw into a scratch tensor; the window average,
                 # bias, BN and ReLU follow on the conv's channels and write the destination the epilogue chose
@@ -1131,8 +1139,9 @@ class Engine:
         meta = {"kernel": hip.convb_kernel_name(plan) if self.dt else hip.conv_kernel_name(plan), "flops": 2 * n_out * k,
                 "bytes": es * (_prod(L.bottom_shapes[0]) + n_out) + (2 if self.dt else 4) * k * ctot, "siblings": len(Ls)}
         if self.dt:
-            if not self.tensors[L.bottoms[0]].dt:
-                raise NetSpecError(f"{L.name}: input blob {L.bottoms[0]} is not channel-blocked")
+            in_name = src if src is not None else L.bottoms[0]   # (a commuted conv leading its group: its bottom, the
+            if not self.tensors[in_name].dt:                     #  pool's top, is never materialised)
+                raise NetSpecError(f"{L.name}: input blob {in_name} is not channel-blocked")
 
             def run(s, g=geom, plan=plan, x=x, wp=wp, ep=ep):
                 lib.convb_forward(g, plan, x, wp, ep, self.alloc.ptr(self._ws) if plan.ws_bytes else None, s)

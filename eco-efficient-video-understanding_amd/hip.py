@@ -21,7 +21,7 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 16
+ABI_VERSION = 17
 MAX_SEG = 3   # ECO_MAX_SEG: extra output segments of a sibling launch
 DT_BF16 = 1
 DT_F32X3 = 3
@@ -169,6 +169,8 @@ _SIGNATURES = {
     "eco_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "eco_set_device": (C.c_int, [C.c_int]),
     "eco_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "eco_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "eco_source_digest": (C.c_char_p, []),
     "eco_conv_plan_create": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvPlan)]),
     "eco_conv_plan_create_ex": (C.c_int, [C.POINTER(ConvGeom), C.c_int32, C.POINTER(ConvPlan)]),
     "eco_conv_plan_create_batched": (C.c_int, [C.POINTER(ConvGeom), C.c_int32, C.c_int32, C.POINTER(ConvPlan)]),
@@ -285,6 +287,16 @@ class EcoLib:
         mem = C.c_uint64(0)
         self._check(self._dll.eco_device_info(int(dev), name, 256, C.byref(cu), C.byref(mem)))
         return {"name": name.value.decode(), "num_cu": cu.value, "hbm_bytes": mem.value}
+
+    def device_pci_bus_id(self, dev: int) -> str:
+        """PCI address of the device as sysfs spells it ("0000:c1:00.0")."""
+        buf = C.create_string_buffer(32)
+        self._check(self._dll.eco_device_pci_bus_id(int(dev), buf, 32))
+        return buf.value.decode()
+
+    def source_digest(self) -> str:
+        """SHA-256 of the sources this library was built from (csrc/Makefile), or "unknown"."""
+        return (self._dll.eco_source_digest() or b"unknown").decode()
 
     # -- convolution ----------------------------------------------------------
     def conv_plan(self, g: ConvGeom, num_cu: Optional[int] = None, batch: int = 1) -> ConvPlan:

@@ -383,7 +383,9 @@ class Net:
             eng.forward()                            # warm-up on the normal stream
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):                # capture stream becomes torch's current stream
+            # thread-local capture mode: only THIS thread's calls are checked against the capture -- a communicator's
+            # watchdog thread (RCCL at N > 1) polling its events must not invalidate it
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # capture stream becomes torch's current stream
                 eng.forward()
             self._graph, self._graph_key = g, eng.generation
         self._graph.replay()

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 16
+#define ECO_ABI_VERSION 17
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -63,6 +63,15 @@ int eco_device_count(int* count);
 int eco_set_device(int device);
 /* Fills name (NUL-terminated, <= name_len), compute-unit count and HBM bytes of `device`. */
 int eco_device_info(int device, char* name, size_t name_len, int* num_cu, uint64_t* hbm_bytes);
+/* PCI address of `device` as sysfs spells it ("0000:c1:00.0", NUL-terminated, <= len): what a multi-process launcher
+ * needs to put each rank on the cores of ITS GPU's NUMA node (the reference is one unpinned MPI process per GPU,
+ * caffe_3d/tools/caffe.cpp:150-200).  (v17) */
+int eco_device_pci_bus_id(int device, char* pci, size_t len);
+/* SHA-256 (64 hex digits) of the sources this library was built from -- the .hip and .h files of csrc, this header and the
+ * Makefile, concatenated in sorted path order -- so that measurements (profiles/) can be tied to a build by what it was
+ * built FROM: two builds of identical sources differ in their bytes, not in this digest.  "unknown" when the library
+ * was compiled outside csrc/Makefile.  (v17) */
+const char* eco_source_digest(void);
 
 /* ---- convolution (+ fused bias / residual / BN / ReLU epilogue) -------------------- */
 

@@ -1,10 +1,11 @@
 """ctypes binding of oracle/_ref/libeco_ref.so -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
 ``libeco_ref.so`` is built by oracle/Makefile from the reference's own, unmodified sources
-(caffe_3d/src/caffe/util/im2col.cpp and layers/{pooling,bn,permute,eltwise,concat,inner_product,reshape,relu}_layer.cpp)
-behind the stand-in headers of oracle/ref_shim/, plus ``ref_conv_forward`` = the reference's
-ConvolutionLayer::Forward_cpu call sequence (per image: reference im2col -> cblas_sgemm -> bias sgemm;
-conv_layer.cpp:28-43, base_conv_layer.cpp:264-287).
+(caffe_3d/src/caffe/util/im2col.cpp and layers/{pooling,bn,permute,eltwise,concat,inner_product,reshape,relu,
+base_conv,conv}_layer.cpp) behind the stand-in headers of oracle/ref_shim/: ``convolution_layer`` runs the compiled
+ConvolutionLayer class itself; ``convolution`` (``ref_conv_forward``) is the same call sequence (per image: reference
+im2col -> cblas_sgemm -> bias sgemm; conv_layer.cpp:28-43, base_conv_layer.cpp:264-287) with an option to spread a
+batch's images over host threads, pinned bit-identically to the class by tests/test_oracle_ref.py.
 The GEMM is SciPy's bundled OpenBLAS (``scipy_cblas_sgemm``), the class of library the reference links.
 
 Only tests/ and bench.py's cpu_baseline leg may import this; it pins oracle/eco_oracle.py against compiled
@@ -85,6 +86,10 @@ def lib():
             d.ref_inner_product_forward.argtypes = [fp, ip, C.c_int, fp, fp, C.c_int, C.c_int, fp]
             d.ref_reshape_shape.argtypes = [ip, C.c_int, C.POINTER(C.c_longlong), C.c_int, C.c_int, C.c_int, ip]
             d.ref_relu_forward.argtypes = [fp, C.c_long, C.c_float, fp]
+            if hasattr(d, "ref_convolution_layer_forward"):   # (round 4: the compiled ConvolutionLayer class)
+                d.ref_convolution_layer_forward.argtypes = [fp, ip, C.c_int, fp, fp, C.c_int, ip, C.c_int, ip, C.c_int,
+                                                            ip, C.c_int, C.c_int, fp, ip]
+                d.ref_convolution_layer_forward.restype = C.c_int
             for f in ("ref_bn_forward", "ref_permute_forward", "ref_eltwise_forward", "ref_concat_forward",
                       "ref_inner_product_forward", "ref_reshape_shape", "ref_relu_forward"):
                 getattr(d, f).restype = C.c_int
@@ -98,8 +103,17 @@ def has_layers() -> bool:
     return hasattr(lib(), "ref_bn_forward")
 
 
+def has_conv_layer() -> bool:
+    """True when the loaded library carries the compiled BaseConvolutionLayer / ConvolutionLayer."""
+    return hasattr(lib(), "ref_convolution_layer_forward")
+
+
 def _ia(v):
     return (C.c_int * len(v))(*[int(x) for x in v])
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
 
 
 def im2col(x: np.ndarray, kernel, stride, pad) -> np.ndarray:
@@ -140,6 +154,24 @@ def convolution(x, w, b, kernel, stride, pad, image_threads: int = 1) -> np.ndar
     return y
 
 
+def convolution_layer(x, w, b, kernel, stride=(), pad=(), force_nd_im2col: bool = False) -> np.ndarray:
+    """The compiled ConvolutionLayer<float> itself: LayerSetUp / Reshape (base_conv_layer.cpp:13-262) and Forward_cpu
+    (conv_layer.cpp:28-43) over OpenBLAS sgemm.  kernel / stride / pad as the prototxt's repeated fields (one value, or one
+    per spatial axis; stride / pad may be empty = the schema defaults 1 / 0)."""
+    x, w = _f32(x), _f32(w)
+    bb = None if b is None else _f32(b)
+    out = (C.c_int * x.ndim)()
+    args = (_ia(x.shape), x.ndim)
+    geo = (_ia(kernel), len(kernel), _ia(stride) if len(stride) else None, len(stride), _ia(pad) if len(pad) else None,
+           len(pad), int(force_nd_im2col))
+    lib().ref_convolution_layer_forward(None, *args, None, None if bb is None else bb.ctypes.data, w.shape[0], *geo, None, out)
+    y = np.empty(tuple(out), np.float32)
+    rc = lib().ref_convolution_layer_forward(x.ctypes.data, *args, w.ctypes.data, None if bb is None else bb.ctypes.data,
+                                             w.shape[0], *geo, y.ctypes.data, out)
+    assert rc == 0
+    return y
+
+
 def pooled_shape(shape, method, kernel, stride, pad):
     """PoolingLayer::LayerSetUp + Reshape (the ceil rule, pooling_layer.cpp:117-147) for a 2-D or 3-D blob shape."""
     out = (C.c_int * len(shape))()
@@ -162,9 +194,6 @@ def pooling(x, method, kernel, stride, pad) -> np.ndarray:
 
 
 # ---- the other layer types of the deploy graphs, through their compiled reference Forward_cpu ------------------------
-def _f32(a):
-    return np.ascontiguousarray(a, np.float32)
-
 
 def bn_inference(x, slope, bias, mean, var, eps, frozen: bool = False) -> np.ndarray:
     """BNLayer::Forward_cpu, TEST phase (bn_layer.cpp:93-207).  Blobs of at most 4 axes -- the reference's CPU code

@@ -27,6 +27,12 @@ class Blob {
   int shape(int i) const { return shape_[CanonicalAxisIndex(i)]; }
   int num_axes() const { return (int)shape_.size(); }
   int count() const { return count_; }
+  string shape_string() const {   // blob.hpp:56-63
+    std::ostringstream stream;
+    for (size_t i = 0; i < shape_.size(); ++i) stream << shape_[i] << " ";
+    stream << "(" << count_ << ")";
+    return stream.str();
+  }
   int count(int start_axis, int end_axis) const {
     CHECK_LE(start_axis, end_axis);
     CHECK_GE(start_axis, 0);

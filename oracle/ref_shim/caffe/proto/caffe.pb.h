@@ -1,5 +1,6 @@
 // oracle/ref_shim: hand-written stand-in for the protoc-generated caffe.pb.h -- only the messages and accessors the
-// compiled reference layer files call (schema: caffe_3d/src/caffe/proto/caffe.proto; PoolingParameter, BNParameter,
+// compiled reference layer files call (schema: caffe_3d/src/caffe/proto/caffe.proto; ConvolutionParameter,
+// PoolingParameter, BNParameter,
 // PermuteParameter, EltwiseParameter, ConcatParameter, InnerProductParameter, ReshapeParameter / BlobShape,
 // ReLUParameter, FillerParameter, ParamSpec, LayerParameter).  Defaults are the schema's.
 #pragma once
@@ -45,6 +46,41 @@ class FillerParameter {
   float value_ = 0.0f;
   const std::string& type() const { return type_; }
   float value() const { return value_; }
+};
+class ConvolutionParameter {   // caffe.proto:506-555 (group 1, axis 1, bias_term true, force_nd_im2col false by default)
+ public:
+  unsigned num_output_ = 0, group_ = 1;
+  bool bias_term_ = true, force_nd_im2col_ = false;
+  int axis_ = 1;
+  std::vector<unsigned> kernel_size_, stride_, pad_;
+  bool has_kh_ = false, has_kw_ = false, has_sh_ = false, has_sw_ = false, has_ph_ = false, has_pw_ = false;
+  unsigned kh_ = 0, kw_ = 0, sh_ = 0, sw_ = 0, ph_ = 0, pw_ = 0;
+  FillerParameter weight_filler_, bias_filler_;
+  unsigned num_output() const { return num_output_; }
+  unsigned group() const { return group_; }
+  bool bias_term() const { return bias_term_; }
+  bool force_nd_im2col() const { return force_nd_im2col_; }
+  int axis() const { return axis_; }
+  int kernel_size_size() const { return (int)kernel_size_.size(); }
+  unsigned kernel_size(int i) const { return kernel_size_[i]; }
+  int stride_size() const { return (int)stride_.size(); }
+  unsigned stride(int i) const { return stride_[i]; }
+  int pad_size() const { return (int)pad_.size(); }
+  unsigned pad(int i) const { return pad_[i]; }
+  bool has_kernel_h() const { return has_kh_; }
+  bool has_kernel_w() const { return has_kw_; }
+  bool has_stride_h() const { return has_sh_; }
+  bool has_stride_w() const { return has_sw_; }
+  bool has_pad_h() const { return has_ph_; }
+  bool has_pad_w() const { return has_pw_; }
+  unsigned kernel_h() const { return kh_; }
+  unsigned kernel_w() const { return kw_; }
+  unsigned stride_h() const { return sh_; }
+  unsigned stride_w() const { return sw_; }
+  unsigned pad_h() const { return ph_; }
+  unsigned pad_w() const { return pw_; }
+  const FillerParameter& weight_filler() const { return weight_filler_; }
+  const FillerParameter& bias_filler() const { return bias_filler_; }
 };
 class ParamSpec {
  public:
@@ -133,6 +169,7 @@ class ReLUParameter {
 };
 class LayerParameter {
  public:
+  ConvolutionParameter convolution_param_;
   PoolingParameter pooling_param_;
   BNParameter bn_param_;
   PermuteParameter permute_param_;
@@ -142,6 +179,7 @@ class LayerParameter {
   ReshapeParameter reshape_param_;
   ReLUParameter relu_param_;
   ParamSpecList param_;
+  const ConvolutionParameter& convolution_param() const { return convolution_param_; }
   const PoolingParameter& pooling_param() const { return pooling_param_; }
   PoolingParameter* mutable_pooling_param() { return &pooling_param_; }
   const BNParameter& bn_param() const { return bn_param_; }

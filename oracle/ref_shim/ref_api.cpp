@@ -9,11 +9,16 @@
 //   caffe_3d/src/caffe/layers/inner_product_layer.cpp   InnerProductLayer
 //   caffe_3d/src/caffe/layers/reshape_layer.cpp         ReshapeLayer (shape rules)
 //   caffe_3d/src/caffe/layers/relu_layer.cpp            ReLULayer
-// plus a convolution forward that performs exactly the call sequence of ConvolutionLayer::Forward_cpu
+//   caffe_3d/src/caffe/layers/base_conv_layer.cpp       BaseConvolutionLayer (LayerSetUp / Reshape / forward_cpu_gemm / _bias)
+//   caffe_3d/src/caffe/layers/conv_layer.cpp            ConvolutionLayer (compute_output_shape / Forward_cpu)
+// i.e. every layer type of the ECO deploy graphs that computes (Split / Dropout(TEST) are identities), as the
+// reference's own object code: ref_convolution_layer_forward below runs the compiled class.
+// plus ref_conv_forward, a second convolution forward that performs exactly the call sequence of ConvolutionLayer::Forward_cpu
 // (layers/conv_layer.cpp:28-43 -> BaseConvolutionLayer::forward_cpu_gemm / forward_cpu_bias,
 // layers/base_conv_layer.cpp:264-287 -> caffe_cpu_gemm, util/math_functions.cpp:12-21): per image, the
 // REFERENCE im2col into a col buffer, one cblas_sgemm W[cout x K] * col[K x S], and the bias as a rank-1 sgemm
-// against an all-ones multiplier.  cblas_sgemm is the one third-party routine (the reference links
+// against an all-ones multiplier -- kept because it can spread the images of a batch over host threads (bench.py's
+// image-parallel CPU baseline); tests/test_oracle_ref.py pins it bit-identically to the compiled class.  cblas_sgemm is the one third-party routine (the reference links
 // ATLAS/OpenBLAS/MKL, unpinned); here it is SciPy's bundled OpenBLAS, resolved at run time by the Python side
 // and handed in as a function pointer, so this library links nothing.
 // Used to pin oracle/eco_oracle.py (tests/test_oracle_ref.py) and as bench.py's CPU baseline.
@@ -160,6 +165,37 @@ int ref_relu_forward(const float* x, long count, float negative_slope, float* y)
   fill(bottom, std::vector<int>(1, (int)count), x);
   BlobVec bv(1, &bottom), tv(1, &top);
   layer.Reshape(bv, tv);
+  layer.Forward_cpu(bv, tv);
+  caffe_copy(top.count(), top.cpu_data(), y);
+  return 0;
+}
+
+// ConvolutionLayer<float>: LayerSetUp / Reshape (base_conv_layer.cpp:13-262) / Forward_cpu (conv_layer.cpp:28-43), the
+// compiled class itself.  x: [n, cin, spatial...] (naxes = 2 + nsp); kernel / stride / pad: nk / ns / np repeated-field
+// entries exactly as a prototxt gives them (one value, or one per spatial axis; ns / np may be 0 = schema defaults);
+// w: [num_output, cin, kernel...]; b: [num_output] or NULL (bias_term false).  out_shape receives the top shape; y may
+// be NULL to query it.
+int ref_convolution_layer_forward(const float* x, const int* shape, int naxes, const float* w, const float* b, int num_output,
+                                  const int* kernel, int nk, const int* stride, int ns, const int* pad, int np,
+                                  int force_nd_im2col, float* y, int* out_shape) {
+  LayerParameter lp;
+  ConvolutionParameter& cp = lp.convolution_param_;
+  cp.num_output_ = (unsigned)num_output;
+  cp.bias_term_ = b != nullptr;
+  cp.force_nd_im2col_ = force_nd_im2col != 0;
+  for (int i = 0; i < nk; ++i) cp.kernel_size_.push_back((unsigned)kernel[i]);
+  for (int i = 0; i < ns; ++i) cp.stride_.push_back((unsigned)stride[i]);
+  for (int i = 0; i < np; ++i) cp.pad_.push_back((unsigned)pad[i]);
+  ConvolutionLayer<float> layer(lp);
+  Blob<float> bottom, top;
+  fill(bottom, shape_of(shape, naxes), y ? x : nullptr);
+  BlobVec bv(1, &bottom), tv(1, &top);
+  layer.LayerSetUp(bv, tv);                        // creates blobs_[0] (and [1]) through the constant filler
+  layer.Reshape(bv, tv);
+  for (int i = 0; i < naxes; ++i) out_shape[i] = top.shape(i);
+  if (!y) return 0;
+  caffe_copy(layer.blobs()[0]->count(), w, layer.blobs()[0]->mutable_cpu_data());
+  if (b) caffe_copy(layer.blobs()[1]->count(), b, layer.blobs()[1]->mutable_cpu_data());
   layer.Forward_cpu(bv, tv);
   caffe_copy(top.count(), top.cpu_data(), y);
   return 0;

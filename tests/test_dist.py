@@ -140,6 +140,15 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 4
     assert line["config"]["collective_ranks"] == 2 and line["config"]["collective_backend"] == "gloo"
     assert line["value"] > 0 and line["cpu_baseline"] is None and "step_frac" in line["roofline"]
+    # N > 1 diagnostics (round-3 verdict): hipGraph replay by default, per-rank step times, the all-gather's own latency
+    # and where rank 0 was pinned -- a sub-linear curve must be diagnosable from this one record
+    cfg = line["config"]
+    assert cfg["submission"].startswith("hipGraph replay"), cfg["submission"]
+    rs = cfg["rank_step_ms"]
+    assert len(rs["per_rank_wall"]) == 2 and rs["min"] <= rs["median"] <= rs["max"] == max(rs["per_rank_wall"])
+    assert abs(rs["max"] - line["ms_per_step"]) < 0.05 * line["ms_per_step"] + 0.01
+    assert cfg["allgather_us"]["max_over_ranks_of_max"] >= cfg["allgather_us"]["median_over_ranks_of_median"] > 0
+    assert cfg["rank0_affinity"] is None or "error" not in cfg["rank0_affinity"], cfg["rank0_affinity"]
     # an N > 1 line still carries a parity field (rank 0's first clip against the CPU reference)
     assert line["parity"]["clips_checked"] == 1 and line["parity"]["max_rel_err"] < 1e-3, line["parity"]
 
@@ -187,6 +196,15 @@ for _ in range(3):                       # the collective is ordered behind the 
     dist.all_gather_into_tensor(out, logits)
 torch.cuda.synchronize()
 assert torch.equal(out, logits) and bool(torch.isfinite(out).all()), (out, logits)
+# bench.py's default at N > 1: the launch list replayed as one hipGraph, captured while the communicator (and its
+# watchdog thread) is alive, the collective issued eagerly behind each replay
+eager = logits.clone()
+out.fill_(float("nan"))
+for _ in range(3):
+    net.forward_device(graph=True)
+    dist.all_gather_into_tensor(out, logits)
+torch.cuda.synchronize()
+assert torch.equal(out, eager), (out, eager)
 print("RCCL_OK", dist.get_backend(), dist.get_world_size())
 dist.destroy_process_group()
 """
@@ -212,3 +230,86 @@ def test_rccl_collective_behind_engine_launches(tmp_path):
         pytest.skip("RCCL cannot bootstrap here: " + out.stderr.strip().splitlines()[-1][:200])
     assert out.returncode == 0, out.stderr[-3000:]
     assert "RCCL_OK nccl 1" in out.stdout
+
+
+# ---- rank placement on the host (eco_amd.dist.plan_rank_cpus): fake sysfs trees -----------------------------------------
+def _fake_sysfs(tmp_path, sockets, cores_per_socket, smt, gpus_per_socket, numa_known=True):
+    """A two-level topology the way Linux numbers a dual-socket SMT host: CPU c and c + sockets*cores_per_socket are the
+    two hyper-threads of one core; socket s holds cores [s*cores_per_socket, (s+1)*cores_per_socket).  GPUs are PCI
+    devices 0000:<i>1:00.0, `gpus_per_socket` per NUMA node."""
+    import os
+    ncore = sockets * cores_per_socket
+    root = tmp_path / "sys"
+    for c in range(ncore * smt):
+        d = root / "devices" / "system" / "cpu" / f"cpu{c}" / "topology"
+        d.mkdir(parents=True)
+        core = c % ncore
+        (d / "thread_siblings_list").write_text(",".join(str(core + k * ncore) for k in range(smt)) + "\n")
+    pci = []
+    for s in range(sockets):
+        cpus = [c + k * ncore for k in range(smt) for c in range(s * cores_per_socket, (s + 1) * cores_per_socket)]
+        nd = root / "devices" / "system" / "node" / f"node{s}"
+        nd.mkdir(parents=True)
+        lo, hi = s * cores_per_socket, (s + 1) * cores_per_socket - 1
+        (nd / "cpulist").write_text(",".join(f"{lo + k * ncore}-{hi + k * ncore}" for k in range(smt)) + "\n")
+        for g in range(gpus_per_socket):
+            bus = f"0000:{s * gpus_per_socket + g:x}1:00.0"
+            d = root / "bus" / "pci" / "devices" / bus
+            d.mkdir(parents=True)
+            (d / "numa_node").write_text(f"{s if numa_known else -1}\n")
+            (d / "local_cpulist").write_text((nd / "cpulist").read_text() if numa_known else "")
+            pci.append(bus.upper() if g % 2 else bus)          # HIP reports upper-case hex on some stacks
+    return str(root), pci
+
+
+def test_rank_cpus_follow_the_gpu_numa_node_and_never_split_a_core(tmp_path):
+    from eco_amd import dist as ed
+    sysfs, pci = _fake_sysfs(tmp_path, sockets=2, cores_per_socket=16, smt=2, gpus_per_socket=4)
+    allowed = range(64)
+    plan = ed.plan_rank_cpus(pci, allowed, sysfs)
+    assert len(plan) == 8 and all(plan)
+    seen = set()
+    for r, cpus in enumerate(plan):
+        node = r // 4
+        assert len(cpus) == 8                                                    # 4 physical cores x 2 threads
+        assert all((c % 32) // 16 == node for c in cpus), (r, cpus)              # on the GPU's own socket
+        cores = {c % 32 for c in cpus}
+        assert len(cores) == 4 and all({k, k + 32} <= set(cpus) for k in cores)  # whole cores: both hyper-threads
+        assert not (seen & set(cpus))
+        seen |= set(cpus)
+    assert seen == set(range(64))
+    # what the round-3 even slice did on this host: ranks r and r + 4 shared physical cores -- this plan never does
+    phys = [{c % 32 for c in cpus} for cpus in plan]
+    assert all(not (phys[a] & phys[b]) for a in range(8) for b in range(a + 1, 8))
+
+
+def test_rank_cpus_respect_the_allowed_mask_and_fall_back_without_numa_information(tmp_path):
+    from eco_amd import dist as ed
+    sysfs, pci = _fake_sysfs(tmp_path, sockets=2, cores_per_socket=8, smt=2, gpus_per_socket=1)
+    # a cgroup that only allows socket 0's first four cores (both threads) + all of socket 1
+    allowed = [0, 1, 2, 3, 16, 17, 18, 19] + list(range(8, 16)) + list(range(24, 32))
+    plan = ed.plan_rank_cpus(pci, allowed, sysfs)
+    assert plan[0] == [0, 1, 2, 3, 16, 17, 18, 19] and plan[1] == sorted(list(range(8, 16)) + list(range(24, 32)))
+    # no NUMA information at all (numa_node -1, empty local_cpulist; or no PCI id): an even split over PHYSICAL cores
+    sysfs2, pci2 = _fake_sysfs(tmp_path / "b", sockets=1, cores_per_socket=8, smt=2, gpus_per_socket=4, numa_known=False)
+    for ids in (pci2, [None] * 4):
+        plan = ed.plan_rank_cpus(ids, range(16), sysfs2)
+        assert plan == [[0, 1, 8, 9], [2, 3, 10, 11], [4, 5, 12, 13], [6, 7, 14, 15]]
+    # more ranks on a node than it has allowed cores: every rank still gets a non-empty set
+    plan = ed.plan_rank_cpus(pci2, [0, 8], sysfs2)
+    assert all(p == [0, 8] for p in plan)
+    assert ed.parse_cpulist("0-3,8-11,16\n") == [0, 1, 2, 3, 8, 9, 10, 11, 16] and ed.parse_cpulist("") == []
+
+
+def test_pin_rank_sets_affinity(tmp_path):
+    import os
+    from eco_amd import dist as ed
+    before = os.sched_getaffinity(0)
+    try:
+        cpus = sorted(before)
+        if len(cpus) < 2:
+            pytest.skip("needs two allowed CPUs")
+        got = ed.pin_rank(1, [None, None], sysfs=str(tmp_path))       # no topology files: CPUs are their own cores
+        assert got["cpus"] == len(os.sched_getaffinity(0)) and set(os.sched_getaffinity(0)) == set(cpus[len(cpus) // 2:])
+    finally:
+        os.sched_setaffinity(0, before)

@@ -182,8 +182,8 @@ def test_eco_lite_c5_bf16_n32():
     """BASELINE.json configs[4]: ECO-Lite num_segments=32 (r2Dto3D 32x96x28x28, global_pool 8x7x7), bf16, 32 clips
     per GPU.  The oracle stays fp32; two comparisons for clip 0: (a) against the oracle run with the same storage
     rounding (weights and every stored activation rounded to bf16 where the blocked path rounds) -- what remains
-    is accumulation order and double rounding; (b) against the plain fp32 oracle within the stated bf16 tolerance
-    (3e-2 of the largest logit; measured value printed).  Then the clip-independence / permutation properties at
+    is accumulation order and double rounding; (b) FOUR clips (0, 11, 20, 31) against the plain fp32 oracle within the
+    stated bf16 tolerance (3e-2 of the largest logit; measured values, top-1 and top-5 agreement printed).  Then the clip-independence / permutation properties at
     the full batch."""
     from eco_amd import blocked
     N, B = 32, 32
@@ -203,10 +203,20 @@ def test_eco_lite_c5_bf16_n32():
           for k, v in params.items()}
     ref_q = _fast_oracle(spec1, qp, x[:N], store_hook=lambda name, v: blocked.bf16_round(v) if name in stored else v,
                          input_hook=lambda name, v: blocked.bf16_round(v))["fc8"]
-    ref = _fast_oracle(spec1, params, x[:N])["fc8"]
-    e_q, e_f = relerr(out[:1], ref_q), relerr(out[:1], ref)
-    print(f"bf16 N=32: rel err vs rounding-aware oracle {e_q:.3e}, vs fp32 oracle {e_f:.3e}, max|logit| {np.abs(ref).max():.1f}")
-    assert e_q < BF16_TOL and e_f < BF16_TOL
+    e_q = relerr(out[:1], ref_q)
+    # (b) four clips of the batch (first, two in the middle, last) against the plain fp32 oracle, each run alone on the
+    # CPU: max rel err, top-1 and top-5 agreement per clip (round-3 verdict: one clip was thin for a 3e-2 tolerance)
+    worst, top5 = 0.0, []
+    for clip in (0, 11, 20, 31):
+        ref = _fast_oracle(spec1, params, x[clip * N:(clip + 1) * N])["fc8"]
+        e = relerr(out[clip:clip + 1], ref)
+        worst = max(worst, e)
+        assert e < BF16_TOL, (clip, e)
+        assert out[clip].argmax() == ref.argmax(), clip
+        top5.append(len(set(np.argsort(-out[clip])[:5]) & set(np.argsort(-ref[0])[:5])))
+    print(f"bf16 N=32: rel err vs rounding-aware oracle (clip 0) {e_q:.3e}; vs fp32 oracle over clips 0/11/20/31 worst "
+          f"{worst:.3e}, top-1 equal on all four, top-5 overlap {top5}; max|logit| {np.abs(ref).max():.1f}")
+    assert e_q < BF16_TOL and min(top5) >= 4
     net1 = Net(models.eco_lite_deploy(num_segments=N, num_clips=1), params=params, dtype="bf16")
     alone = net1.forward(data=x[17 * N:18 * N])["fc8"]
     # a single clip gets other split-K factors: another fp32 summation order, so a stored bf16 value may round

@@ -213,7 +213,7 @@ def test_reshape_rules_through_compiled_layer():
 @layers_built
 def test_reduced_eco_lite_layer_by_layer_through_compiled_reference_code():
     """One reduced ECO-Lite net (same graph, 32x32 frames, channels / 8) run layer by layer through COMPILED reference
-    code only -- conv (reference im2col + OpenBLAS sgemm), BN, ReLU, 2-D pooling, Concat, Eltwise, Permute,
+    code only -- conv (the compiled ConvolutionLayer class over OpenBLAS sgemm), BN, ReLU, 2-D pooling, Concat, Eltwise, Permute,
     InnerProduct, Reshape's shape rule -- against the NumPy restatement.  Two layer kinds cannot be executed by the
     reference's CPU code and are evaluated as documented: 5-D BN through the 4-D code on the folded blob with the
     cuDNN eps rule, the 3-D global AVE pool by the oracle (its 2-D golden vectors are pinned above)."""
@@ -229,8 +229,8 @@ def test_reduced_eco_lite_layer_by_layer_through_compiled_reference_code():
 
     def conv(L, bt, p):
         count("Convolution")
-        g = L.geom
-        return [eco_ref.convolution(bt[0], p[0], p[1] if g["bias_term"] else None, g["kernel"], g["stride"], g["pad"])]
+        g = L.geom                                                                  # the compiled ConvolutionLayer class
+        return [eco_ref.convolution_layer(bt[0], p[0], p[1] if g["bias_term"] else None, g["kernel"], g["stride"], g["pad"])]
 
     def bn(L, bt, p):
         count("BN")
@@ -267,3 +267,34 @@ def test_reduced_eco_lite_layer_by_layer_through_compiled_reference_code():
         assert used.get(t, 0) >= 1, t
     assert used["Convolution"] == sum(L.type == "Convolution" for L in spec.layers)
     assert used["BN"] == sum(L.type == "BN" for L in spec.layers)
+
+
+@layers_built
+def test_compiled_convolution_layer_class():
+    """base_conv_layer.cpp + conv_layer.cpp compiled unmodified (round 4): the class's LayerSetUp / Reshape / Forward_cpu
+    against (a) ref_conv_forward, the restated call sequence bench.py's image-parallel CPU baseline uses -- bit-identical,
+    same sgemm calls -- and (b) the NumPy oracle; prototxt-style repeated fields (one value for every axis, empty stride /
+    pad = schema defaults), bias_term false, force_nd_im2col on a 2-D blob, the ECO geometries incl. the stem and a
+    strided 3-D conv."""
+    if not eco_ref.has_conv_layer():
+        pytest.skip("oracle/_ref built before round 4")
+    rng = np.random.default_rng(5)
+    cases = [((2, 5, 9, 11), (3, 3), (1, 1), (1, 1), 7), ((2, 3, 20, 20), (7,), (2,), (3,), 8),
+             ((2, 6, 4, 8, 8), (3, 3, 3), (2, 2, 2), (1, 1, 1), 8), ((2, 6, 4, 8, 8), (1,), (), (), 5),
+             ((1, 4, 3, 6, 6), (3,), (1,), (1,), 4), ((3, 8, 7, 7), (1, 1), (), (), 16)]
+    for shp, k, s, p, cout in cases:
+        nsp = len(shp) - 2
+        kk = tuple(k) * nsp if len(k) == 1 else tuple(k)
+        ss = (tuple(s) * nsp if len(s) == 1 else tuple(s)) or (1,) * nsp
+        pp = (tuple(p) * nsp if len(p) == 1 else tuple(p)) or (0,) * nsp
+        x = rng.normal(size=shp).astype(np.float32)
+        w = rng.normal(size=(cout, shp[1]) + kk).astype(np.float32)
+        b = rng.normal(size=cout).astype(np.float32)
+        for bias in (b, None):
+            got = eco_ref.convolution_layer(x, w, bias, k, s, p)
+            assert np.array_equal(got, eco_ref.convolution(x, w, bias, kk, ss, pp)), (shp, k)
+            ref = orc.convolution(x, w, bias, kk, ss, pp)
+            assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+        if nsp == 2:   # force_nd_im2col: the N-D im2col on a 2-D blob gives the same col buffer
+            assert np.array_equal(eco_ref.convolution_layer(x, w, b, k, s, p, force_nd_im2col=True),
+                                  eco_ref.convolution_layer(x, w, b, k, s, p))

@@ -1,0 +1,164 @@
+"""Full-width logits against EXECUTED REFERENCE CODE (tests/golden/reference_logits.json).
+
+The fixture was produced by tests/golden/make_reference_logits.py: the reference's own deploy prototxt files, parsed with the
+reference's own caffe_pb2, run layer by layer through the reference's own object code (oracle/_ref: ConvolutionLayer,
+BNLayer, ReLULayer, PoolingLayer, ConcatLayer, EltwiseLayer, ReshapeLayer, PermuteLayer, InnerProductLayer compiled
+unmodified) on seeded weights and frames (tests/golden/ref_params.py).  Neither the product package nor the NumPy oracle
+took part in producing it.
+
+* `-m gpu`: the HIP path (fused default plan, the Winograd routes, and the layer-by-layer plan with every prototxt blob
+  materialised) against the fixture: fc8 within 1e-3 of max|logit| (north_star), top-1 equal, every materialised blob's
+  fingerprint (sums + 16 spot values) within 1e-3.  This is BASELINE.json configs[0] -- "ECO-Lite num_segments=4,
+  batch=1 ... on caffe_3d CPU forward" -- checked directly, not through the NumPy restatement.
+* CPU: the NumPy oracle against the same fixture at full width (pins the restatement AND the product's graph layer, which
+  the oracle consumes, against the reference's own graph walk), and -- where /root/reference exists -- that the committed
+  fixture is what the generator produces today.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import eco_oracle as orc
+from tests.golden import ref_params
+from tests.conftest import HAVE_REFERENCE
+
+FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_logits.json")
+TOL = 1e-3          # north_star: logits within 1e-3 relative of the caffe_3d CPU forward
+
+
+def load_fixture():
+    with open(FIXTURE) as f:
+        fx = json.load(f)
+    assert fx["recipe"] == ref_params.RECIPE
+    return fx
+
+
+def build_case(fx, key):
+    """(prototxt text, NetSpec, params by layer name, frames, fixture entry) for one fixture net, through the PRODUCT's model
+    generator; the parameter list of the fixture (names, types, shapes in the reference's LayerSetUp form) must be exactly
+    the product graph's parameter layers."""
+    from eco_amd import models
+    from eco_amd.netspec import NetSpec, param_shapes
+    c = fx["nets"][key]
+    gen = models.eco_full_deploy if "full" in key else models.eco_lite_deploy
+    proto = gen(num_segments=c["num_segments"], num_clips=c["num_clips"])
+    spec = NetSpec.from_prototxt(proto)
+    want = {L.name: (L.type, param_shapes(L)) for L in spec.layers if param_shapes(L)}
+    assert [p["name"] for p in c["params"]] == list(want), "parameter layers differ from the reference file's"
+    params = {}
+    for p in c["params"]:
+        typ, shapes = want[p["name"]]
+        assert typ == p["type"]
+        blobs = ref_params.layer_blobs(p["name"], p["type"], p["shapes"], seed=fx["seed_params"])
+        assert [int(np.prod(s)) for s in shapes] == [b.size for b in blobs], p["name"]
+        params[p["name"]] = [b.reshape(s) for b, s in zip(blobs, shapes)]
+    shp = c["input_shape"]
+    assert tuple(shp) == tuple(spec.blob_shapes["data"])
+    x = ref_params.frames(shp[0], shp[2], shp[3], seed=fx["seed_frames"])
+    return proto, spec, params, x, c
+
+
+def check_logits(got, c, tol=TOL):
+    ref = np.asarray(c["fc8"], np.float32)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max()) / scale
+    assert err < tol, err
+    assert (got.argmax(axis=1) == ref.argmax(axis=1)).all()
+    # top-5 sets agree as well (logits this far apart are not reordered by 1e-3 of the maximum ... checked, not assumed)
+    assert all(set(np.argsort(-g)[:5]) == set(np.argsort(-r)[:5]) for g, r in zip(got, ref))
+    return err
+
+
+# ---- CPU: the NumPy restatement (and the product's graph layer it consumes) against executed reference code --------------
+@pytest.mark.parametrize("key", ["eco_lite_n4_b1", "eco_full_n4_b1"])
+def test_oracle_matches_compiled_reference_at_full_width(key):
+    fx = load_fixture()
+    proto, spec, params, x, c = build_case(fx, key)
+    ref = orc.forward(spec, params, {"data": x}, keep="all")
+    err = check_logits(ref["fc8"], c, tol=1e-5)
+    seen = 0
+    for name, st in c["blobs"].items():
+        assert name in ref, name
+        ok, msg = ref_params.check_stats(ref[name], st, rtol=2e-5)
+        assert ok, (name, msg)
+        seen += 1
+    assert seen == len(c["blobs"]) >= 78, seen
+    print(f"{key}: oracle vs compiled reference, fc8 rel err {err:.2e}, {seen} blobs")
+
+
+def test_fixture_covers_every_layer_type_and_records_its_limits():
+    fx = load_fixture()
+    assert set(fx["nets"]) >= {"eco_lite_n4_b1", "eco_full_n4_b1", "eco_lite_n8_b2"}
+    assert "layers/conv_layer.cpp" in fx["compiled"] and "layers/base_conv_layer.cpp" in fx["compiled"]
+    for key, c in fx["nets"].items():
+        assert c["notes"] == {"bn5d": 11, "pool3d_global": 1}, (key, c["notes"])   # what reference CPU code cannot run
+        assert len(c["fc8"]) == c["num_clips"] and len(c["fc8"][0]) == 400
+    # two clips through reference code: the clips are independent units (same frames -> same logits is NOT assumed:
+    # the second clip has its own frames, so its logits must differ)
+    two = np.asarray(fx["nets"]["eco_lite_n8_b2"]["fc8"], np.float32)
+    assert np.abs(two[0] - two[1]).max() > 1e-3 * np.abs(two).max()
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not HAVE_REFERENCE, reason="needs /root/reference (authoring container)")
+def test_committed_fixture_is_what_the_generator_produces():
+    """Re-run the generator for configs[0] and compare with the committed JSON (OpenBLAS thread count may change the
+    summation order: 1e-5; blob fingerprints likewise)."""
+    from tests.golden import make_reference_logits as gen
+    fx = load_fixture()
+    case = [c for c in gen.CASES if c["key"] == "eco_lite_n4_b1"][0]
+    net, edits = gen.load_net(case["file"], case["num_segments"], case["num_clips"])
+    blobs, stats, plist, notes, _ = gen.forward(net, fx["seed_params"], fx["seed_frames"])
+    c = fx["nets"]["eco_lite_n4_b1"]
+    assert edits == c["edits"] and plist == c["params"] and notes == c["notes"]
+    check_logits(blobs["fc8"], c, tol=1e-5)
+    for name, st in c["blobs"].items():
+        ok, msg = ref_params.check_stats(blobs[name], st, rtol=1e-5)
+        assert ok, (name, msg)
+
+
+# ---- GPU: the HIP path against executed reference code, directly --------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", ["eco_lite_n4_b1", "eco_full_n4_b1", "eco_lite_n8_b2"])
+def test_hip_logits_match_compiled_reference(key):
+    from eco_amd.net import Net
+    fx = load_fixture()
+    proto, spec, params, x, c = build_case(fx, key)
+    worst = 0.0
+    # default plan; the layer-by-layer plan (every prototxt blob materialised); Winograd forced onto the trunk in both tile
+    # sizes (a single short clip would otherwise run those convolutions directly)
+    for fuse, wino in ((True, True), (False, True), (True, 4), (True, 2)):
+        net = Net(proto, params=params, fuse=fuse, winograd=wino)
+        out = net.forward(data=x)["fc8"].copy()
+        worst = max(worst, check_logits(out, c))
+        seen = 0
+        for name, st in c["blobs"].items():
+            if name in net.blobs and name in net._engine.tensors:
+                got = net.blobs[name].data
+                ok, msg = ref_params.check_stats(np.asarray(got).reshape(st["shape"]), st, rtol=TOL)
+                assert ok, (key, fuse, wino, name, msg)
+                seen += 1
+        if not fuse:
+            assert seen == len(c["blobs"]), (seen, len(c["blobs"]))     # every blob of the reference's walk was compared
+        else:
+            assert seen >= 20, seen
+        del net
+    print(f"{key}: HIP vs compiled reference code, worst fc8 rel err {worst:.2e}")
+
+
+@pytest.mark.gpu
+def test_hip_bf16_logits_vs_compiled_reference():
+    """The blocked bf16 path (configs[4] arithmetic) on the configs[0] fixture: stated bf16 tolerance 3e-2,
+    top-1 equal; two clips (eco_lite_n8_b2)."""
+    from eco_amd.net import Net
+    fx = load_fixture()
+    for key in ("eco_lite_n4_b1", "eco_lite_n8_b2"):
+        proto, spec, params, x, c = build_case(fx, key)
+        out = Net(proto, params=params, dtype="bf16").forward(data=x)["fc8"].copy()
+        ref = np.asarray(c["fc8"], np.float32)
+        err = float(np.abs(out - ref).max() / np.abs(ref).max())
+        assert err < 3e-2, err
+        assert (out.argmax(axis=1) == ref.argmax(axis=1)).all()

@@ -7,7 +7,8 @@ OUT=gpurun_out/${1:-prof}
 mkdir -p $OUT
 export TMPDIR=/tmp
 B="python $PWD/bench.py --no-cpu-baseline --no-extra-configs"
-sha256sum eco-efficient-video-understanding_amd/libeco_hip.so | cut -d' ' -f1 > $OUT/lib.sha256   # bench.py reports PMC traffic only for this build
+# bench.py reports PMC traffic only while the running library was built from THESE sources (eco_source_digest())
+python -c "import sys; sys.path.insert(0, '.'); from eco_amd import hip; print(hip.EcoLib(hip.LIB_PATH).source_digest())" > $OUT/src.sha256
 rocprofv3 --kernel-trace --stats -d $PWD/$OUT/trace -o bench --output-format csv -- $B --steps 10 --warmup 3 > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $PWD/$OUT/pmc_fetch -o bench --output-format csv -- $B --steps 2 --warmup 1 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $PWD/$OUT/pmc_write -o bench --output-format csv -- $B --steps 2 --warmup 1 > $OUT/pmc_write.log 2>&1
@@ -22,6 +23,12 @@ rocprofv3 --pmc FETCH_SIZE -d $PWD/$OUT/pmc_fetch_bf16 -o bench --output-format 
 rocprofv3 --pmc WRITE_SIZE -d $PWD/$OUT/pmc_write_bf16 -o bench --output-format csv -- $BB > $OUT/pmc_write_bf16.log 2>&1
 python bench.py --segments 32 --dtype bf16 > $OUT/bench_line_bf16.json 2> $OUT/bench_line_bf16.err
 python bench.py --variant full > $OUT/bench_line_full.json 2> $OUT/bench_line_full.err
+# configs[3] (ECO-Full): kernel trace + the same three counter passes
+BF="$B --variant full"
+rocprofv3 --kernel-trace --stats -d $PWD/$OUT/trace_full -o bench --output-format csv -- $BF --steps 10 --warmup 3 > $OUT/trace_full.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA -d $PWD/$OUT/pmc_sq_full -o bench --output-format csv -- $BF --steps 2 --warmup 1 > $OUT/pmc_sq_full.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $PWD/$OUT/pmc_fetch_full -o bench --output-format csv -- $BF --steps 2 --warmup 1 > $OUT/pmc_fetch_full.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $PWD/$OUT/pmc_write_full -o bench --output-format csv -- $BF --steps 2 --warmup 1 > $OUT/pmc_write_full.log 2>&1
 # online recognition: one clip per step, the launch list replayed as a hipGraph and submitted call by call
 python bench.py --clips-per-gpu 1 --graph --no-cpu-baseline --steps 200 --warmup 20 > $OUT/bench_line_b1_graph.json 2> $OUT/bench_line_b1_graph.err
 python bench.py --clips-per-gpu 1 --no-cpu-baseline --steps 200 --warmup 20 > $OUT/bench_line_b1.json 2> $OUT/bench_line_b1.err

@@ -34,15 +34,16 @@ def main():
             f.write("%s,%s,%.3f,%.1f,%.1f,%.1f,%s\n" % (short(r["Name"]).replace(",", ";"), r["Calls"],
                     float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3,
                     float(r["MaxNs"]) / 1e3, r["Percentage"]))
-    bf = os.path.join(src, "trace_bf16", "bench_kernel_stats.csv")
-    if os.path.exists(bf):
-        with open(os.path.join(out_dir, f"{tag}_bf16_kernel_stats.csv"), "w") as f:
-            f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --segments 32 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline\n")
-            f.write("kernel,calls,total_ms,avg_us,min_us,max_us,percent\n")
-            for r in csv.DictReader(open(bf)):
-                f.write("%s,%s,%.3f,%.1f,%.1f,%.1f,%s\n" % (short(r["Name"]).replace(",", ";"), r["Calls"],
-                        float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3,
-                        float(r["MaxNs"]) / 1e3, r["Percentage"]))
+    for sub, cmd in (("bf16", "--segments 32 --dtype bf16"), ("full", "--variant full")):
+        bf = os.path.join(src, f"trace_{sub}", "bench_kernel_stats.csv")
+        if os.path.exists(bf):
+            with open(os.path.join(out_dir, f"{tag}_{sub}_kernel_stats.csv"), "w") as f:
+                f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py {cmd} --steps 10 --warmup 3 --no-cpu-baseline\n")
+                f.write("kernel,calls,total_ms,avg_us,min_us,max_us,percent\n")
+                for r in csv.DictReader(open(bf)):
+                    f.write("%s,%s,%.3f,%.1f,%.1f,%.1f,%s\n" % (short(r["Name"]).replace(",", ";"), r["Calls"],
+                            float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3,
+                            float(r["MaxNs"]) / 1e3, r["Percentage"]))
     for nm in ("bench_line.json", "bench_line_bf16.json", "bench_line_full.json", "bench_line_b1.json",
                "bench_line_b1_graph.json", "eco_time.txt", "eco_time_bf16.txt", "eco_time_full.txt"):
         p = os.path.join(src, nm)
@@ -50,11 +51,13 @@ def main():
             with open(p) as fi, open(os.path.join(out_dir, f"{tag}_{nm}"), "w") as fo:
                 fo.write("".join(l for l in fi if "amdgpu.ids" not in l))
     summary = summarize_traffic(src, "", os.path.join(out_dir, f"{tag}_pmc_hbm_traffic.csv"), "python bench.py")
-    sha = os.path.join(src, "lib.sha256")
+    sha = os.path.join(src, "src.sha256")
     with open(os.path.join(out_dir, "hbm_traffic_latest.json"), "w") as f:
         json.dump({"source": f"profiles/{tag}_pmc_hbm_traffic.csv",
-                   # the build the counters belong to: bench.py reports `roofline.traffic` only while it still runs it
-                   "lib_sha256": open(sha).read().strip() if os.path.exists(sha) else None,
+                   # what the profiled build was made FROM (eco_source_digest() of the library that ran): bench.py reports
+                   # `roofline.traffic` while the running library reports the same digest -- a rebuild of identical
+                   # sources keeps the field, an edited kernel drops it
+                   "src_sha256": open(sha).read().strip().splitlines()[-1] if os.path.exists(sha) else None,
                    "kernels": summary}, f, indent=1)
     sq = os.path.join(src, "pmc_sq", "bench_counter_collection.csv")
     if os.path.exists(sq):
@@ -66,6 +69,12 @@ def main():
     sqb = os.path.join(src, "pmc_sq_bf16", "bench_counter_collection.csv")
     if os.path.exists(sqb):
         summarize_sq(sqb, os.path.join(out_dir, f"{tag}_bf16_pmc_sq.csv"), "python bench.py --segments 32 --dtype bf16")
+    # configs[3] (ECO-Full)
+    if os.path.exists(os.path.join(src, "pmc_fetch_full")):
+        summarize_traffic(src, "_full", os.path.join(out_dir, f"{tag}_full_pmc_hbm_traffic.csv"), "python bench.py --variant full")
+    sqf = os.path.join(src, "pmc_sq_full", "bench_counter_collection.csv")
+    if os.path.exists(sqf):
+        summarize_sq(sqf, os.path.join(out_dir, f"{tag}_full_pmc_sq.csv"), "python bench.py --variant full")
     print("wrote", os.listdir(out_dir))
 
 
@@ -89,7 +98,8 @@ def summarize_traffic(src, suffix, out_path, cmd):
         for k, v in sorted(traffic.items(), key=lambda kv: -kv[1].get("fetch_kib", 0)):
             fk, wk = v.get("fetch_kib", 0.0), v.get("write_kib", 0.0)
             hbm = 2 * fk * 1024 + wk * 1024
-            summary[k] = {"fetch_kib": fk, "write_kib": wk, "hbm_bytes_per_launch": hbm}
+            summary[k] = {"fetch_kib": fk, "write_kib": wk, "hbm_bytes_per_launch": hbm,
+                          "launches": int(v.get("fetch_kib_launches", v.get("write_kib_launches", 1)))}
             f.write("%s,%.1f,%.1f,%.2f\n" % (k.replace(",", ";"), fk, wk, hbm / 1e6))
     return summary
 
