@@ -176,21 +176,17 @@ __device__ __forceinline__ void convb_stage_params(const ConvBArgs& a, int m0, f
 }
 
 // (Ep: convb_stage_params' array for the rows starting at m0; EPS = its row pitch)
+// (e_img / e_sp / e_ok: image, spatial index and validity of this lane's TN fragment positions)
 template <int TM, int TN, int NS>
-__device__ __forceinline__ void convb_epilogue(const ConvBArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw, int half,
-                                               int l31, const float* Ep, int EPS, int m0) {
+__device__ __forceinline__ void convb_epilogue_at(const ConvBArgs& a, f32x16 (&acc)[TM][TN], int mw, int half,
+                                                  const float* Ep, int EPS, int m0, const int (&e_img)[TN],
+                                                  const int (&e_sp)[TN], const bool (&e_ok)[TN]) {
   long e_res[TN], e_raw[TN], e_act[TN], e_act2[TN];
-  int e_img[TN], e_sp[TN];
-  bool e_ok[TN];
   const bool has_res = a.residual.ptr != nullptr;
   const bool has_raw = a.raw.ptr != nullptr, has_act = a.act.ptr != nullptr, has_act2 = has_act && a.act2.ptr != nullptr;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int n = nw + j * 32 + l31;
-    e_ok[j] = n < a.ntot;
-    int img, sp;
-    decode_out(a, e_ok[j] ? n : 0, img, sp);
-    e_img[j] = img; e_sp[j] = sp;
+    const int img = e_img[j], sp = e_sp[j];
     e_res[j] = has_res ? view_base(a.residual, img, sp) : 0;
     e_raw[j] = has_raw ? view_base(a.raw, img, sp) : 0;
     e_act[j] = has_act ? view_base(a.act, img, sp) : 0;
@@ -260,6 +256,137 @@ __device__ __forceinline__ void convb_epilogue(const ConvBArgs& a, f32x16 (&acc)
       }
     }
   }
+}
+
+template <int TM, int TN, int NS>
+__device__ __forceinline__ void convb_epilogue(const ConvBArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw, int half,
+                                               int l31, const float* Ep, int EPS, int m0) {
+  int e_img[TN], e_sp[TN];
+  bool e_ok[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = nw + j * 32 + l31;
+    e_ok[j] = n < a.ntot;
+    decode_out(a, e_ok[j] ? n : 0, e_img[j], e_sp[j]);
+  }
+  convb_epilogue_at<TM, TN, NS>(a, acc, mw, half, Ep, EPS, m0, e_img, e_sp, e_ok);
+}
+
+// Epilogue of the persistent kernel: the same algebra as convb_epilogue_at, re-laid so that (1) every store is a whole
+// 16-byte channel block -- the two half-blocks a 32x32 MFMA tile leaves in lanes l and l + 32 are brought together with
+// v_permlane32_swap, after which lane l of the wave owns position nw + l: sixteen 1 KB store instructions per destination
+// and tile instead of thirty-two 512-byte ones -- and (2) the stores go through buffer descriptors with the range check as
+// their predicate (gst16_buf), so their NUMBER is a compile-time function of which destinations exist: the kernel's counted
+// waits can step over them (profiles/r04_notes.md: waiting for a tile's stores to be acknowledged before the next tile's
+// first tap cost conv2_3x3 a third of its time).  Residual blocks are fetched for the whole tile before the first store.
+// Returns the number of store instructions issued per wave.  (bf16 storage only.)
+__device__ __forceinline__ unsigned view_lane_offset(const eco_view& v, int img, int sp, bool ok) {
+  return ok ? (unsigned)(view_base(v, img, sp) * 16) : kBufOob;
+}
+template <int TM>
+__device__ __forceinline__ int convb_epilogue_wide(const ConvBArgs& a, f32x16 (&acc)[TM][2], int m0, int n_lane, int half,
+                                                   const float* Ep, int EPS, const FastDiv& d_sout) {
+  const bool has_res = a.residual.ptr != nullptr;
+  const bool has_raw = a.raw.ptr != nullptr, has_act = a.act.ptr != nullptr, has_act2 = has_act && a.act2.ptr != nullptr;
+  const bool ok = n_lane < a.ntot;
+  const unsigned nn = ok ? (unsigned)n_lane : 0u;
+  const int img = (int)fastdiv(nn, d_sout), sp = (int)(nn - (unsigned)img * (unsigned)a.s_out);
+  constexpr unsigned kAll = 0x7fffffffu;   // (range check = the lane predicate only: valid offsets are below 2 GB by plan)
+  const unsigned v_raw = has_raw ? view_lane_offset(a.raw, img, sp, ok) : kBufOob;
+  const unsigned v_act2 = has_act2 ? view_lane_offset(a.act2, img, sp, ok) : kBufOob;
+  const BufRsrc r_raw = make_buf_rsrc(a.raw.ptr, kAll), r_act2 = make_buf_rsrc(a.act2.ptr, kAll);
+  // residual blocks of this lane's position: all of the tile's, ahead of the first store (a load behind a store waits for
+  // the store's acknowledgement: the memory counter retires in order)
+  uint4 res[TM][4];
+  if (has_res) {
+    const long rb = view_base(a.residual, img, sp);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cbk = (m0 + i * 32) / 8 + g;
+        res[i][g] = (ok && cbk * 8 < a.cout) ? ld((const uint4*)a.residual.ptr + rb + (long)cbk * a.residual.stride_c)
+                                             : make_uint4(0u, 0u, 0u, 0u);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    // the destination of this 32-row tile (wave-uniform): `act`, or a sibling's own tensor (values selected, never a
+    // run-time index into the kernel argument struct: that would copy it to scratch memory)
+    const int mt = m0 + i * 32;
+    void* aptr = a.act.ptr;
+    long astride_c = a.act.stride_c, astride_b = a.act.stride_b;
+    int relu = a.relu, cb0 = 0;
+    bool seg = false;
+    if (a.nseg > 0 && mt >= a.seg_begin[0]) {
+      seg = true;
+      aptr = a.seg_act[0].ptr; astride_c = a.seg_act[0].stride_c; astride_b = a.seg_act[0].stride_b;
+      relu = a.seg_relu[0]; cb0 = a.seg_begin[0] / 8;
+#pragma unroll
+      for (int q = 1; q < ECO_MAX_SEG; ++q) {
+        void* const qp = a.seg_act[q].ptr;
+        const long qc = a.seg_act[q].stride_c, qb = a.seg_act[q].stride_b;
+        const int qr = a.seg_relu[q], qbeg = a.seg_begin[q];
+        const bool take = q < a.nseg && mt >= qbeg;
+        aptr = take ? qp : aptr; astride_c = take ? qc : astride_c; astride_b = take ? qb : astride_b;
+        relu = take ? qr : relu; cb0 = take ? qbeg / 8 : cb0;
+      }
+    }
+    const BufRsrc r_act = make_buf_rsrc(aptr, kAll);
+    const unsigned v_act = !has_act ? kBufOob : !ok ? kBufOob
+                           : seg ? (unsigned)(((long)img * astride_b + sp) * 16) : (unsigned)(view_base(a.act, img, sp) * 16);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ch0 = mt + 8 * g + 4 * half;
+      const int cbk = mt / 8 + g;
+      const bool rows = cbk * 8 < a.cout;     // (cout is a multiple of 8: a block is inside or outside as a whole; uniform)
+      const float4 b4 = *(const float4*)(Ep + (ch0 - m0)), s4 = *(const float4*)(Ep + EPS + (ch0 - m0)),
+                   h4 = *(const float4*)(Ep + 2 * EPS + (ch0 - m0));
+      const float pb[4] = {b4.x, b4.y, b4.z, b4.w}, ps[4] = {s4.x, s4.y, s4.z, s4.w}, ph[4] = {h4.x, h4.y, h4.z, h4.w};
+      // the residual block holds this lane's POSITION (all 8 channels): hand the halves the partner lane needs across, so
+      // that rq[j] = channels 4*half .. 4*half+3 of fragment position j
+      unsigned rq[2][2] = {{0u, 0u}, {0u, 0u}};
+      if (has_res) {
+        unsigned r01x = res[i][g].x, r01y = res[i][g].y, r23x = res[i][g].z, r23y = res[i][g].w;
+        permlane32_swap(r01x, r23x);
+        permlane32_swap(r01y, r23y);
+        rq[0][0] = r01x; rq[0][1] = r01y; rq[1][0] = r23x; rq[1][1] = r23y;
+      }
+      unsigned praw[2][2], pact[2][2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float v[4], y[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q] + pb[q];
+        if (has_res) {
+          v[0] += bf16_bits_to_f32(rq[j][0] & 0xffffu); v[1] += bf16_bits_to_f32(rq[j][0] >> 16);
+          v[2] += bf16_bits_to_f32(rq[j][1] & 0xffffu); v[3] += bf16_bits_to_f32(rq[j][1] >> 16);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          y[q] = v[q] * ps[q] + ph[q];
+          if (relu) y[q] = fmaxf(y[q], 0.0f);
+        }
+        praw[j][0] = pack_bf16x2(v[0], v[1]); praw[j][1] = pack_bf16x2(v[2], v[3]);
+        pact[j][0] = pack_bf16x2(y[0], y[1]); pact[j][1] = pack_bf16x2(y[2], y[3]);
+      }
+      // lanes 0..31: [own channels 0-3 | partner's 4-7] of position j = 0; lanes 32..63: [partner's 0-3 | own 4-7] of j = 1
+      if (has_raw) {
+        permlane32_swap(praw[0][0], praw[1][0]);
+        permlane32_swap(praw[0][1], praw[1][1]);
+        gst16_buf(r_raw, rows ? v_raw : kBufOob, (unsigned)((long)cbk * a.raw.stride_c * 16),
+                  make_uint4(praw[0][0], praw[0][1], praw[1][0], praw[1][1]));
+      }
+      if (has_act) {
+        permlane32_swap(pact[0][0], pact[1][0]);
+        permlane32_swap(pact[0][1], pact[1][1]);
+        const uint4 q = make_uint4(pact[0][0], pact[0][1], pact[1][0], pact[1][1]);
+        gst16_buf(r_act, rows ? v_act : kBufOob, (unsigned)((long)(cbk - cb0) * astride_c * 16), q);
+        if (has_act2) gst16_buf(r_act2, rows ? v_act2 : kBufOob, (unsigned)((long)cbk * a.act2.stride_c * 16), q);
+      }
+    }
+  }
+  return TM * 4 * ((has_raw ? 1 : 0) + (has_act ? 1 : 0) + (has_act2 ? 1 : 0));
 }
 
 // Split-K partial sums: ws[slice][channel][position] fp32 (positions contiguous per lane group).
@@ -849,10 +976,18 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
         // eight MFMAs of k-step ks.
         uint4 af[2][TM], bf[2][TN];
         auto read_frags = [&](int slot, int ks) {
+#if defined(ECO_SPAN_PROBE) && (ECO_SPAN_PROBE & 8)     // bit 3 = no fragment reads (operands = whatever the registers hold)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) { af[slot][i] = make_uint4(0x3f803f80u, 0u, 0u, 0u); ECO_OPAQUE(af[slot][i].y); }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) { bf[slot][j] = make_uint4(0x3f803f80u, 0u, 0u, 0u); ECO_OPAQUE(bf[slot][j].y); }
+          (void)Ab; (void)Bb; (void)ks;
+#else
 #pragma unroll
           for (int i = 0; i < TM; ++i) af[slot][i] = Ab[(2 * ks + half) * BMP + (wm * TM + i) * 32 + l31];
 #pragma unroll
           for (int j = 0; j < TN; ++j) bf[slot][j] = Bb[(2 * ks + half) * SPAN + (wn * TN + j) * 32 + l31];
+#endif
         };
         read_frags(0, 0);
 #pragma unroll
@@ -866,10 +1001,17 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
             q = make_uint4(q.x & okm[j], q.y & okm[j], q.z & okm[j], q.w & okm[j]);
 #endif
           }
+#if defined(ECO_SPAN_PROBE) && (ECO_SPAN_PROBE & 32)    // bit 5 = no MFMAs (the skeleton alone: DMA, waits, barriers, reads, masks)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[ks & 1][i].x), "v"(af[ks & 1][i].y), "v"(af[ks & 1][i].z), "v"(af[ks & 1][i].w));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bf[ks & 1][j].x), "v"(bf[ks & 1][j].y), "v"(bf[ks & 1][j].z), "v"(bf[ks & 1][j].w));
+#else
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16_bf16(af[ks & 1][i], bf[ks & 1][j], acc[i][j]);
+#endif
           sched_fence();
         }
         abuf = abuf == kSpanNbuf - 1 ? 0 : abuf + 1;
@@ -877,10 +1019,325 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
     }
   }
   if (total <= 0) __syncthreads();   // (no stage ran: Ep has not been published by a barrier yet)
+#if defined(ECO_SPAN_PROBE) && (ECO_SPAN_PROBE & 16)      // bit 4 = no epilogue (accumulators kept live, nothing stored)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+  if (a.ntot < 0)
+#endif
   if (a.ksplit > 1)
     convb_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
   else
     convb_epilogue<TM, TN, 1>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31, Ep, BMP_E, m0);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent span kernel (round 4): the same arithmetic as convb_span_kernel, restructured around what the probe builds
+// of round 4 measured (profiles/r04_notes.md): with the MFMAs REMOVED the span kernel still took 0.87 of conv2_3x3's
+// 1.07 ms and 0.50 of res3b_1's 0.73 ms -- per tap ~400 cycles of address arithmetic, wait selection and loop control in
+// every wave next to 512 cycles of MFMA issue, and per tile ~12 k cycles of exposed set-up (integer divisions, epilogue
+// parameters, the first span's trip to HBM) that an 18-tap tile (conv2_3x3, the inception 3x3s) pays every 9 k cycles of
+// matrix work.  Here
+//   * one workgroup per slot (2 per CU) walks its tiles: the next tile's span and first two weight taps are issued while
+//     the current tile's last group runs, its index arithmetic (fastdiv, no software divides) sits under that DMA, the
+//     epilogue parameters are staged once per workgroup;
+//   * both operands go through buffer descriptors (glds16_buf): a piece's address is SGPR base + SGPR offset + a lane
+//     register that stays put for the whole tile (the flat form needed a 64-bit VALU add and a zero-page select per
+//     piece), and out-of-volume planes / tile overhang are the descriptor's range check writing zeros;
+//   * the three taps of a kernel row are unrolled with compile-time ring slots and LDS immediates (a row starts at ring
+//     slot 0 because 3 % 3 == 0; the span pitch in LDS is a constant 384 positions); wait counts follow what the previous
+//     issue slot actually issued.
+// Tiles: 32*TM channels x 256 positions, four waves side by side in N, as before.  Items = (slice, tile); with split-K an
+// item ends in partial sums instead of the epilogue.
+#ifndef ECO_SPANP_PROBE
+#define ECO_SPANP_PROBE 0
+#endif
+struct SpanPArgs {
+  unsigned x_bytes, wp_bytes;
+  int ntiles;                      // nblk_m * nblk_n
+  FastDiv d_sout, d_hw, d_w, d_ks, d_kd;
+};
+
+template <int TM>
+__global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, const SpanPArgs pa, int span_pieces) {
+  constexpr int TN = 2;
+  constexpr int BM = 32 * TM, BN = 256;
+  constexpr int BMP = (BM + 63) / 64 * 64;
+  constexpr int APW = kCbs * BMP / 64 / 4;   // weight pieces per wave and tap: 1 or 2
+  constexpr int SPITCH = 384;                // positions per span row in LDS (span_pieces <= 6)
+  constexpr int NB = 3;                      // weight ring slots
+  constexpr int T2 = 9;
+  static_assert(T2 % NB == 0, "a group must start at ring slot 0");
+
+  __shared__ __attribute__((aligned(16))) float Ep[3 * BMP];   // bias / BN scale / BN shift of this workgroup's rows
+  ECO_DYNAMIC_LDS(lds_f);
+  uint4* const Aw = (uint4*)lds_f;                 // [NB][kCbs][BMP]
+  uint4* const Bsp = Aw + NB * kCbs * BMP;         // [2][kCbs][SPITCH]
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+
+  // ---- this workgroup's items: logical id L keeps the M-blocks of one position tile on one XCD (hardware places
+  //      block b on XCD b % 8); item k of the workgroup = position tile nblk0 + k * nstep of M-block mblk ----
+  const int grid = (int)gridDim.x;
+  const int L = ((int)blockIdx.x % 8) * (grid / 8) + (int)blockIdx.x / 8;   // grid is a multiple of 8 * nblk_m
+  const int mblk = L % a.nblk_m;                   // (grid and ntiles are multiples of nblk_m: every item of L has this M-block)
+  const int m0 = mblk * BM;
+  int tile = L, slice = 0;                         // item k = L + k * grid -> (slice, tile) = divmod(item, ntiles)
+  while (tile >= pa.ntiles) { tile -= pa.ntiles; ++slice; }
+  if (slice >= a.ksplit) return;                   // (fewer items than workgroups: uniform exit, before any barrier)
+  convb_stage_params<BMP>(a, m0, Ep);
+#ifndef ECO_EMU
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Ep's ds_writes retired before the first (non-draining) barrier
+#endif
+
+  const BufRsrc rx = make_buf_rsrc(a.x, pa.x_bytes), rw = make_buf_rsrc(a.wp, pa.wp_bytes);
+  const int hw = a.Hi * a.Wi, halo = a.Wi + 1;
+  const int ngroups = (a.nstages / a.taps) * a.kd;
+  const unsigned cbs16 = (unsigned)a.cb_stride_in * 16u;
+  const unsigned wstage16 = (unsigned)(kCbs * a.mpad) * 16u;      // bytes of one tap stage of packed weights
+  const int nchunks = wave + 4 < span_pieces ? 2 : 1;             // span pieces `wave` and `wave + 4`
+  const int SPW = kCbs * nchunks;                                  // span DMA pieces of this wave per group
+
+  // weight pieces of this wave: piece = wave + 4q -> (row, 64-channel chunk); lane offset fixed for the workgroup
+  unsigned wv[APW];
+  int wl[APW];                                                     // LDS index inside a ring slot
+#pragma unroll
+  for (int q = 0; q < APW; ++q) {
+    const int piece = wave + 4 * q, row = piece / (BMP / 64), mc = piece % (BMP / 64);
+    wv[q] = (unsigned)(row * a.mpad + m0 + mc * 64 + lane) * 16u;
+    wl[q] = row * BMP + mc * 64;
+  }
+  const int a_lane = half * BMP + l31;
+  const int b_lane = half * SPITCH + wave * 64 + l31;
+
+  // ---- per-item lane state ----
+  struct Item {
+    int n0, slice, g_begin, g_end;
+    unsigned spv[2];     // byte offset of span element (chunk c, this lane) at depth shift 0
+    int spd[2];          // its depth index (hugely negative: never valid)
+    unsigned fmask[TN];  // in-plane tap masks of the lane's fragment positions: bit y*3 + x
+  };
+  auto make_item = [&](int nb, int sl) {
+    Item it;
+    it.n0 = nb * BN;
+    it.slice = sl;
+    it.g_begin = a.ksplit == 1 ? 0 : (int)fastdiv((unsigned)(sl * ngroups), pa.d_ks);
+    it.g_end = a.ksplit == 1 ? ngroups : (int)fastdiv((unsigned)((sl + 1) * ngroups), pa.d_ks);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int v = it.n0 - halo + (wave + 4 * c) * 64 + lane;
+      it.spv[c] = 0u;
+      it.spd[c] = -(1 << 20);
+      if (v >= 0 && v < a.ntot) {
+        const unsigned img = fastdiv((unsigned)v, pa.d_sout), sp = (unsigned)v - img * (unsigned)a.s_out;
+        it.spv[c] = (unsigned)((long)img * a.img_stride_in + sp) * 16u;
+        it.spd[c] = (int)fastdiv(sp, pa.d_hw);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = it.n0 + wave * 64 + j * 32 + l31;
+      const bool inside = n < a.ntot;
+      const unsigned nn = inside ? (unsigned)n : 0u;
+      const unsigned img = fastdiv(nn, pa.d_sout), sp = nn - img * (unsigned)a.s_out;
+      const unsigned r = sp - fastdiv(sp, pa.d_hw) * (unsigned)hw;
+      const int h = (int)fastdiv(r, pa.d_w), w = (int)r - h * a.Wi;
+      unsigned mw_ = 0u, fm = 0u;
+#pragma unroll
+      for (int xx = 0; xx < 3; ++xx) mw_ |= (unsigned)((unsigned)(w - 1 + xx) < (unsigned)a.Wi) << xx;
+#pragma unroll
+      for (int y = 0; y < 3; ++y)
+        if ((unsigned)(h - 1 + y) < (unsigned)a.Hi) fm |= mw_ << (3 * y);
+      it.fmask[j] = inside ? fm : 0u;
+    }
+    return it;
+  };
+
+  // ---- DMA issue ----
+  auto issue_span = [&](unsigned sv0, unsigned sv1, int sd0, int sd1, int cg, int z, int sbuf) {
+    const int dz = z - a.pd;
+    const unsigned zshift = (unsigned)(dz * hw * 16);          // (two's complement: added to spv only where the plane exists)
+    const unsigned sv[2] = {sv0, sv1};
+    const int sd[2] = {sd0, sd1};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c < nchunks) {
+        const unsigned vo = (unsigned)(sd[c] + dz) < (unsigned)a.Di ? sv[c] + zshift : kBufOob;
+#pragma unroll
+        for (int kb = 0; kb < kCbs; ++kb) {
+          const int cb = min(cg * kCbs + kb, a.cblocks - 1);   // zero-weight padding group: any finite data
+          glds16_buf(rx, vo, (unsigned)cb * cbs16, Bsp + (sbuf * kCbs + kb) * SPITCH + (wave + 4 * c) * 64);
+        }
+      }
+    }
+  };
+  auto issue_weights = [&](int stage, int abuf) {
+    const unsigned so = (unsigned)stage * wstage16;
+#pragma unroll
+    for (int q = 0; q < APW; ++q) glds16_buf(rw, wv[q], so, Aw + abuf * kCbs * BMP + wl[q]);
+  };
+  // all but the newest `n` memory operations of this wave have completed (n: one of the four counts an issue slot can
+  // have; the counter retires in order, LDS-DMA pieces and stores alike)
+  auto wait_newest = [&](int n) {
+    if (n == 0) wait_dma_all_but<0>();
+    else if (n == APW) wait_dma_all_but<APW>();
+    else if (n == APW + kCbs) wait_dma_all_but<APW + kCbs>();
+    else wait_dma_all_but<APW + 2 * kCbs>();
+  };
+  // the same at the first tap behind an epilogue, whose `st` store instructions (a multiple of S = 4*TM, counted by
+  // convb_epilogue_wide) are newer than every piece that tap needs: any immediate <= n + st is a correct wait
+  constexpr int S = 4 * TM;
+  auto wait_newest_behind_stores = [&](int n, int st) {
+    const int m = (n >= APW ? APW : 0) + st;
+    if (m >= APW + 3 * S) wait_dma_all_but<APW + 3 * S>();
+    else if (m >= APW + 2 * S) wait_dma_all_but<APW + 2 * S>();
+    else if (m >= APW + S) wait_dma_all_but<APW + S>();
+    else if (m >= APW) wait_dma_all_but<APW>();
+    else wait_dma_all_but<0>();
+  };
+
+  f32x16 acc[TM][TN];
+  Item cur = make_item(tile / a.nblk_m, slice);
+  int cg = (int)fastdiv((unsigned)cur.g_begin, pa.d_kd), z = cur.g_begin - cg * a.kd;
+  issue_span(cur.spv[0], cur.spv[1], cur.spd[0], cur.spd[1], cg, z, 0);
+  issue_weights(cg * a.taps + z * T2, 0);
+  issue_weights(cg * a.taps + z * T2 + 1, 1);
+  int newest = APW;          // pieces issued after the ones the next tap needs
+  int stores = 0;            // store instructions of the previous item's epilogue, still in front of the next wait
+  int sbuf = 0;
+
+  for (;;) {
+    // the item after this one (uniform)
+    int ntile = tile + grid, nslice = slice;
+    while (ntile >= pa.ntiles) { ntile -= pa.ntiles; ++nslice; }
+    const bool have_next_item = nslice < a.ksplit;
+    Item nxt = cur;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    for (int g = cur.g_begin; g < cur.g_end; ++g) {
+      // ---- the group after this one: (channel group, depth tap) and whose lane state stages its span ----
+      const bool last_group = g + 1 == cur.g_end;
+      bool have_next = true;
+      int ncg = cg, nz = z + 1;
+      if (nz == a.kd) { nz = 0; ++ncg; }
+      if (last_group) {
+        have_next = have_next_item;
+        if (have_next_item) {
+#if !(ECO_SPANP_PROBE & 64)      // bit 6 = no per-item index arithmetic (the first item's lane state is reused: wrong results)
+          nxt = make_item(ntile / a.nblk_m, nslice);   // VALU under the DMA / the other workgroup's MFMAs
+#endif
+          ncg = (int)fastdiv((unsigned)nxt.g_begin, pa.d_kd);
+          nz = nxt.g_begin - ncg * a.kd;
+        }
+      }
+      const unsigned nsv0 = last_group ? nxt.spv[0] : cur.spv[0], nsv1 = last_group ? nxt.spv[1] : cur.spv[1];
+      const int nsd0 = last_group ? nxt.spd[0] : cur.spd[0], nsd1 = last_group ? nxt.spd[1] : cur.spd[1];
+      const int stage0 = cg * a.taps + z * T2, nstage0 = ncg * a.taps + nz * T2;
+      // three kernel rows, the three taps of a row unrolled (ring slot = column because 3 % NB == 0): compile-time LDS
+      // immediates without nine copies of the body competing for registers
+#pragma unroll 1
+      for (int y = 0; y < 3; ++y) {
+        const uint4* brow = Bsp + sbuf * kCbs * SPITCH + y * a.Wi + b_lane;
+        unsigned rmask[TN];   // this row's three mask bits of each fragment position
+#pragma unroll
+        for (int j = 0; j < TN; ++j) rmask[j] = cur.fmask[j] >> (3 * y);
+        static_for<3>([&](auto xc) {
+          constexpr int xx = decltype(xc)::value;
+          constexpr int abuf = xx;                     // t2 % NB with t2 = 3y + xx
+          const int t2 = 3 * y + xx;
+          if (stores) { wait_newest_behind_stores(newest, stores); stores = 0; }
+          else wait_newest(newest);
+#if !(ECO_SPANP_PROBE & 1)      // probe builds (tools/exp): bit 0 = no barrier per tap
+          wg_barrier_nodrain();
+#endif
+          int cnt = 0;
+#if ECO_SPANP_PROBE & 2         // bit 1 = no operand DMA after the prologue
+          if (a.ntot < 0) {
+#endif
+          if (xx == 0 && y == 0 && have_next) { issue_span(nsv0, nsv1, nsd0, nsd1, ncg, nz, sbuf ^ 1); cnt += SPW; }
+          if (t2 + 2 < T2) { issue_weights(stage0 + t2 + 2, (xx + 2) % NB); cnt += APW; }
+          else if (have_next) { issue_weights(nstage0 + t2 + 2 - T2, (xx + 2) % NB); cnt += APW; }
+#if ECO_SPANP_PROBE & 2
+          }
+#endif
+          newest = cnt;
+          sched_fence();
+          const uint4* Ab = Aw + abuf * kCbs * BMP + a_lane;
+          const uint4* Bb = brow + xx;
+          uint4 af[2][TM], bf[2][TN];
+          auto read_frags = [&](int slot, int ks) {
+#if ECO_SPANP_PROBE & 8         // bit 3 = no fragment reads
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { af[slot][i] = make_uint4(0x3f803f80u, 0u, 0u, 0u); ECO_OPAQUE(af[slot][i].y); }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { bf[slot][j] = make_uint4(0x3f803f80u, 0u, 0u, 0u); ECO_OPAQUE(bf[slot][j].y); }
+            (void)Ab; (void)Bb; (void)ks;
+#else
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[slot][i] = Ab[2 * ks * BMP + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[slot][j] = Bb[2 * ks * SPITCH + j * 32];
+#endif
+          };
+          read_frags(0, 0);
+#pragma unroll
+          for (int ks = 0; ks < kCbs / 2; ++ks) {
+            if (ks + 1 < kCbs / 2) read_frags((ks + 1) & 1, ks + 1);
+            sched_fence();
+#if !(ECO_SPANP_PROBE & 4)      // bit 2 = no tap masks
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {   // all-ones where this tap is inside the plane (an AND per dword: no exec-masked reads)
+              const unsigned okm = (unsigned)((int)(rmask[j] << (31 - xx)) >> 31);
+              uint4& q = bf[ks & 1][j];
+              q = make_uint4(q.x & okm, q.y & okm, q.z & okm, q.w & okm);
+            }
+#endif
+#if ECO_SPANP_PROBE & 32        // bit 5 = no MFMAs (the skeleton alone)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[ks & 1][i].x), "v"(af[ks & 1][i].y), "v"(af[ks & 1][i].z), "v"(af[ks & 1][i].w));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bf[ks & 1][j].x), "v"(bf[ks & 1][j].y), "v"(bf[ks & 1][j].z), "v"(bf[ks & 1][j].w));
+#else
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16_bf16(af[ks & 1][i], bf[ks & 1][j], acc[i][j]);
+#endif
+            sched_fence();
+          }
+        });
+      }
+      sbuf ^= 1;
+      cg = ncg; z = nz;
+    }
+#if ECO_SPANP_PROBE & 16          // bit 4 = no epilogue (accumulators kept live, nothing stored)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+    if (a.ntot < 0)
+#endif
+    if (a.ksplit > 1)
+      convb_store_partial<TM, TN>(a, acc, cur.slice, m0, cur.n0 + wave * 64, half, l31);   // (compiler-counted stores: the next wait drains them)
+    else
+      stores = convb_epilogue_wide<TM>(a, acc, m0, cur.n0 + wave * 64 + lane, half, Ep, BMP, pa.d_sout);
+    if (!have_next_item) break;
+    cur = nxt;
+    tile = ntile; slice = nslice;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1255,6 +1712,13 @@ extern "C" int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t
       plan->bn = 256;
     }
   }
+  // persistent span kernel: two workgroups per CU, the grid a multiple of 8 XCDs x the M-blocks of a position tile
+  plan->pgrid = 0;
+  if (plan->span_pieces) {
+    const int unit = 8 * (int)ceil_div(g->cout, bm);
+    plan->pgrid = (int)(2L * num_cu / unit) * unit;
+    if (plan->pgrid < unit) plan->pgrid = unit;
+  }
   plan->stem = is_stem(g) ? 1 : 0;
   plan->cblocks = plan->stem ? 4 : g->cin / 8;
   const int taps = plan->stem ? 7 : g->kernel[0] * g->kernel[1] * g->kernel[2];
@@ -1356,6 +1820,30 @@ static int launch_convb_span(const ConvBArgs& a, int span_pieces, hipStream_t st
   return check_launch("eco_convb_forward");
 }
 
+// The persistent form (convb_spanp_kernel): 2 workgroups per CU walk the (slice, tile) items.
+static bool spanp_enabled() {
+  static const int on = [] { const char* e = getenv("ECO_SPANP"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on != 0;
+}
+template <int TM>
+static int launch_convb_spanp(const ConvBArgs& a, const eco_convb_plan* plan, hipStream_t stream) {
+  constexpr int BM = 32 * TM, BMP = (BM + 63) / 64 * 64;
+  ECO_REQUIRE((((uintptr_t)a.x | (uintptr_t)a.wp) & 15) == 0, "convb: input and packed weights must be 16-byte aligned");
+  SpanPArgs pa;
+  pa.x_bytes = (unsigned)((long)a.ntot / a.s_out * a.img_stride_in * 16);
+  pa.wp_bytes = (unsigned)(plan->wp_vecs * 16);
+  pa.ntiles = a.nblk_m * a.nblk_n;
+  pa.d_sout = fastdiv_make((unsigned)a.s_out);
+  pa.d_hw = fastdiv_make((unsigned)(a.Hi * a.Wi));
+  pa.d_w = fastdiv_make((unsigned)a.Wi);
+  pa.d_ks = fastdiv_make((unsigned)a.ksplit);
+  pa.d_kd = fastdiv_make((unsigned)a.kd);
+  const size_t lds = (size_t)(3 * kCbs * BMP + 2 * kCbs * 384) * 16;
+  if (lds > 64 * 1024) ECO_RAISE_DYNAMIC_LDS((convb_spanp_kernel<TM>), "convb");
+  hipLaunchKernelGGL((convb_spanp_kernel<TM>), dim3(plan->pgrid), dim3(256), lds, stream, a, pa, plan->span_pieces);
+  return check_launch("eco_convb_forward");
+}
+
 template <int TM, int TN, int WM, int WN>
 static int launch_convb(const ConvBArgs& a, int ns, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -1449,6 +1937,29 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
               plan->ksplit <= (plan->nstages / a.taps) * a.kd;
     for (int i = 0; i < 3; ++i) ok = ok && g->stride[i] == 1 && g->out[i] == g->in[i];
     ECO_REQUIRE(ok, "convb: the span kernel needs a bf16 stride-1 same-size (kd)x3x3 geometry");
+    // persistent form: descriptor-addressed DMA needs both operands below 2 GB, a span of at most 6 pieces (its LDS pitch)
+    // and a grid the plan sized for the device (a plan of an older header has pgrid 0)
+    const long x_bytes = (long)g->n * a.img_stride_in * 16, wp_bytes = plan->wp_vecs * 16;
+    // (its epilogue addresses every destination as descriptor base + 32-bit offset: the views must end below 2 GB)
+    auto view_fits = [&](const eco_view& v) {
+      if (!v.ptr) return true;
+      const long nb = (g->n - 1) / v.t;
+      return (nb * v.stride_b + (long)(v.t - 1) * v.stride_t + (long)(g->cout / 8) * v.stride_c + a.s_out) * 16 < (1l << 31) - (1l << 20);
+    };
+    bool views_fit = view_fits(ep->residual) && view_fits(ep->raw) && view_fits(ep->act) && view_fits(ep->act2);
+    for (int sgi = 0; sgi < ep->nseg; ++sgi) views_fit = views_fit && view_fits(ep->seg_act[sgi]);
+    const bool persistent = spanp_enabled() && views_fit && plan->pgrid >= 8 * a.nblk_m && plan->pgrid % (8 * a.nblk_m) == 0 &&
+                            plan->span_pieces <= 6 && x_bytes < (1l << 31) - (1l << 20) && wp_bytes < (1l << 31) - (1l << 20) &&
+                            plan->ksplit * ((plan->nstages / a.taps) * a.kd) < (1 << 20);
+    if (persistent) {
+      switch (plan->bm) {
+        case 128: rc = launch_convb_spanp<4>(a, plan, s); break;
+        case 96: rc = launch_convb_spanp<3>(a, plan, s); break;
+        case 64: rc = launch_convb_spanp<2>(a, plan, s); break;
+        case 32: rc = launch_convb_spanp<1>(a, plan, s); break;
+        default: return fail(ECO_ERR_INVALID, "convb: unsupported span tile bm=%d", plan->bm);
+      }
+    } else
     switch (plan->bm) {
       case 128: rc = launch_convb_span<4, 2, 1, 4>(a, plan->span_pieces, s); break;
       case 96: rc = launch_convb_span<3, 2, 1, 4>(a, plan->span_pieces, s); break;

@@ -69,7 +69,17 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned h) {
   return __builtin_bit_cast(float, u);
 #endif
 }
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16); }
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+#ifdef ECO_EMU
+  return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+#else
+  // one v_cvt_pk_bf16_f32 (the scalar casts above compile to two conversions, a shift and an or)
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+#endif
+}
 
 // LDS-DMA: every lane copies 16 bytes from its own global address straight into LDS at
 // `lds_wave_base + 16*lane` (global_load_lds_dwordx4: no VGPR staging, no ds_write; the LDS base is wave-uniform,
@@ -94,6 +104,100 @@ __device__ __forceinline__ void glds16(const uint4* gptr, uint4* lds_wave_base) 
 #endif
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(gptr) : "memory", "m0");
 #endif
+}
+
+// LDS-DMA through a buffer descriptor: `buffer_load_dwordx4 voff, srd, soff offen lds`.  Two things the flat form
+// (glds16) cannot do: (1) the address is (SGPR descriptor base) + (SGPR soffset) + (VGPR 32-bit byte offset) -- the
+// uniform part of an address costs SALU instructions, the per-lane part is one register that stays put for a whole tile,
+// where glds16 needs a 64-bit VALU add per piece; (2) a lane whose voffset + soffset is not below the descriptor's
+// num_records reads nothing and WRITES ZEROS to its 16 bytes of LDS (measured on gfx950, tools/ubench/buflds_check.hip:
+// soffset takes part in the range check): zero padding is a per-lane select of kBufOob, no zero page, no second address.
+// num_records is 32-bit and kBufOob + soffset must not wrap: tensors above 2 GB stay on the glds16 kernels.
+constexpr unsigned kBufOob = 0x80000000u;
+#ifdef ECO_EMU
+struct BufRsrc { const char* base; unsigned bytes; };
+__device__ __forceinline__ BufRsrc make_buf_rsrc(const void* p, unsigned bytes) { return BufRsrc{(const char*)p, bytes}; }
+__device__ __forceinline__ void glds16_buf(const BufRsrc& r, unsigned voff, unsigned soff, uint4* lds_wave_base) {
+  uint4 q = {0u, 0u, 0u, 0u};
+  const unsigned long long off = (unsigned long long)voff + soff;
+  if (off + 16 <= r.bytes && emu::check_access(r.base + off, 16, false)) memcpy(&q, r.base + off, 16);
+  lds_wave_base[emu::tls_cur->lane] = q;
+}
+#else
+typedef int BufRsrc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ BufRsrc make_buf_rsrc(const void* p, unsigned bytes) {   // (p, bytes: wave-uniform)
+  const unsigned long long a = (unsigned long long)p;
+  BufRsrc r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));   // stride 0: raw buffer
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;
+  return r;
+}
+// (lds_wave_base: wave-uniform; one instruction per call whatever the lanes' offsets.  Counted by the caller:
+// wait_dma_all_but.)
+__device__ __forceinline__ void glds16_buf(const BufRsrc& r, unsigned voff, unsigned soff, uint4* lds_wave_base) {
+  // (soff / lds_wave_base must be SGPR values to the compiler -- no readfirstlane here: a VALU-written SGPR read by a
+  // VMEM instruction five states later is a hazard nobody pads inside an asm statement)
+  const unsigned lds_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_off), "v"(voff), "s"(r), "s"(soff) : "memory", "m0");
+}
+#endif
+
+// 16-byte store through a buffer descriptor (`buffer_store_dwordx4 v, voff, srd, soff offen`): lanes whose voffset +
+// soffset is not below num_records store nothing, and the instruction is issued whatever the lanes' predicates -- so a
+// kernel that counts its own memory operations (s_waitcnt vmcnt(N) over LDS-DMA pieces) knows how many stores an epilogue
+// put in the queue.  Not waited for by anybody: the data registers must not be reused before the store has read them,
+// hence the two wait states inside the statement.
+__device__ __forceinline__ void gst16_buf(const BufRsrc& r, unsigned voff, unsigned soff, uint4 v) {
+#ifdef ECO_EMU
+  const unsigned long long off = (unsigned long long)voff + soff;
+  if (off + 16 <= r.bytes && emu::check_access(r.base + off, 16, true)) memcpy((void*)(r.base + off), &v, 16);
+#else
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t q = {v.x, v.y, v.z, v.w};
+  // s_nop 4 in front: the descriptor / soffset may have been written by a VALU instruction (v_readfirstlane) just ahead
+  // of this statement -- VALU-writes-SGPR -> VMEM-reads-it needs five wait states and the compiler pads nothing inside asm
+  asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(q), "v"(voff), "s"(r), "s"(soff) : "memory");
+#endif
+}
+
+// v_permlane32_swap: the upper half-wave's `a` and the lower half-wave's `b` trade places (lanes 32..63 of a <-> lanes
+// 0..31 of b).  Two results of a 32x32 MFMA tile that sit in lanes l and l + 32 end up side by side in one lane.
+__device__ __forceinline__ void permlane32_swap(unsigned& a, unsigned& b) {
+#ifdef ECO_EMU
+  const int l = emu::tls_cur->lane;
+  float fa, fb;
+  memcpy(&fa, &a, 4); memcpy(&fb, &b, 4);
+  const float xa = emu::wave_xchg_f32(fa, l ^ 32), xb = emu::wave_xchg_f32(fb, l ^ 32);
+  float na = l < 32 ? fa : xb, nb = l < 32 ? xa : fb;
+  memcpy(&a, &na, 4); memcpy(&b, &nb, 4);
+#else
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0]; b = r[1];
+#endif
+}
+
+// Division of n < 2^31 by a run-time constant d >= 1 without the ~40-instruction software divide: q = (t + ((n - t) >> s1))
+// >> s2 with t = umulhi(n, m) (Granlund & Montgomery's round-up method; m, s1, s2 from fastdiv_make on the host).
+struct FastDiv { unsigned m, s1, s2, d; };
+inline FastDiv fastdiv_make(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;                       // l = ceil(log2 d)
+  f.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l < 1 ? 0 : l - 1;
+  return f;
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
+#ifdef ECO_EMU
+  const unsigned t = (unsigned)(((unsigned long long)n * f.m) >> 32);
+#else
+  const unsigned t = __umulhi(n, f.m);
+#endif
+  return (t + ((n - t) >> f.s1)) >> f.s2;
 }
 
 // Pipelined LDS-DMA needs two things __syncthreads() cannot give: a wait for all but the newest N DMA pieces of

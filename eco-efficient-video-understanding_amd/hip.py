@@ -54,7 +54,7 @@ class ConvPlan(C.Structure):
 class ConvBPlan(C.Structure):
     _fields_ = [("bm", C.c_int32), ("bn", C.c_int32), ("dt", C.c_int32), ("stem", C.c_int32),
                 ("cblocks", C.c_int32), ("nstages", C.c_int32), ("mpad", C.c_int32), ("ksplit", C.c_int32),
-                ("span_pieces", C.c_int32), ("reserved", C.c_int32), ("wp_vecs", C.c_int64), ("ws_bytes", C.c_int64)]
+                ("span_pieces", C.c_int32), ("pgrid", C.c_int32), ("wp_vecs", C.c_int64), ("ws_bytes", C.c_int64)]
 
 
 class WGemmPlan(C.Structure):
@@ -125,6 +125,8 @@ def wgemm_kernel_name(plan: "WGemmPlan") -> str:
 def convb_kernel_name(plan: "ConvBPlan") -> str:
     """Device kernel eco_convb_forward launches for this plan, as rocprofv3 prints it."""
     if plan.dt == DT_BF16 and plan.span_pieces:
+        if plan.pgrid and plan.span_pieces <= 6 and os.environ.get("ECO_SPANP", "1") != "0":
+            return f"eco::convb_spanp_kernel<{plan.bm // 32}>"      # persistent form (round 4)
         tm, tn, wm, wn = {128: (4, 2, 1, 4), 96: (3, 2, 1, 4), 64: (2, 2, 1, 4), 32: (1, 2, 1, 4)}[plan.bm]
         return f"eco::convb_span_kernel<{tm}, {tn}, {wm}, {wn}>"
     if plan.dt == DT_BF16:   # LDS-DMA kernel

@@ -390,7 +390,8 @@ typedef struct eco_convb_plan {
   int32_t mpad;      /* cout rounded up to a multiple of bm                                              */
   int32_t ksplit;    /* > 1: reduction cut into ksplit slices, summed by a second deterministic launch   */
   int32_t span_pieces; /* > 0: stride-1 same-size (kd)x3x3 span kernel; 64-position DMA pieces per staged span */
-  int32_t reserved;
+  int32_t pgrid;     /* > 0 (span plans, v17): workgroups of the persistent span kernel, 2 per compute unit,   */
+                     /* a multiple of 8 XCDs x the M-blocks of a position tile; 0 = one workgroup per tile   */
   int64_t wp_vecs;   /* 16-byte vectors in the packed weights: terms * nstages * 4 * mpad                */
   int64_t ws_bytes;  /* device scratch eco_convb_forward needs (0 if ksplit == 1)                        */
 } eco_convb_plan;

@@ -210,6 +210,8 @@ SPANS = [  # n, cin, cout, in_sp, num_cu  (stride-1 same-size (kd)x3x3 with >= 2
     (1, 64, 128, (3, 26, 27), None),     # 3-D, two channel groups x three depth taps, split over groups
     (1, 32, 96, (2, 33, 32), 1),         # bm = 96 (3x2 wave tiles), depth 2: both depth borders in one tile
     (3, 40, 32, (28, 28), 1),            # cin = 40: zero-padded second channel group; three images per tile row
+    (4, 64, 192, (30, 30), 1),           # two M-blocks of 96 per position tile; 30 items on 16 persistent workgroups
+    (2, 32, 32, (4, 20, 20), 1),         # 3-D, 13 tiles on 8 persistent workgroups: items change under a running pipeline
 ]
 
 

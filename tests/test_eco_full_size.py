@@ -206,16 +206,23 @@ def test_eco_lite_c5_bf16_n32():
     e_q = relerr(out[:1], ref_q)
     # (b) four clips of the batch (first, two in the middle, last) against the plain fp32 oracle, each run alone on the
     # CPU: max rel err, top-1 and top-5 agreement per clip (round-3 verdict: one clip was thin for a 3e-2 tolerance)
-    worst, top5 = 0.0, []
+    worst, top5, top1 = 0.0, [], []
     for clip in (0, 11, 20, 31):
         ref = _fast_oracle(spec1, params, x[clip * N:(clip + 1) * N])["fc8"]
         e = relerr(out[clip:clip + 1], ref)
         worst = max(worst, e)
         assert e < BF16_TOL, (clip, e)
-        assert out[clip].argmax() == ref.argmax(), clip
+        # top-1: equal, or the fp32 reference itself is a near-tie -- the class bf16 picks is within twice the measured
+        # absolute error of the reference's maximum (random-init logits DO tie that closely: clip 11's top two are 5.8
+        # apart at max|logit| 8578, and bf16 storage moves logits by up to ~30; measured on MI355X, round 4)
+        abs_err = float(np.abs(out[clip] - ref[0]).max())
+        got1, ref1 = int(out[clip].argmax()), int(ref.argmax())
+        top1.append(got1 == ref1)
+        assert ref[0, ref1] - ref[0, got1] <= 2.0 * abs_err, (clip, got1, ref1, float(ref[0, ref1] - ref[0, got1]), abs_err)
         top5.append(len(set(np.argsort(-out[clip])[:5]) & set(np.argsort(-ref[0])[:5])))
     print(f"bf16 N=32: rel err vs rounding-aware oracle (clip 0) {e_q:.3e}; vs fp32 oracle over clips 0/11/20/31 worst "
-          f"{worst:.3e}, top-1 equal on all four, top-5 overlap {top5}; max|logit| {np.abs(ref).max():.1f}")
+          f"{worst:.3e}, top-1 equal {top1} (else a reference near-tie within 2x the error), top-5 overlap {top5}; "
+          f"max|logit| {np.abs(ref).max():.1f}")
     assert e_q < BF16_TOL and min(top5) >= 4
     net1 = Net(models.eco_lite_deploy(num_segments=N, num_clips=1), params=params, dtype="bf16")
     alone = net1.forward(data=x[17 * N:18 * N])["fc8"]
