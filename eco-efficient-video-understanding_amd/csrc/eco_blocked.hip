@@ -1742,6 +1742,16 @@ extern "C" int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t
       plan->ws_bytes = (int64_t)sp * g->cout * ntot * 4;
     }
   }
+#ifdef ECO_CONVB_KSPLIT_ENV   // experiment builds only (tools/exp): split-K factor of span plans from the environment
+  if (plan->span_pieces && getenv("ECO_CONVB_KSPLIT")) {
+    long sp = atol(getenv("ECO_CONVB_KSPLIT"));
+    const long ng = plan->nstages / 9;
+    if (tiles < 2 * slots && sp >= 1 && sp <= ng) {
+      plan->ksplit = (int)sp;
+      plan->ws_bytes = sp > 1 ? (int64_t)sp * g->cout * ntot * 4 : 0;
+    }
+  }
+#endif
   return ECO_OK;
 }
 
