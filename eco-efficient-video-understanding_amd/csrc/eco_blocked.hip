@@ -69,6 +69,8 @@ struct ConvBArgs {
   long img_stride_in, cb_stride_in;   // in blocks
   int s_out, ntot, nblk_m, nblk_n, ksplit;
   float* ws;
+  int wide;            // 1: every destination view ends below 2 GB -> the 16-byte-store epilogue (convb_epilogue_wide)
+  FastDiv d_sout;      // position -> image by multiply-high
 };
 
 // ---- element helpers: NS = 1 -> bf16 storage, NS = 3 -> fp32 storage split into three bf16 terms -----------------
@@ -283,9 +285,10 @@ __device__ __forceinline__ void convb_epilogue(const ConvBArgs& a, f32x16 (&acc)
 __device__ __forceinline__ unsigned view_lane_offset(const eco_view& v, int img, int sp, bool ok) {
   return ok ? (unsigned)(view_base(v, img, sp) * 16) : kBufOob;
 }
+// (mw: first channel of the wave's rows; m0: first channel of the workgroup's rows = row 0 of Ep)
 template <int TM>
-__device__ __forceinline__ int convb_epilogue_wide(const ConvBArgs& a, f32x16 (&acc)[TM][2], int m0, int n_lane, int half,
-                                                   const float* Ep, int EPS, const FastDiv& d_sout) {
+__device__ __forceinline__ int convb_epilogue_wide(const ConvBArgs& a, f32x16 (&acc)[TM][2], int mw, int m0, int n_lane,
+                                                   int half, const float* Ep, int EPS, const FastDiv& d_sout) {
   const bool has_res = a.residual.ptr != nullptr;
   const bool has_raw = a.raw.ptr != nullptr, has_act = a.act.ptr != nullptr, has_act2 = has_act && a.act2.ptr != nullptr;
   const bool ok = n_lane < a.ntot;
@@ -304,7 +307,7 @@ __device__ __forceinline__ int convb_epilogue_wide(const ConvBArgs& a, f32x16 (&
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int cbk = (m0 + i * 32) / 8 + g;
+        const int cbk = (mw + i * 32) / 8 + g;
         res[i][g] = (ok && cbk * 8 < a.cout) ? ld((const uint4*)a.residual.ptr + rb + (long)cbk * a.residual.stride_c)
                                              : make_uint4(0u, 0u, 0u, 0u);
       }
@@ -313,7 +316,7 @@ __device__ __forceinline__ int convb_epilogue_wide(const ConvBArgs& a, f32x16 (&
   for (int i = 0; i < TM; ++i) {
     // the destination of this 32-row tile (wave-uniform): `act`, or a sibling's own tensor (values selected, never a
     // run-time index into the kernel argument struct: that would copy it to scratch memory)
-    const int mt = m0 + i * 32;
+    const int mt = mw + i * 32;
     void* aptr = a.act.ptr;
     long astride_c = a.act.stride_c, astride_b = a.act.stride_b;
     int relu = a.relu, cb0 = 0;
@@ -794,8 +797,15 @@ __global__ __launch_bounds__(256, 2) void convb_dma_kernel(const ConvBArgs a, co
   if (!(s_begin < s_end)) __syncthreads();   // (no stage ran: Ep has not been published by a barrier yet)
   if (a.ksplit > 1)
     convb_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
-  else
+  else {
+    if constexpr (TN == 2) {   // 64-position wave tiles: whole 16-byte blocks per lane
+      if (a.wide) {
+        convb_epilogue_wide<TM>(a, acc, m0 + wm * TM * 32, m0, n0 + wn * 64 + lane, half, Ep, BMP_E, a.d_sout);
+        return;
+      }
+    }
     convb_epilogue<TM, TN, 1>(a, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31, Ep, BMP_E, m0);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1333,7 +1343,7 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
     if (a.ksplit > 1)
       convb_store_partial<TM, TN>(a, acc, cur.slice, m0, cur.n0 + wave * 64, half, l31);   // (compiler-counted stores: the next wait drains them)
     else
-      stores = convb_epilogue_wide<TM>(a, acc, m0, cur.n0 + wave * 64 + lane, half, Ep, BMP, pa.d_sout);
+      stores = convb_epilogue_wide<TM>(a, acc, m0, m0, cur.n0 + wave * 64 + lane, half, Ep, BMP, pa.d_sout);
     if (!have_next_item) break;
     cur = nxt;
     tile = ntile; slice = nslice;
@@ -1938,6 +1948,16 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
               "convb: plan needs a %ld-byte workspace", (long)plan->ws_bytes);
   a.ksplit = plan->ksplit;
   a.ws = (float*)workspace;
+  // (the 16-byte-store epilogue addresses every destination as descriptor base + 32-bit offset: views must end below 2 GB)
+  auto view_fits = [&](const eco_view& v) {
+    if (!v.ptr) return true;
+    const long nb = (g->n - 1) / v.t;
+    return (nb * v.stride_b + (long)(v.t - 1) * v.stride_t + (long)(g->cout / 8) * v.stride_c + a.s_out) * 16 < (1l << 31) - (1l << 20);
+  };
+  bool views_fit = view_fits(ep->residual) && view_fits(ep->raw) && view_fits(ep->act) && view_fits(ep->act2);
+  for (int sgi = 0; sgi < ep->nseg; ++sgi) views_fit = views_fit && view_fits(ep->seg_act[sgi]);
+  a.wide = (ns == 1 && views_fit) ? 1 : 0;
+  a.d_sout = fastdiv_make((unsigned)a.s_out);
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (plan->span_pieces) {
@@ -1950,14 +1970,6 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
     // persistent form: descriptor-addressed DMA needs both operands below 2 GB, a span of at most 6 pieces (its LDS pitch)
     // and a grid the plan sized for the device (a plan of an older header has pgrid 0)
     const long x_bytes = (long)g->n * a.img_stride_in * 16, wp_bytes = plan->wp_vecs * 16;
-    // (its epilogue addresses every destination as descriptor base + 32-bit offset: the views must end below 2 GB)
-    auto view_fits = [&](const eco_view& v) {
-      if (!v.ptr) return true;
-      const long nb = (g->n - 1) / v.t;
-      return (nb * v.stride_b + (long)(v.t - 1) * v.stride_t + (long)(g->cout / 8) * v.stride_c + a.s_out) * 16 < (1l << 31) - (1l << 20);
-    };
-    bool views_fit = view_fits(ep->residual) && view_fits(ep->raw) && view_fits(ep->act) && view_fits(ep->act2);
-    for (int sgi = 0; sgi < ep->nseg; ++sgi) views_fit = views_fit && view_fits(ep->seg_act[sgi]);
     const bool persistent = spanp_enabled() && views_fit && plan->pgrid >= 8 * a.nblk_m && plan->pgrid % (8 * a.nblk_m) == 0 &&
                             plan->span_pieces <= 6 && x_bytes < (1l << 31) - (1l << 20) && wp_bytes < (1l << 31) - (1l << 20) &&
                             plan->ksplit * ((plan->nstages / a.taps) * a.kd) < (1 << 20);
