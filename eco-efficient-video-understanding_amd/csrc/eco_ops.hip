@@ -369,7 +369,33 @@ __global__ __launch_bounds__(1024) void global_avgpool_fc_kernel(const float* x,
   const long fstride = (long)c * s;
   // one channel per wave at a time; a lane owns positions lane, lane+64, ... of each of the t frames (no division in
   // the loop, four independent partial sums so that four loads are in flight)
-  for (int ch = wave; ch < c; ch += kWaves) {
+  // single-frame volumes of at most 256 positions (the 3-D tail: 4 x 7 x 7, 8 x 7 x 7): four channels of the wave at a time,
+  // all sixteen loads issued before the first butterfly -- one channel at a time the loop was a chain of L2 round trips
+  // (57 us of the 1.2 ms online step for a single clip's 512 x 196 volume, round 3)
+  int ch = wave;
+  if (t == 1 && s > kWave && s <= 4 * kWave) {
+    for (; ch + 3 * kWaves < c; ch += 4 * kWaves) {
+      float q[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* xp = xb + (long)(ch + u * kWaves) * s;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) q[u][v] = lane + v * kWave < s ? ld(xp + lane + v * kWave) : 0.0f;
+      }
+      float a4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a4[u] = (q[u][0] + q[u][1]) + (q[u][2] + q[u][3]);
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a4[u] += shfl_xor(a4[u], m);
+      if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pooled[ch + u * kWaves] = a4[u] * inv;
+      }
+    }
+  }
+  for (; ch < c; ch += kWaves) {
     const float* xp = xb + (long)ch * s;
     float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
     if (s <= kWave) {          // 2-D stream: one load per frame (7x7 planes), eight frames in flight
@@ -403,9 +429,17 @@ __global__ __launch_bounds__(1024) void global_avgpool_fc_kernel(const float* x,
   const int o_end = min(o_begin + out_per_block, n_out);
   for (int o = o_begin + wave; o < o_end; o += kWaves) {
     const float* wr = w + (long)o * wk + c0;
-    float acc = 0.0f;
-    for (int i = lane; i < c; i += kWave) acc += pooled[i] * ld(wr + i);
-    acc = wave_sum(acc);
+    float acc = 0.0f, acc1 = 0.0f;
+    int i = lane;
+    for (; i + 7 * kWave < c; i += 8 * kWave) {   // eight weight loads in flight
+      float wq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wq[u] = ld(wr + i + u * kWave);
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) { acc += pooled[i + u * kWave] * wq[u]; acc1 += pooled[i + (u + 1) * kWave] * wq[u + 1]; }
+    }
+    for (; i < c; i += kWave) acc += pooled[i] * ld(wr + i);
+    acc = wave_sum(acc + acc1);
     if (lane == 0) {
       float* yp = y + (long)b * n_out + o;
       float v = acc + (bias ? ld(bias + o) : 0.0f);

@@ -351,6 +351,18 @@ def test_inner_product_tail_softmax(backend):
     lib.global_avgpool_fc_forward(backend.ptr(backend.dev(f)), backend.ptr(backend.dev(w2)),
                                   backend.ptr(backend.dev(b2)), backend.ptr(y2), B, C, S, NO, C + 5, 5, False)
     assert relerr(backend.host(y2, (B, NO)), ref2) < TOL
+    # the ECO tail's own shape class: one frame of 65..256 positions per channel (res5b at num_segments 16 / 32: 4x7x7,
+    # 8x7x7), enough channels for the four-channels-at-a-time pooling loop, a ragged channel count and >= 512 weights per
+    # logit for the eight-loads-in-flight fc loop
+    for C3, dhw in ((152, (4, 7, 7)), (520, (3, 5, 5)), (100, (8, 7, 7))):
+        S3 = int(np.prod(dhw))
+        f3 = rng.standard_normal((B, C3) + dhw).astype(np.float32)
+        w3 = rng.standard_normal((NO, C3)).astype(np.float32)
+        ref3 = orc.inner_product(f3.reshape(B, C3, S3).mean(2, dtype=np.float64).astype(np.float32), w3, b2)
+        y3 = backend.empty((B, NO))
+        lib.global_avgpool_fc_forward(backend.ptr(backend.dev(f3)), backend.ptr(backend.dev(w3)), backend.ptr(backend.dev(b2)),
+                                      backend.ptr(y3), B, C3, S3, NO, C3, 0, False)
+        assert relerr(backend.host(y3, (B, NO)), ref3) < TOL, (C3, dhw)
     sm = rng.standard_normal((2, 7, 3)).astype(np.float32)
     ys = backend.empty(sm.shape)
     lib.softmax_forward(backend.ptr(backend.dev(sm)), backend.ptr(ys), 2, 7, 3)
