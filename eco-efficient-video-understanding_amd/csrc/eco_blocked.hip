@@ -503,6 +503,9 @@ __global__ __launch_bounds__(256, 2) void convb_kernel(const ConvBArgs a) {
   constexpr int BMP_E = (BM + 63) / 64 * 64;
   __shared__ __attribute__((aligned(16))) float Ep[3 * BMP_E];   // bias / BN scale / BN shift of this workgroup's rows
   convb_stage_params<BMP_E>(a, m0, Ep);
+#ifndef ECO_EMU
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Ep's ds_writes retired before the first (non-draining) barrier
+#endif
   const int s_begin = (int)((long)slice * a.nstages / a.ksplit);
   const int s_end = (int)((long)(slice + 1) * a.nstages / a.ksplit);
 
@@ -690,6 +693,9 @@ __global__ __launch_bounds__(256, 2) void convb_dma_kernel(const ConvBArgs a, co
   constexpr int BMP_E = (BM + 63) / 64 * 64;
   __shared__ __attribute__((aligned(16))) float Ep[3 * BMP_E];   // bias / BN scale / BN shift of this workgroup's rows
   convb_stage_params<BMP_E>(a, m0, Ep);
+#ifndef ECO_EMU
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Ep's ds_writes retired before the first (non-draining) barrier
+#endif
   const int s_begin = (int)((long)slice * a.nstages / a.ksplit);
   const int s_end = (int)((long)(slice + 1) * a.nstages / a.ksplit);
 
@@ -855,6 +861,9 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
   constexpr int BMP_E = (BM + 63) / 64 * 64;
   __shared__ __attribute__((aligned(16))) float Ep[3 * BMP_E];   // bias / BN scale / BN shift of this workgroup's rows
   convb_stage_params<BMP_E>(a, m0, Ep);
+#ifndef ECO_EMU
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Ep's ds_writes retired before the first (non-draining) barrier
+#endif
   const int ngroups = (a.nstages / a.taps) * a.kd;          // (channel group, depth tap)
   const int g_begin = (int)((long)slice * ngroups / a.ksplit);
   const int g_end = (int)((long)(slice + 1) * ngroups / a.ksplit);

@@ -1654,6 +1654,12 @@ static int conv_forward_impl(const eco_conv_geom* g, const eco_conv_plan* plan, 
     const int64_t blocks = ((int64_t)2 * plan->streamk_wgs * plan->bm * plan->bn * 4 + 255) / 256 * 256;   // two per workgroup
     ECO_REQUIRE(blocks + (int64_t)plan->streamk_wgs * 4 <= plan->ws_bytes && plan->ktab_elems >= plan->kpad + a.nblk_n + 1,
                 "conv: stream-K plan workspace / table too small");
+    // The finishing workgroup of a shared tile spins on flags of other workgroups: every one of the plan's workgroups
+    // must be resident.  A plan sized for more compute units than the current device has (num_cu given by the caller)
+    // would deadlock, so it is refused here rather than launched (round-3 advisor finding).
+    ECO_REQUIRE(plan->streamk_wgs <= 2 * current_device_num_cu(),
+                "conv: stream-K plan has %d persistent workgroups, the current device runs at most %d side by side",
+                plan->streamk_wgs, 2 * current_device_num_cu());
     a.sk_wgs = plan->streamk_wgs;
     a.sk_cum = ktab + plan->kpad;
     a.sk_flags = (int*)((char*)workspace + blocks);

@@ -230,7 +230,8 @@ int eco_pool_forward(const eco_pool_geom* g, const float* x, float* y, void* str
  * follows such a pool in an Inception block applied to the pool's INPUT instead (both maps are linear and the pool's
  * coefficients constant, so they commute), this kernel finishes  pool -> conv -> BN -> ReLU
  * (models_ECO_Lite/kinetics/deploy.prototxt:330-400; pooling_layer.cpp, conv_layer.cpp:28-43, bn_layer.cpp:93-207)
- * on cout instead of cin channels. */
+ * on cout instead of cin channels.  x must be a dense N,C,H,W tensor (planes contiguous, no strides); 16-byte accesses are
+ * used when x, the view's base and w allow it (w % 4 == 0 and aligned pointers), 4-byte ones otherwise. */
 int eco_avgpool_affine_forward(const float* x, const float* bias, const float* bn_scale, const float* bn_shift,
                                int32_t relu, const eco_view* dst, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
 
