@@ -1101,10 +1101,16 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
   const int wave = uniform(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
 
-  // ---- this workgroup's items: logical id L keeps the M-blocks of one position tile on one XCD (hardware places
-  //      block b on XCD b % 8); item k of the workgroup = position tile nblk0 + k * nstep of M-block mblk ----
+  // ---- this workgroup's items: item k = L + k * grid.  The logical id L (a bijection of the block index; grid is a
+  //      multiple of 8 * nblk_m) orders blocks by (chunk of 8 * nblk_m consecutive blocks, XCD = b % 8, M-block): the
+  //      M-blocks of one position tile land on one XCD (hardware places block b on XCD b % 8), AND the workgroups with
+  //      L < R are a run of consecutive blocks for every R -- so the items of a last, partial round spread over all eight
+  //      XCDs and one per CU (blocks b and b + grid/2 share a CU).  Round 4 first used L = (b % 8) * (grid / 8) + b / 8:
+  //      res4's 272 second-round items then all sat on XCDs 0-4, four items on each of their CUs and two on the others'
+  //      (1.2 waves per SIMD over the launch, profiles/r04_bf16_pmc_sq.csv). ----
   const int grid = (int)gridDim.x;
-  const int L = ((int)blockIdx.x % 8) * (grid / 8) + (int)blockIdx.x / 8;   // grid is a multiple of 8 * nblk_m
+  const int bx = (int)blockIdx.x;
+  const int L = ((bx / (8 * a.nblk_m)) * 8 + bx % 8) * a.nblk_m + (bx / 8) % a.nblk_m;
   const int mblk = L % a.nblk_m;                   // (grid and ntiles are multiples of nblk_m: every item of L has this M-block)
   const int m0 = mblk * BM;
   int tile = L, slice = 0;                         // item k = L + k * grid -> (slice, tile) = divmod(item, ntiles)
