@@ -69,6 +69,9 @@ struct ConvBArgs {
   long img_stride_in, cb_stride_in;   // in blocks
   int s_out, ntot, nblk_m, nblk_n, ksplit;
   float* ws;
+  // split-K workspace ws[slice][channel][position - ws_n0], ws_pitch positions per row, ws_slices slices summed by the
+  // reduce launch (a whole-tensor split: 0 / ntot / ksplit; the persistent kernel's K-split tail: its last position tiles)
+  int ws_n0, ws_pitch, ws_slices;
   int wide;            // 1: every destination view ends below 2 GB -> the 16-byte-store epilogue (convb_epilogue_wide)
   FastDiv d_sout;      // position -> image by multiply-high
 };
@@ -396,7 +399,7 @@ __device__ __forceinline__ int convb_epilogue_wide(const ConvBArgs& a, f32x16 (&
 template <int TM, int TN>
 __device__ __forceinline__ void convb_store_partial(const ConvBArgs& a, f32x16 (&acc)[TM][TN], int slice, int mw, int nw,
                                                     int half, int l31) {
-  float* base = a.ws + (long)slice * a.cout * a.ntot;
+  float* base = a.ws + (long)slice * a.cout * a.ws_pitch - a.ws_n0;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = nw + j * 32 + l31;
@@ -406,7 +409,7 @@ __device__ __forceinline__ void convb_store_partial(const ConvBArgs& a, f32x16 (
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ch = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (ch < a.cout) st(base + (long)ch * a.ntot + n, acc[i][j][r]);
+        if (ch < a.cout) st(base + (long)ch * a.ws_pitch + n, acc[i][j][r]);
       }
   }
 }
@@ -415,9 +418,9 @@ __device__ __forceinline__ void convb_store_partial(const ConvBArgs& a, f32x16 (
 // the epilogue; writes whole blocks.
 template <int NS>
 __global__ __launch_bounds__(256) void convb_splitk_reduce_kernel(const ConvBArgs a) {
-  const long total = (long)(a.cout / 8) * a.ntot;
+  const long total = (long)(a.cout / 8) * a.ws_pitch;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int cbk = (int)(idx / a.ntot), n = (int)(idx - (long)cbk * a.ntot);
+    const int cbk = (int)(idx / a.ws_pitch), nl = (int)(idx - (long)cbk * a.ws_pitch), n = a.ws_n0 + nl;
     int img, sp;
     decode_out(a, n, img, sp);
 #pragma unroll
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256) void convb_splitk_reduce_kernel(const ConvBArg
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float s = 0.0f;
-        for (int sl = 0; sl < a.ksplit; ++sl) s += ld(a.ws + ((long)sl * a.cout + ch0 + q) * a.ntot + n);
+        for (int sl = 0; sl < a.ws_slices; ++sl) s += ld(a.ws + ((long)sl * a.cout + ch0 + q) * a.ws_pitch + nl);
         v[q] = s + (a.bias ? ld(a.bias + ch0 + q) : 0.0f);
       }
       if (a.residual.ptr) {
@@ -1077,7 +1080,11 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
 struct SpanPArgs {
   unsigned x_bytes, wp_bytes;
   int ntiles;                      // nblk_m * nblk_n
-  FastDiv d_sout, d_hw, d_w, d_ks, d_kd;
+  // items: tiles [0, t_main) whole (epilogue), then the last t_tail tiles cut into kb slices of their groups each (partial
+  // sums + the reduce launch): a whole-tensor split-K is t_main = 0, a plain launch t_tail = 0, and a launch whose tile
+  // count leaves a partial last round per CU splits just that remainder -- e.g. res4's 784 tiles on 256 CUs: 768 + 16 x 8
+  int t_main, t_tail, kb, nitems;
+  FastDiv d_sout, d_hw, d_w, d_ks, d_kd, d_tail;
 };
 
 template <int TM>
@@ -1113,9 +1120,8 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
   const int L = ((bx / (8 * a.nblk_m)) * 8 + bx % 8) * a.nblk_m + (bx / 8) % a.nblk_m;
   const int mblk = L % a.nblk_m;                   // (grid and ntiles are multiples of nblk_m: every item of L has this M-block)
   const int m0 = mblk * BM;
-  int tile = L, slice = 0;                         // item k = L + k * grid -> (slice, tile) = divmod(item, ntiles)
-  while (tile >= pa.ntiles) { tile -= pa.ntiles; ++slice; }
-  if (slice >= a.ksplit) return;                   // (fewer items than workgroups: uniform exit, before any barrier)
+  int item = L;                                    // item k of this workgroup = L + k * grid
+  if (item >= pa.nitems) return;                   // (fewer items than workgroups: uniform exit, before any barrier)
   convb_stage_params<BMP>(a, m0, Ep);
 #ifndef ECO_EMU
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Ep's ds_writes retired before the first (non-draining) barrier
@@ -1143,17 +1149,26 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
 
   // ---- per-item lane state ----
   struct Item {
-    int n0, slice, g_begin, g_end;
+    int n0, slice, g_begin, g_end;   // slice < 0: a whole tile (epilogue); else slice `slice` of pa.kb (partial sums)
     unsigned spv[2];     // byte offset of span element (chunk c, this lane) at depth shift 0
     int spd[2];          // its depth index (hugely negative: never valid)
     unsigned fmask[TN];  // in-plane tap masks of the lane's fragment positions: bit y*3 + x
   };
-  auto make_item = [&](int nb, int sl) {
+  auto make_item = [&](int id) {
     Item it;
-    it.n0 = nb * BN;
-    it.slice = sl;
-    it.g_begin = a.ksplit == 1 ? 0 : (int)fastdiv((unsigned)(sl * ngroups), pa.d_ks);
-    it.g_end = a.ksplit == 1 ? ngroups : (int)fastdiv((unsigned)((sl + 1) * ngroups), pa.d_ks);
+    int tile = id;
+    it.slice = -1;
+    it.g_begin = 0;
+    it.g_end = ngroups;
+    if (id >= pa.t_main) {
+      const int j = id - pa.t_main;
+      const int sl = (int)fastdiv((unsigned)j, pa.d_tail);
+      tile = pa.t_main + j - sl * pa.t_tail;
+      it.slice = sl;
+      it.g_begin = (int)fastdiv((unsigned)(sl * ngroups), pa.d_ks);
+      it.g_end = (int)fastdiv((unsigned)((sl + 1) * ngroups), pa.d_ks);
+    }
+    it.n0 = (tile / a.nblk_m) * BN;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int v = it.n0 - halo + (wave + 4 * c) * 64 + lane;
@@ -1228,7 +1243,7 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
   };
 
   f32x16 acc[TM][TN];
-  Item cur = make_item(tile / a.nblk_m, slice);
+  Item cur = make_item(item);
   int cg = (int)fastdiv((unsigned)cur.g_begin, pa.d_kd), z = cur.g_begin - cg * a.kd;
   issue_span(cur.spv[0], cur.spv[1], cur.spd[0], cur.spd[1], cg, z, 0);
   issue_weights(cg * a.taps + z * T2, 0);
@@ -1239,9 +1254,8 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
 
   for (;;) {
     // the item after this one (uniform)
-    int ntile = tile + grid, nslice = slice;
-    while (ntile >= pa.ntiles) { ntile -= pa.ntiles; ++nslice; }
-    const bool have_next_item = nslice < a.ksplit;
+    const int nitem = item + grid;
+    const bool have_next_item = nitem < pa.nitems;
     Item nxt = cur;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1260,7 +1274,7 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
         have_next = have_next_item;
         if (have_next_item) {
 #if !(ECO_SPANP_PROBE & 64)      // bit 6 = no per-item index arithmetic (the first item's lane state is reused: wrong results)
-          nxt = make_item(ntile / a.nblk_m, nslice);   // VALU under the DMA / the other workgroup's MFMAs
+          nxt = make_item(nitem);                      // VALU under the DMA / the other workgroup's MFMAs
 #endif
           ncg = (int)fastdiv((unsigned)nxt.g_begin, pa.d_kd);
           nz = nxt.g_begin - ncg * a.kd;
@@ -1355,13 +1369,13 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
         for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
     if (a.ntot < 0)
 #endif
-    if (a.ksplit > 1)
+    if (cur.slice >= 0)
       convb_store_partial<TM, TN>(a, acc, cur.slice, m0, cur.n0 + wave * 64, half, l31);   // (compiler-counted stores: the next wait drains them)
     else
       stores = convb_epilogue_wide<TM>(a, acc, m0, m0, cur.n0 + wave * 64 + lane, half, Ep, BMP, pa.d_sout);
     if (!have_next_item) break;
     cur = nxt;
-    tile = ntile; slice = nslice;
+    item = nitem;
   }
 }
 
@@ -1744,6 +1758,8 @@ extern "C" int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t
     plan->pgrid = (int)(2L * num_cu / unit) * unit;
     if (plan->pgrid < unit) plan->pgrid = unit;
   }
+  plan->tail_tiles = 0;
+  plan->tail_ksplit = 1;
   plan->stem = is_stem(g) ? 1 : 0;
   plan->cblocks = plan->stem ? 4 : g->cin / 8;
   const int taps = plan->stem ? 7 : g->kernel[0] * g->kernel[1] * g->kernel[2];
@@ -1765,6 +1781,27 @@ extern "C" int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t
     if (sp >= 2) {
       plan->ksplit = (int)sp;
       plan->ws_bytes = (int64_t)sp * g->cout * ntot * 4;
+    }
+  }
+  // K-split tail of the persistent span kernel: with more tiles than CUs and a remainder r = tiles mod CUs, r CUs would
+  // run one whole item more than the others -- res4: 784 tiles on 256 CUs, 16 of them four items instead of three, a
+  // quarter of the launch with 240 CUs idle.  The last r tiles are cut into kb slices of their channel-group range so
+  // that r * kb <= CUs: one short extra round for everybody, partial sums for r tiles only.
+  if (plan->pgrid > 0 && plan->ksplit == 1) {
+    const long cus = plan->pgrid / 2, r = tiles % cus;
+    const long groups = plan->nstages / 9;
+    long kb = r > 0 ? cus / r : 0;
+    if (kb > 8) kb = 8;
+    if (kb > groups) kb = groups;
+    // worth it on long reductions only: the tail costs a reduce launch and a round trip of its partial sums -- measured
+    // +12-15 % on the 2-3-group inception 3x3s (64 tail tiles of an 18-27-tap item), -15 % on res4, -2 % on res3
+    const long rounds = ceil_div(tiles, cus);
+    const bool pays = groups >= 12 && (kb - 1) * 20 >= kb * rounds;      // predicted gain (1 - 1/kb) / rounds >= 5 %
+    if (tiles > cus && r > 0 && kb >= 2 && pays && r % ceil_div(g->cout, bm) == 0) {
+      plan->tail_tiles = (int)r;
+      plan->tail_ksplit = (int)kb;
+      const long tail_pos = ntot - (ceil_div(ntot, plan->bn) - r / ceil_div(g->cout, bm)) * plan->bn;
+      plan->ws_bytes = (int64_t)kb * g->cout * tail_pos * 4;
     }
   }
 #ifdef ECO_CONVB_KSPLIT_ENV   // experiment builds only (tools/exp): split-K factor of span plans from the environment
@@ -1868,11 +1905,17 @@ static int launch_convb_spanp(const ConvBArgs& a, const eco_convb_plan* plan, hi
   pa.x_bytes = (unsigned)((long)a.ntot / a.s_out * a.img_stride_in * 16);
   pa.wp_bytes = (unsigned)(plan->wp_vecs * 16);
   pa.ntiles = a.nblk_m * a.nblk_n;
+  // whole-tensor split: every tile in ksplit slices; K-split tail: the plan's last tail_tiles in tail_ksplit slices
+  pa.t_tail = a.ksplit > 1 ? pa.ntiles : a.ws_slices > 1 ? plan->tail_tiles : 0;
+  pa.kb = a.ksplit > 1 ? a.ksplit : a.ws_slices > 1 ? plan->tail_ksplit : 1;
+  pa.t_main = pa.ntiles - pa.t_tail;
+  pa.nitems = pa.t_main + pa.t_tail * pa.kb;
   pa.d_sout = fastdiv_make((unsigned)a.s_out);
   pa.d_hw = fastdiv_make((unsigned)(a.Hi * a.Wi));
   pa.d_w = fastdiv_make((unsigned)a.Wi);
-  pa.d_ks = fastdiv_make((unsigned)a.ksplit);
+  pa.d_ks = fastdiv_make((unsigned)pa.kb);
   pa.d_kd = fastdiv_make((unsigned)a.kd);
+  pa.d_tail = fastdiv_make((unsigned)(pa.t_tail > 0 ? pa.t_tail : 1));
   const size_t lds = (size_t)(3 * kCbs * BMP + 2 * kCbs * 384) * 16;
   if (lds > 64 * 1024) ECO_RAISE_DYNAMIC_LDS((convb_spanp_kernel<TM>), "convb");
   hipLaunchKernelGGL((convb_spanp_kernel<TM>), dim3(plan->pgrid), dim3(256), lds, stream, a, pa, plan->span_pieces);
@@ -1963,6 +2006,7 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
               "convb: plan needs a %ld-byte workspace", (long)plan->ws_bytes);
   a.ksplit = plan->ksplit;
   a.ws = (float*)workspace;
+  a.ws_n0 = 0; a.ws_pitch = a.ntot; a.ws_slices = plan->ksplit;
   // (the 16-byte-store epilogue addresses every destination as descriptor base + 32-bit offset: views must end below 2 GB)
   auto view_fits = [&](const eco_view& v) {
     if (!v.ptr) return true;
@@ -1988,6 +2032,19 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
     const bool persistent = spanp_enabled() && views_fit && plan->pgrid >= 8 * a.nblk_m && plan->pgrid % (8 * a.nblk_m) == 0 &&
                             plan->span_pieces <= 6 && x_bytes < (1l << 31) - (1l << 20) && wp_bytes < (1l << 31) - (1l << 20) &&
                             plan->ksplit * ((plan->nstages / a.taps) * a.kd) < (1 << 20);
+    // K-split tail (persistent form only; the per-tile kernel runs such a plan unsplit): the reduce launch covers the
+    // tail's positions
+    const bool tail = persistent && plan->ksplit == 1 && plan->tail_tiles > 0 && plan->tail_ksplit > 1;
+    if (tail) {
+      ECO_REQUIRE(plan->tail_tiles % a.nblk_m == 0 && plan->tail_tiles < a.nblk_m * a.nblk_n &&
+                      plan->tail_ksplit <= (plan->nstages / a.taps) * a.kd,
+                  "convb: bad K-split tail (%d tiles x %d)", plan->tail_tiles, plan->tail_ksplit);
+      a.ws_n0 = (a.nblk_n - plan->tail_tiles / a.nblk_m) * plan->bn;
+      a.ws_pitch = a.ntot - a.ws_n0;
+      a.ws_slices = plan->tail_ksplit;
+      ECO_REQUIRE(workspace && (int64_t)a.ws_slices * g->cout * a.ws_pitch * 4 <= plan->ws_bytes,
+                  "convb: plan needs a %ld-byte workspace", (long)plan->ws_bytes);
+    }
     if (persistent) {
       switch (plan->bm) {
         case 128: rc = launch_convb_spanp<4>(a, plan, s); break;
@@ -2020,8 +2077,8 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
     case 32: ECO_REQUIRE(plan->bn == 256, "convb: bad plan"); rc = launch_convb<1, 2, 1, 4>(a, ns, s); break;
     default: return fail(ECO_ERR_INVALID, "convb: unsupported block tile bm=%d", plan->bm);
   }
-  if (rc != ECO_OK || a.ksplit == 1) return rc;
-  const int rgrid = grid_for_b((long)(a.cout / 8) * a.ntot);
+  if (rc != ECO_OK || a.ws_slices == 1) return rc;
+  const int rgrid = grid_for_b((long)(a.cout / 8) * a.ws_pitch);
   if (ns == 1) hipLaunchKernelGGL((convb_splitk_reduce_kernel<1>), dim3(rgrid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((convb_splitk_reduce_kernel<3>), dim3(rgrid), dim3(256), 0, s, a);
   return check_launch("eco_convb_forward(split-K reduce)");

@@ -54,7 +54,8 @@ class ConvPlan(C.Structure):
 class ConvBPlan(C.Structure):
     _fields_ = [("bm", C.c_int32), ("bn", C.c_int32), ("dt", C.c_int32), ("stem", C.c_int32),
                 ("cblocks", C.c_int32), ("nstages", C.c_int32), ("mpad", C.c_int32), ("ksplit", C.c_int32),
-                ("span_pieces", C.c_int32), ("pgrid", C.c_int32), ("wp_vecs", C.c_int64), ("ws_bytes", C.c_int64)]
+                ("span_pieces", C.c_int32), ("pgrid", C.c_int32), ("wp_vecs", C.c_int64), ("ws_bytes", C.c_int64),
+                ("tail_tiles", C.c_int32), ("tail_ksplit", C.c_int32)]
 
 
 class WGemmPlan(C.Structure):

@@ -394,7 +394,10 @@ typedef struct eco_convb_plan {
   int32_t pgrid;     /* > 0 (span plans, v17): workgroups of the persistent span kernel, 2 per compute unit,   */
                      /* a multiple of 8 XCDs x the M-blocks of a position tile; 0 = one workgroup per tile   */
   int64_t wp_vecs;   /* 16-byte vectors in the packed weights: terms * nstages * 4 * mpad                */
-  int64_t ws_bytes;  /* device scratch eco_convb_forward needs (0 if ksplit == 1)                        */
+  int64_t ws_bytes;  /* device scratch eco_convb_forward needs (0: none)                                 */
+  int32_t tail_tiles;  /* > 0 (persistent span plans with ksplit == 1, v17): the last tail_tiles tiles are   */
+  int32_t tail_ksplit; /* cut into tail_ksplit slices of their reduction (partial sums + a reduce launch     */
+                       /* over their positions only), so that a partial last round per CU becomes a short one */
 } eco_convb_plan;
 
 /* Requirements: cout % 8 == 0 and cin % 8 == 0, or the stem geometry (cin 3, 2-D 7x7, stride 2, pad 3, even W).

@@ -212,7 +212,10 @@ SPANS = [  # n, cin, cout, in_sp, num_cu  (stride-1 same-size (kd)x3x3 with >= 2
     (3, 40, 32, (28, 28), 1),            # cin = 40: zero-padded second channel group; three images per tile row
     (4, 64, 192, (30, 30), 1),           # two M-blocks of 96 per position tile; 30 items on 16 persistent workgroups
     (2, 32, 32, (4, 20, 20), 1),         # 3-D, 13 tiles on 8 persistent workgroups: items change under a running pipeline
+    (1, 384, 64, (50, 50), 1),           # 10 tiles on 4 CUs, twelve channel groups: a K-split tail of 2 tiles x 2 slices
+    (2, 128, 192, (3, 27, 26), 2),       # two M-blocks, 16 + 1 position tiles on 8 CUs, 12 groups: a tail of one position tile (2 tiles) x 4
 ]
+TAILS = {"s6": (2, 2), "s7": (2, 4)}   # case id -> (tail_tiles, tail_ksplit) the plan must choose (long reductions only)
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -224,6 +227,8 @@ def test_convb_span_kernel(backend, dt, n, cin, cout, in_sp, num_cu):
     if dt == BF16:
         assert plan.span_pieces == -(-(256 + 2 * (in_sp[-1] + 1)) // 64) and plan.bn == 256
         assert (plan.ksplit > 1) == (num_cu is None)
+        case = f"s{SPANS.index((n, cin, cout, in_sp, num_cu))}"
+        assert (plan.tail_tiles, plan.tail_ksplit) == TAILS.get(case, (0, 1)), (case, plan.tail_tiles, plan.tail_ksplit)
     else:
         assert plan.span_pieces == 0
 
