@@ -13,6 +13,9 @@ rocprofv3 --kernel-trace --stats -d $PWD/$OUT/trace -o bench --output-format csv
 rocprofv3 --pmc FETCH_SIZE -d $PWD/$OUT/pmc_fetch -o bench --output-format csv -- $B --steps 2 --warmup 1 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $PWD/$OUT/pmc_write -o bench --output-format csv -- $B --steps 2 --warmup 1 > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA -d $PWD/$OUT/pmc_sq -o bench --output-format csv -- $B --steps 2 --warmup 1 > $OUT/pmc_sq.log 2>&1
+# the un-profiled bench lines report `roofline.traffic` from profiles/hbm_traffic_latest.json when that file belongs to the
+# sources of the running library: condense this run's PMC passes first (into this box's copy of profiles/), then bench
+python tools/summarize_profiles.py $OUT boxtmp > /dev/null 2>&1
 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 # the other BASELINE configurations: configs[4] (bf16, N=32) with its kernel trace, configs[3] (ECO-Full)
 rocprofv3 --kernel-trace --stats -d $PWD/$OUT/trace_bf16 -o bench --output-format csv -- $B --segments 32 --dtype bf16 --steps 10 --warmup 3 > $OUT/trace_bf16.log 2>&1
