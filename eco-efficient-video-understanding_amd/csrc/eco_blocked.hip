@@ -72,6 +72,12 @@ struct ConvBArgs {
   // split-K workspace ws[slice][channel][position - ws_n0], ws_pitch positions per row, ws_slices slices summed by the
   // reduce launch (a whole-tensor split: 0 / ntot / ksplit; the persistent kernel's K-split tail: its last position tiles)
   int ws_n0, ws_pitch, ws_slices;
+  // ws_frag = 1 (bf16 launches whose destinations take the 16-byte-store epilogue): the partial sums leave in the MFMA
+  // fragment layout instead -- ws[slice][tile - ws_tile0][wave][i][j][g][lane] float4 = registers 4g..4g+3 of the wave's
+  // 32x32 tile (i, j): 8*TM one-KB stores per wave and slice where the [channel][position] form takes 32*TM 256-byte
+  // ones, and the reduce launch (convb_splitk_reduce_frag_kernel) rebuilds a tile's accumulators with 16-byte loads and runs
+  // the same epilogue as an unsplit tile.  ws_ntl = tiles the workspace covers.
+  int ws_frag, ws_tile0, ws_ntl;
   int wide;            // 1: every destination view ends below 2 GB -> the 16-byte-store epilogue (convb_epilogue_wide)
   FastDiv d_sout;      // position -> image by multiply-high
 };
@@ -412,6 +418,61 @@ __device__ __forceinline__ void convb_store_partial(const ConvBArgs& a, f32x16 (
         if (ch < a.cout) st(base + (long)ch * a.ws_pitch + n, acc[i][j][r]);
       }
   }
+}
+
+// ... in the fragment layout (ConvBArgs::ws_frag).  `stores` of the caller: 8*TM buffer stores per wave when counted.
+template <int TM>
+__device__ __forceinline__ int convb_store_partial_frag(const ConvBArgs& a, f32x16 (&acc)[TM][2], int slice, int tile,
+                                                        int wave, int lane, const BufRsrc& rws) {
+  const unsigned so = (unsigned)((((long)slice * a.ws_ntl + (tile - a.ws_tile0)) * 4 + wave) * (TM * 8) * 64 * 16);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 q = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        gst16_buf(rws, (unsigned)((((i * 2 + j) * 4 + g) * 64 + lane) * 16), so,
+                  make_uint4(__builtin_bit_cast(unsigned, q.x), __builtin_bit_cast(unsigned, q.y), __builtin_bit_cast(unsigned, q.z), __builtin_bit_cast(unsigned, q.w)));
+      }
+  return TM * 8;
+}
+
+// Second pass of a fragment-layout split: one workgroup per (tile, 32-row m-tile of its waves) -- the producing kernel's
+// four waves, one of their TM m-tiles each, so that a tail of 16 tiles still spreads over 64 workgroups -- each lane sums
+// its eight float4 over the slices in a fixed order (all loads of up to eight slices in flight: 1 KB per wave instruction)
+// and the m-tile gets the epilogue an unsplit tile would have had.  WN = waves side by side in N (4: 128/96/64/32 x 256
+// tiles; 2: 256 / 128 x 128 tiles).
+template <int TM, int WN>
+__global__ __launch_bounds__(256) void convb_splitk_reduce_frag_kernel(const ConvBArgs a) {
+  constexpr int WM = 4 / WN, BM = 32 * TM * WM, BN = 64 * WN, BMP = (BM + 63) / 64 * 64;
+  constexpr int kMaxSlices = 8;                 // (plans split at most eight ways)
+  __shared__ __attribute__((aligned(16))) float Ep[3 * BMP];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6), half = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tl = (int)blockIdx.x / TM, i = (int)blockIdx.x - tl * TM;   // local tile, m-tile of every wave
+  const int tile = a.ws_tile0 + tl;
+  const int mblk = tile % a.nblk_m, nblk = tile / a.nblk_m;
+  const int m0 = mblk * BM, n0 = nblk * BN;
+  convb_stage_params<BMP>(a, m0, Ep);
+  f32x16 acc[1][2];
+  const float4* base = (const float4*)a.ws + (((long)tl * 4 + wave) * (TM * 8) + i * 8) * 64 + lane;
+  const long sstride = (long)a.ws_ntl * 4 * (TM * 8) * 64;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 q[kMaxSlices];
+#pragma unroll
+      for (int sl = 0; sl < kMaxSlices; ++sl)
+        q[sl] = sl < a.ws_slices ? ld(base + sl * sstride + (j * 4 + g) * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 sum = q[0];
+#pragma unroll
+      for (int sl = 1; sl < kMaxSlices; ++sl) { sum.x += q[sl].x; sum.y += q[sl].y; sum.z += q[sl].z; sum.w += q[sl].w; }
+      acc[0][j][4 * g] = sum.x; acc[0][j][4 * g + 1] = sum.y; acc[0][j][4 * g + 2] = sum.z; acc[0][j][4 * g + 3] = sum.w;
+    }
+  __syncthreads();   // Ep
+  convb_epilogue_wide<1>(a, acc, m0 + (wm * TM + i) * 32, m0, n0 + wn * 64 + lane, half, Ep, BMP, a.d_sout);
 }
 
 // Second pass of split-K: one thread per (position, 8-channel block) sums the slices in a fixed order and applies
@@ -804,9 +865,16 @@ __global__ __launch_bounds__(256, 2) void convb_dma_kernel(const ConvBArgs a, co
     }
   }
   if (!(s_begin < s_end)) __syncthreads();   // (no stage ran: Ep has not been published by a barrier yet)
-  if (a.ksplit > 1)
+  if (a.ksplit > 1) {
+    if constexpr (TN == 2) {
+      if (a.ws_frag) {
+        const BufRsrc rws = make_buf_rsrc(a.ws, 0x7fffffffu);
+        convb_store_partial_frag<TM>(a, acc, slice, mblk + nblk * a.nblk_m, wave, lane, rws);
+        return;
+      }
+    }
     convb_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
-  else {
+  } else {
     if constexpr (TN == 2) {   // 64-position wave tiles: whole 16-byte blocks per lane
       if (a.wide) {
         convb_epilogue_wide<TM>(a, acc, m0 + wm * TM * 32, m0, n0 + wn * 64 + lane, half, Ep, BMP_E, a.d_sout);
@@ -1128,6 +1196,7 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
 #endif
 
   const BufRsrc rx = make_buf_rsrc(a.x, pa.x_bytes), rw = make_buf_rsrc(a.wp, pa.wp_bytes);
+  const BufRsrc rws = make_buf_rsrc(a.ws, 0x7fffffffu);   // partial sums (fragment layout: the plan keeps them below 2 GB)
   const int hw = a.Hi * a.Wi, halo = a.Wi + 1;
   const int ngroups = (a.nstages / a.taps) * a.kd;
   const unsigned cbs16 = (unsigned)a.cb_stride_in * 16u;
@@ -1149,7 +1218,7 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
 
   // ---- per-item lane state ----
   struct Item {
-    int n0, slice, g_begin, g_end;   // slice < 0: a whole tile (epilogue); else slice `slice` of pa.kb (partial sums)
+    int n0, tile, slice, g_begin, g_end;   // slice < 0: a whole tile (epilogue); else slice `slice` of pa.kb (partial sums)
     unsigned spv[2];     // byte offset of span element (chunk c, this lane) at depth shift 0
     int spd[2];          // its depth index (hugely negative: never valid)
     unsigned fmask[TN];  // in-plane tap masks of the lane's fragment positions: bit y*3 + x
@@ -1168,6 +1237,7 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
       it.g_begin = (int)fastdiv((unsigned)(sl * ngroups), pa.d_ks);
       it.g_end = (int)fastdiv((unsigned)((sl + 1) * ngroups), pa.d_ks);
     }
+    it.tile = tile;
     it.n0 = (tile / a.nblk_m) * BN;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -1369,9 +1439,10 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
         for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
     if (a.ntot < 0)
 #endif
-    if (cur.slice >= 0)
-      convb_store_partial<TM, TN>(a, acc, cur.slice, m0, cur.n0 + wave * 64, half, l31);   // (compiler-counted stores: the next wait drains them)
-    else
+    if (cur.slice >= 0) {
+      if (a.ws_frag) stores = convb_store_partial_frag<TM>(a, acc, cur.slice, cur.tile, wave, lane, rws);   // (counted: stepped over)
+      else convb_store_partial<TM, TN>(a, acc, cur.slice, m0, cur.n0 + wave * 64, half, l31);   // (compiler-counted stores: the next wait drains them)
+    } else
       stores = convb_epilogue_wide<TM>(a, acc, m0, m0, cur.n0 + wave * 64 + lane, half, Ep, BMP, pa.d_sout);
     if (!have_next_item) break;
     cur = nxt;
@@ -1780,7 +1851,7 @@ extern "C" int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t
     if (plan->span_pieces && sp > plan->nstages / 9) sp = plan->nstages / 9;   // the span kernel splits whole groups
     if (sp >= 2) {
       plan->ksplit = (int)sp;
-      plan->ws_bytes = (int64_t)sp * g->cout * ntot * 4;
+      plan->ws_bytes = (int64_t)sp * tiles * bm * plan->bn * 4;   // whole tiles: the fragment layout of the partial sums
     }
   }
   // K-split tail of the persistent span kernel: with more tiles than CUs and a remainder r = tiles mod CUs, r CUs would
@@ -1801,7 +1872,8 @@ extern "C" int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t
       plan->tail_tiles = (int)r;
       plan->tail_ksplit = (int)kb;
       const long tail_pos = ntot - (ceil_div(ntot, plan->bn) - r / ceil_div(g->cout, bm)) * plan->bn;
-      plan->ws_bytes = (int64_t)kb * g->cout * tail_pos * 4;
+      plan->ws_bytes = (int64_t)kb * r * bm * plan->bn * 4;
+      (void)tail_pos;
     }
   }
 #ifdef ECO_CONVB_KSPLIT_ENV   // experiment builds only (tools/exp): split-K factor of span plans from the environment
@@ -1810,7 +1882,7 @@ extern "C" int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t
     const long ng = plan->nstages / 9;
     if (tiles < 2 * slots && sp >= 1 && sp <= ng) {
       plan->ksplit = (int)sp;
-      plan->ws_bytes = sp > 1 ? (int64_t)sp * g->cout * ntot * 4 : 0;
+      plan->ws_bytes = sp > 1 ? (int64_t)sp * tiles * bm * plan->bn * 4 : 0;
     }
   }
 #endif
@@ -2007,6 +2079,7 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
   a.ksplit = plan->ksplit;
   a.ws = (float*)workspace;
   a.ws_n0 = 0; a.ws_pitch = a.ntot; a.ws_slices = plan->ksplit;
+  a.ws_frag = 0; a.ws_tile0 = 0; a.ws_ntl = a.nblk_m * a.nblk_n;
   // (the 16-byte-store epilogue addresses every destination as descriptor base + 32-bit offset: views must end below 2 GB)
   auto view_fits = [&](const eco_view& v) {
     if (!v.ptr) return true;
@@ -2017,6 +2090,11 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
   for (int sgi = 0; sgi < ep->nseg; ++sgi) views_fit = views_fit && view_fits(ep->seg_act[sgi]);
   a.wide = (ns == 1 && views_fit) ? 1 : 0;
   a.d_sout = fastdiv_make((unsigned)a.s_out);
+  // whole-tensor split: the fragment layout when the epilogue it ends in is the 16-byte one, every instance of the
+  // launched kernel has 64-position wave tiles (all bf16 ones) and the padded workspace fits plan and descriptor
+  const int64_t frag_bytes = (int64_t)plan->ksplit * a.nblk_m * a.nblk_n * plan->bm * plan->bn * 4;
+  if (plan->ksplit > 1 && plan->ksplit <= 8 && a.wide && !plan->stem && frag_bytes <= plan->ws_bytes && frag_bytes < (1l << 31) - (1l << 20))
+    a.ws_frag = 1;
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (plan->span_pieces) {
@@ -2042,7 +2120,11 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
       a.ws_n0 = (a.nblk_n - plan->tail_tiles / a.nblk_m) * plan->bn;
       a.ws_pitch = a.ntot - a.ws_n0;
       a.ws_slices = plan->tail_ksplit;
-      ECO_REQUIRE(workspace && (int64_t)a.ws_slices * g->cout * a.ws_pitch * 4 <= plan->ws_bytes,
+      a.ws_tile0 = a.nblk_m * a.nblk_n - plan->tail_tiles;
+      a.ws_ntl = plan->tail_tiles;
+      const int64_t tfrag = (int64_t)plan->tail_ksplit * plan->tail_tiles * plan->bm * plan->bn * 4;
+      a.ws_frag = (a.wide && plan->tail_ksplit <= 8 && tfrag <= plan->ws_bytes && tfrag < (1l << 31) - (1l << 20)) ? 1 : 0;
+      ECO_REQUIRE(workspace && (a.ws_frag || (int64_t)a.ws_slices * g->cout * a.ws_pitch * 4 <= plan->ws_bytes),
                   "convb: plan needs a %ld-byte workspace", (long)plan->ws_bytes);
     }
     if (persistent) {
@@ -2053,13 +2135,15 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
         case 32: rc = launch_convb_spanp<1>(a, plan, s); break;
         default: return fail(ECO_ERR_INVALID, "convb: unsupported span tile bm=%d", plan->bm);
       }
-    } else
+    } else {
+    a.ws_frag = 0;   // (the per-tile span kernel writes its partial sums as [channel][position])
     switch (plan->bm) {
       case 128: rc = launch_convb_span<4, 2, 1, 4>(a, plan->span_pieces, s); break;
       case 96: rc = launch_convb_span<3, 2, 1, 4>(a, plan->span_pieces, s); break;
       case 64: rc = launch_convb_span<2, 2, 1, 4>(a, plan->span_pieces, s); break;
       case 32: rc = launch_convb_span<1, 2, 1, 4>(a, plan->span_pieces, s); break;
       default: return fail(ECO_ERR_INVALID, "convb: unsupported span tile bm=%d", plan->bm);
+    }
     }
   } else
   switch (plan->bm) {
@@ -2078,6 +2162,20 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
     default: return fail(ECO_ERR_INVALID, "convb: unsupported block tile bm=%d", plan->bm);
   }
   if (rc != ECO_OK || a.ws_slices == 1) return rc;
+  if (a.ws_frag) {
+    const int wn = plan->bn / 64;   // waves side by side in N of the producing kernel (4 or 2)
+    const int tm = plan->bm / 32 / (4 / wn);
+#define ECO_FRAG_REDUCE(TMv, WNv) hipLaunchKernelGGL((convb_splitk_reduce_frag_kernel<TMv, WNv>), dim3(a.ws_ntl * TMv), dim3(256), 0, s, a)
+    if (wn == 4 && tm == 4) ECO_FRAG_REDUCE(4, 4);
+    else if (wn == 4 && tm == 3) ECO_FRAG_REDUCE(3, 4);
+    else if (wn == 4 && tm == 2) ECO_FRAG_REDUCE(2, 4);
+    else if (wn == 4 && tm == 1) ECO_FRAG_REDUCE(1, 4);
+    else if (wn == 2 && tm == 4) ECO_FRAG_REDUCE(4, 2);
+    else if (wn == 2 && tm == 2) ECO_FRAG_REDUCE(2, 2);
+    else return fail(ECO_ERR_INVALID, "convb: no fragment-layout reduce for a %d x %d tile", plan->bm, plan->bn);
+#undef ECO_FRAG_REDUCE
+    return check_launch("eco_convb_forward(split-K reduce)");
+  }
   const int rgrid = grid_for_b((long)(a.cout / 8) * a.ws_pitch);
   if (ns == 1) hipLaunchKernelGGL((convb_splitk_reduce_kernel<1>), dim3(rgrid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((convb_splitk_reduce_kernel<3>), dim3(rgrid), dim3(256), 0, s, a);
