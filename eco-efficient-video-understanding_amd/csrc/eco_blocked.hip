@@ -175,14 +175,17 @@ __device__ __forceinline__ void decode_out(const ConvBArgs& a, int n, int& img, 
 // short reductions (conv2_3x3, the inception 3x3s: 18-27 stages per tile) that chain was 15-20 % of the launch
 // (profiles/r03_notes.md).  Visible to every wave after the main loop's first barrier.
 template <int BMP>
-__device__ __forceinline__ void convb_stage_params(const ConvBArgs& a, int m0, float* Ep) {
+__device__ __forceinline__ void convb_stage_params(const ConvBArgs& a, int m0, float* Ep, bool fold = false) {
   const int t = (int)threadIdx.x;
   if (t < BMP) {
     const int ch = m0 + t;
     const bool in = ch < a.cout;
-    Ep[t] = (in && a.bias) ? ld(a.bias + ch) : 0.0f;
-    Ep[BMP + t] = (in && a.bn_scale) ? ld(a.bn_scale + ch) : 1.0f;
-    Ep[2 * BMP + t] = (in && a.bn_scale) ? ld(a.bn_shift + ch) : 0.0f;
+    const float b = (in && a.bias) ? ld(a.bias + ch) : 0.0f;
+    const float sc = (in && a.bn_scale) ? ld(a.bn_scale + ch) : 1.0f;
+    const float sh = (in && a.bn_scale) ? ld(a.bn_shift + ch) : 0.0f;
+    Ep[t] = b;
+    Ep[BMP + t] = sc;
+    Ep[2 * BMP + t] = fold ? fmaf(b, sc, sh) : sh;   // fold: (v + b) * sc + sh as v * sc + (b * sc + sh) (convb_epilogue_lean)
   }
 }
 
@@ -297,13 +300,27 @@ __device__ __forceinline__ unsigned view_lane_offset(const eco_view& v, int img,
 // (mw: first channel of the wave's rows; m0: first channel of the workgroup's rows = row 0 of Ep)
 template <int TM>
 __device__ __forceinline__ int convb_epilogue_wide(const ConvBArgs& a, f32x16 (&acc)[TM][2], int mw, int m0, int n_lane,
-                                                   int half, const float* Ep, int EPS, const FastDiv& d_sout) {
+                                                   int half, const float* Ep, int EPS, const FastDiv& d_sout
+#ifdef ECO_SPANP_TS
+                                                   , unsigned long long* tsp = nullptr
+#endif
+                                                   ) {
+#ifdef ECO_SPANP_TS
+#define ECO_TSE(k) do { if (tsp) tsp[21 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ECO_TSE(k) do { } while (0)
+#endif
+  ECO_TSE(0);
   const bool has_res = a.residual.ptr != nullptr;
   const bool has_raw = a.raw.ptr != nullptr, has_act = a.act.ptr != nullptr, has_act2 = has_act && a.act2.ptr != nullptr;
   const bool ok = n_lane < a.ntot;
   const unsigned nn = ok ? (unsigned)n_lane : 0u;
   const int img = (int)fastdiv(nn, d_sout), sp = (int)(nn - (unsigned)img * (unsigned)a.s_out);
+#ifdef ECO_EPI_PROBE_NOSTORE             // probe builds (tools/exp): every store fails its range check -- issued, never written
+  constexpr unsigned kAll = 0u;
+#else
   constexpr unsigned kAll = 0x7fffffffu;   // (range check = the lane predicate only: valid offsets are below 2 GB by plan)
+#endif
   const unsigned v_raw = has_raw ? view_lane_offset(a.raw, img, sp, ok) : kBufOob;
   const unsigned v_act2 = has_act2 ? view_lane_offset(a.act2, img, sp, ok) : kBufOob;
   const BufRsrc r_raw = make_buf_rsrc(a.raw.ptr, kAll), r_act2 = make_buf_rsrc(a.act2.ptr, kAll);
@@ -321,8 +338,10 @@ __device__ __forceinline__ int convb_epilogue_wide(const ConvBArgs& a, f32x16 (&
                                              : make_uint4(0u, 0u, 0u, 0u);
       }
   }
+  ECO_TSE(1);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    ECO_TSE(2 + i);
     // the destination of this 32-row tile (wave-uniform): `act`, or a sibling's own tensor (values selected, never a
     // run-time index into the kernel argument struct: that would copy it to scratch memory)
     const int mt = mw + i * 32;
@@ -436,6 +455,64 @@ __device__ __forceinline__ int convb_store_partial_frag(const ConvBArgs& a, f32x
                   make_uint4(__builtin_bit_cast(unsigned, q.x), __builtin_bit_cast(unsigned, q.y), __builtin_bit_cast(unsigned, q.z), __builtin_bit_cast(unsigned, q.w)));
       }
   return TM * 8;
+}
+
+// The epilogue of the commonest launch -- one destination, bias + folded BN + ReLU, nothing else (no raw copy, no
+// residual, no second destination, no sibling segments) -- as its own lean body: y = max(acc * scale + shift', 0) with
+// shift' = bias * scale + shift folded once per workgroup (convb_stage_params fold).  Round 4's cycle stamps
+// (tools/exp/spanp_ts.py) had the general body at ~690 cycles per 8-channel block group (three parameter reads from LDS
+// waited for on the spot, ~70 instructions with six uniform branches and spilled-SGPR reloads) -- 11 k cycles per
+// 128 x 256 tile, 5.8 k of a 25 k-cycle inception 3x3 item.  Here the parameters of a 32-row tile are read in one go,
+// the next tile's while this one is converted, and a group is 8 FMA + 8 max + 4 conversions + 2 lane swaps + the store.
+template <int TM>
+__device__ __forceinline__ int convb_epilogue_lean(const ConvBArgs& a, f32x16 (&acc)[TM][2], int mw, int m0, int n_lane,
+                                                   int half, const float* Ep, int EPS, const FastDiv& d_sout) {
+  const bool ok = n_lane < a.ntot;
+  const unsigned nn = ok ? (unsigned)n_lane : 0u;
+  const int img = (int)fastdiv(nn, d_sout), sp = (int)(nn - (unsigned)img * (unsigned)a.s_out);
+#ifdef ECO_EPI_PROBE_NOSTORE
+  constexpr unsigned kAll = 0u;
+#else
+  constexpr unsigned kAll = 0x7fffffffu;
+#endif
+  const BufRsrc r_act = make_buf_rsrc(a.act.ptr, kAll);
+  const unsigned v_act = ok ? (unsigned)(view_base(a.act, img, sp) * 16) : kBufOob;
+  const unsigned cstep = (unsigned)(a.act.stride_c * 16);
+  float4 ps[2][4], ph[2][4];
+  auto load_params = [&](int i, int slot) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = mw + i * 32 + 8 * g + 4 * half - m0;
+      ps[slot][g] = *(const float4*)(Ep + EPS + c);
+      ph[slot][g] = *(const float4*)(Ep + 2 * EPS + c);
+    }
+  };
+  load_params(0, 0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (i + 1 < TM) load_params(i + 1, (i + 1) & 1);
+    const int mt = mw + i * 32;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cbk = mt / 8 + g;
+      const bool rows = cbk * 8 < a.cout;
+      const float4 s4 = ps[i & 1][g], h4 = ph[i & 1][g];
+      const float sc[4] = {s4.x, s4.y, s4.z, s4.w}, sh[4] = {h4.x, h4.y, h4.z, h4.w};
+      unsigned pact[2][2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float y[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[q] = fmaxf(fmaf(acc[i][j][4 * g + q], sc[q], sh[q]), 0.0f);
+        pact[j][0] = pack_bf16x2(y[0], y[1]);
+        pact[j][1] = pack_bf16x2(y[2], y[3]);
+      }
+      permlane32_swap(pact[0][0], pact[1][0]);
+      permlane32_swap(pact[0][1], pact[1][1]);
+      gst16_buf(r_act, rows ? v_act : kBufOob, (unsigned)cbk * cstep, make_uint4(pact[0][0], pact[0][1], pact[1][0], pact[1][1]));
+    }
+  }
+  return TM * 4;
 }
 
 // Second pass of a fragment-layout split: one workgroup per (tile, 32-row m-tile of its waves) -- the producing kernel's
@@ -1145,6 +1222,19 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
 #ifndef ECO_SPANP_PROBE
 #define ECO_SPANP_PROBE 0
 #endif
+#ifdef ECO_SPANP_TS   // probe builds (tools/exp/spanp_ts.py): cycle stamps of waves 0 and 3 of the first 64 workgroups
+__device__ unsigned long long eco_spanp_ts[64 * 2 * 8 * 32];
+extern "C" int eco_spanp_ts_read(void* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(eco_spanp_ts), sizeof(eco_spanp_ts));
+}
+#define ECO_TS(slot)                                                                                              \
+  do {                                                                                                            \
+    if ((wave == 0 || wave == 3) && ts_item < 8 && lane == 0)                                                     \
+      ts_l[((wave ? 1 : 0) * 8 + ts_item) * 32 + (slot)] = __builtin_readcyclecounter();                          \
+  } while (0)
+#else
+#define ECO_TS(slot) do { } while (0)
+#endif
 struct SpanPArgs {
   unsigned x_bytes, wp_bytes;
   int ntiles;                      // nblk_m * nblk_n
@@ -1152,6 +1242,7 @@ struct SpanPArgs {
   // sums + the reduce launch): a whole-tensor split-K is t_main = 0, a plain launch t_tail = 0, and a launch whose tile
   // count leaves a partial last round per CU splits just that remainder -- e.g. res4's 784 tiles on 256 CUs: 768 + 16 x 8
   int t_main, t_tail, kb, nitems;
+  int lean;                        // 1: whole tiles end in convb_epilogue_lean (act only, BN/bias + ReLU)
   FastDiv d_sout, d_hw, d_w, d_ks, d_kd, d_tail;
 };
 
@@ -1167,6 +1258,11 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
   static_assert(T2 % NB == 0, "a group must start at ring slot 0");
 
   __shared__ __attribute__((aligned(16))) float Ep[3 * BMP];   // bias / BN scale / BN shift of this workgroup's rows
+#ifdef ECO_SPANP_TS
+  __shared__ unsigned long long ts_l[2 * 8 * 32];
+  int ts_item = 0;
+  for (int q = (int)threadIdx.x; q < 2 * 8 * 32; q += 256) ts_l[q] = 0ull;
+#endif
   ECO_DYNAMIC_LDS(lds_f);
   uint4* const Aw = (uint4*)lds_f;                 // [NB][kCbs][BMP]
   uint4* const Bsp = Aw + NB * kCbs * BMP;         // [2][kCbs][SPITCH]
@@ -1190,7 +1286,7 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
   const int m0 = mblk * BM;
   int item = L;                                    // item k of this workgroup = L + k * grid
   if (item >= pa.nitems) return;                   // (fewer items than workgroups: uniform exit, before any barrier)
-  convb_stage_params<BMP>(a, m0, Ep);
+  convb_stage_params<BMP>(a, m0, Ep, pa.lean != 0);
 #ifndef ECO_EMU
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Ep's ds_writes retired before the first (non-draining) barrier
 #endif
@@ -1365,11 +1461,14 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
           constexpr int xx = decltype(xc)::value;
           constexpr int abuf = xx;                     // t2 % NB with t2 = 3y + xx
           const int t2 = 3 * y + xx;
+          if (g == cur.g_begin && t2 < 6) ECO_TS(1 + 3 * t2);
           if (stores) { wait_newest_behind_stores(newest, stores); stores = 0; }
           else wait_newest(newest);
+          if (g == cur.g_begin && t2 < 6) ECO_TS(2 + 3 * t2);
 #if !(ECO_SPANP_PROBE & 1)      // probe builds (tools/exp): bit 0 = no barrier per tap
           wg_barrier_nodrain();
 #endif
+          if (g == cur.g_begin && t2 < 6) ECO_TS(3 + 3 * t2);
           int cnt = 0;
 #if ECO_SPANP_PROBE & 2         // bit 1 = no operand DMA after the prologue
           if (a.ntot < 0) {
@@ -1439,15 +1538,33 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
         for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
     if (a.ntot < 0)
 #endif
+    ECO_TS(19);
     if (cur.slice >= 0) {
       if (a.ws_frag) stores = convb_store_partial_frag<TM>(a, acc, cur.slice, cur.tile, wave, lane, rws);   // (counted: stepped over)
       else convb_store_partial<TM, TN>(a, acc, cur.slice, m0, cur.n0 + wave * 64, half, l31);   // (compiler-counted stores: the next wait drains them)
     } else
+    if (pa.lean)
+      stores = convb_epilogue_lean<TM>(a, acc, m0, m0, cur.n0 + wave * 64 + lane, half, Ep, BMP, pa.d_sout);
+    else
+#ifdef ECO_SPANP_TS
+      stores = convb_epilogue_wide<TM>(a, acc, m0, m0, cur.n0 + wave * 64 + lane, half, Ep, BMP, pa.d_sout,
+                                       ((wave == 0 || wave == 3) && ts_item < 8 && lane == 0) ? &ts_l[((wave ? 1 : 0) * 8 + ts_item) * 32] : nullptr);
+#else
       stores = convb_epilogue_wide<TM>(a, acc, m0, m0, cur.n0 + wave * 64 + lane, half, Ep, BMP, pa.d_sout);
+#endif
+    ECO_TS(20);
+#ifdef ECO_SPANP_TS
+    ++ts_item;
+#endif
     if (!have_next_item) break;
     cur = nxt;
     item = nitem;
   }
+#ifdef ECO_SPANP_TS
+  __syncthreads();
+  if (bx < 64)
+    for (int q = tid; q < 2 * 8 * 32; q += 256) eco_spanp_ts[bx * (2 * 8 * 32) + q] = ts_l[q];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1982,6 +2099,7 @@ static int launch_convb_spanp(const ConvBArgs& a, const eco_convb_plan* plan, hi
   pa.kb = a.ksplit > 1 ? a.ksplit : a.ws_slices > 1 ? plan->tail_ksplit : 1;
   pa.t_main = pa.ntiles - pa.t_tail;
   pa.nitems = pa.t_main + pa.t_tail * pa.kb;
+  pa.lean = (a.wide && a.act.ptr && !a.raw.ptr && !a.residual.ptr && !a.act2.ptr && a.nseg == 0 && a.relu) ? 1 : 0;
   pa.d_sout = fastdiv_make((unsigned)a.s_out);
   pa.d_hw = fastdiv_make((unsigned)(a.Hi * a.Wi));
   pa.d_w = fastdiv_make((unsigned)a.Wi);

@@ -233,6 +233,15 @@ def test_convb_span_kernel(backend, dt, n, cin, cout, in_sp, num_cu):
         assert plan.span_pieces == 0
 
 
+@pytest.mark.parametrize("n,cin,cout,in_sp,num_cu", SPANS, ids=[f"s{i}" for i in range(len(SPANS))])
+def test_convb_span_kernel_single_destination(backend, n, cin, cout, in_sp, num_cu):
+    """One destination, bias + BN + ReLU, no raw copy and no residual: the persistent kernel's lean epilogue
+    (convb_epilogue_lean: bias folded into the BN shift once per workgroup); the tail / split cases finish in the
+    reduce kernel's general epilogue, on the same data."""
+    k = (3,) * len(in_sp)
+    run_convb(backend, BF16, n, cin, cout, in_sp, k, (1,) * len(in_sp), (1,) * len(in_sp), num_cu=num_cu, seed=5, raw=False)
+
+
 def test_convb_rejects_unblocked_geometries(backend):
     g = hip.conv_geom(1, 20, 32, (4, 4), (1, 1), (1, 1), (0, 0), (4, 4))
     with pytest.raises(hip.EcoError, match="multiple of the 8-channel block"):
