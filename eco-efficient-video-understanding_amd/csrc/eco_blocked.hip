@@ -79,6 +79,7 @@ struct ConvBArgs {
   // the same epilogue as an unsplit tile.  ws_ntl = tiles the workspace covers.
   int ws_frag, ws_tile0, ws_ntl;
   int wide;            // 1: every destination view ends below 2 GB -> the 16-byte-store epilogue (convb_epilogue_wide)
+  int lean;            // 1 (needs wide): one destination per 32-row tile, bias + BN + ReLU only -> convb_epilogue_lean
   FastDiv d_sout;      // position -> image by multiply-high
 };
 
@@ -363,14 +364,15 @@ __device__ __forceinline__ int convb_epilogue_wide(const ConvBArgs& a, f32x16 (&
         relu = take ? qr : relu; cb0 = take ? qbeg / 8 : cb0;
       }
     }
+    const float floor_ = relu ? 0.0f : -__builtin_inff();   // ReLU / no ReLU as one v_max either way
     const BufRsrc r_act = make_buf_rsrc(aptr, kAll);
     const unsigned v_act = !has_act ? kBufOob : !ok ? kBufOob
                            : seg ? (unsigned)(((long)img * astride_b + sp) * 16) : (unsigned)(view_base(a.act, img, sp) * 16);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int ch0 = mt + 8 * g + 4 * half;
       const int cbk = mt / 8 + g;
       const bool rows = cbk * 8 < a.cout;     // (cout is a multiple of 8: a block is inside or outside as a whole; uniform)
+      const int ch0 = mt + 8 * g + 4 * half;
       const float4 b4 = *(const float4*)(Ep + (ch0 - m0)), s4 = *(const float4*)(Ep + EPS + (ch0 - m0)),
                    h4 = *(const float4*)(Ep + 2 * EPS + (ch0 - m0));
       const float pb[4] = {b4.x, b4.y, b4.z, b4.w}, ps[4] = {s4.x, s4.y, s4.z, s4.w}, ph[4] = {h4.x, h4.y, h4.z, h4.w};
@@ -395,8 +397,7 @@ __device__ __forceinline__ int convb_epilogue_wide(const ConvBArgs& a, f32x16 (&
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          y[q] = v[q] * ps[q] + ph[q];
-          if (relu) y[q] = fmaxf(y[q], 0.0f);
+          y[q] = fmaxf(v[q] * ps[q] + ph[q], floor_);
         }
         praw[j][0] = pack_bf16x2(v[0], v[1]); praw[j][1] = pack_bf16x2(v[2], v[3]);
         pact[j][0] = pack_bf16x2(y[0], y[1]); pact[j][1] = pack_bf16x2(y[2], y[3]);
@@ -457,14 +458,15 @@ __device__ __forceinline__ int convb_store_partial_frag(const ConvBArgs& a, f32x
   return TM * 8;
 }
 
-// The epilogue of the commonest launch -- one destination, bias + folded BN + ReLU, nothing else (no raw copy, no
-// residual, no second destination, no sibling segments) -- as its own lean body: y = max(acc * scale + shift', 0) with
+// The epilogue of the commonest launch -- one destination per 32-row tile (`act` or a sibling segment's tensor), bias +
+// folded BN (+ ReLU), nothing else (no raw copy, no residual, no second destination) -- as its own lean body:
+// y = max(acc * scale + shift', 0 or -inf) with
 // shift' = bias * scale + shift folded once per workgroup (convb_stage_params fold).  Round 4's cycle stamps
 // (tools/exp/spanp_ts.py) had the general body at ~690 cycles per 8-channel block group (three parameter reads from LDS
 // waited for on the spot, ~70 instructions with six uniform branches and spilled-SGPR reloads) -- 11 k cycles per
 // 128 x 256 tile, 5.8 k of a 25 k-cycle inception 3x3 item.  Here the parameters of a 32-row tile are read in one go,
 // the next tile's while this one is converted, and a group is 8 FMA + 8 max + 4 conversions + 2 lane swaps + the store.
-template <int TM>
+template <int TM, bool SEG>
 __device__ __forceinline__ int convb_epilogue_lean(const ConvBArgs& a, f32x16 (&acc)[TM][2], int mw, int m0, int n_lane,
                                                    int half, const float* Ep, int EPS, const FastDiv& d_sout) {
   const bool ok = n_lane < a.ntot;
@@ -475,9 +477,7 @@ __device__ __forceinline__ int convb_epilogue_lean(const ConvBArgs& a, f32x16 (&
 #else
   constexpr unsigned kAll = 0x7fffffffu;
 #endif
-  const BufRsrc r_act = make_buf_rsrc(a.act.ptr, kAll);
-  const unsigned v_act = ok ? (unsigned)(view_base(a.act, img, sp) * 16) : kBufOob;
-  const unsigned cstep = (unsigned)(a.act.stride_c * 16);
+  const unsigned v_plain = ok ? (unsigned)(view_base(a.act, img, sp) * 16) : kBufOob;
   float4 ps[2][4], ph[2][4];
   auto load_params = [&](int i, int slot) {
 #pragma unroll
@@ -492,6 +492,29 @@ __device__ __forceinline__ int convb_epilogue_lean(const ConvBArgs& a, f32x16 (&
   for (int i = 0; i < TM; ++i) {
     if (i + 1 < TM) load_params(i + 1, (i + 1) & 1);
     const int mt = mw + i * 32;
+    // destination of this 32-row tile (wave-uniform): `act`, or a sibling's own tensor (as in convb_epilogue_wide)
+    void* aptr = a.act.ptr;
+    long astride_c = a.act.stride_c, astride_b = a.act.stride_b;
+    int cb0 = 0, relu = a.relu;
+    bool seg = false;
+    if (SEG && a.nseg > 0 && mt >= a.seg_begin[0]) {   // (SEG = false: the caller's launches never carry segments)
+      seg = true;
+      aptr = a.seg_act[0].ptr; astride_c = a.seg_act[0].stride_c; astride_b = a.seg_act[0].stride_b;
+      cb0 = a.seg_begin[0] / 8; relu = a.seg_relu[0];
+#pragma unroll
+      for (int q = 1; q < ECO_MAX_SEG; ++q) {
+        void* const qp = a.seg_act[q].ptr;
+        const long qc = a.seg_act[q].stride_c, qb = a.seg_act[q].stride_b;
+        const int qbeg = a.seg_begin[q], qr = a.seg_relu[q];
+        const bool take = q < a.nseg && mt >= qbeg;
+        aptr = take ? qp : aptr; astride_c = take ? qc : astride_c; astride_b = take ? qb : astride_b;
+        cb0 = take ? qbeg / 8 : cb0; relu = take ? qr : relu;
+      }
+    }
+    const float floor_ = relu ? 0.0f : -__builtin_inff();   // ReLU as max(y, 0); no ReLU as max(y, -inf): one instruction either way
+    const BufRsrc r_act = make_buf_rsrc(aptr, kAll);
+    const unsigned v_act = !seg ? v_plain : ok ? (unsigned)(((long)img * astride_b + sp) * 16) : kBufOob;
+    const unsigned cstep = (unsigned)(astride_c * 16);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int cbk = mt / 8 + g;
@@ -503,13 +526,13 @@ __device__ __forceinline__ int convb_epilogue_lean(const ConvBArgs& a, f32x16 (&
       for (int j = 0; j < 2; ++j) {
         float y[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) y[q] = fmaxf(fmaf(acc[i][j][4 * g + q], sc[q], sh[q]), 0.0f);
+        for (int q = 0; q < 4; ++q) y[q] = fmaxf(fmaf(acc[i][j][4 * g + q], sc[q], sh[q]), floor_);
         pact[j][0] = pack_bf16x2(y[0], y[1]);
         pact[j][1] = pack_bf16x2(y[2], y[3]);
       }
       permlane32_swap(pact[0][0], pact[1][0]);
       permlane32_swap(pact[0][1], pact[1][1]);
-      gst16_buf(r_act, rows ? v_act : kBufOob, (unsigned)cbk * cstep, make_uint4(pact[0][0], pact[0][1], pact[1][0], pact[1][1]));
+      gst16_buf(r_act, rows ? v_act : kBufOob, (unsigned)(cbk - cb0) * cstep, make_uint4(pact[0][0], pact[0][1], pact[1][0], pact[1][1]));
     }
   }
   return TM * 4;
@@ -833,7 +856,7 @@ __global__ __launch_bounds__(256, 2) void convb_dma_kernel(const ConvBArgs a, co
   const int m0 = mblk * BM, n0 = nblk * BN;
   constexpr int BMP_E = (BM + 63) / 64 * 64;
   __shared__ __attribute__((aligned(16))) float Ep[3 * BMP_E];   // bias / BN scale / BN shift of this workgroup's rows
-  convb_stage_params<BMP_E>(a, m0, Ep);
+  convb_stage_params<BMP_E>(a, m0, Ep, TN == 2 && a.lean != 0 && a.ksplit == 1);
 #ifndef ECO_EMU
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Ep's ds_writes retired before the first (non-draining) barrier
 #endif
@@ -953,6 +976,10 @@ __global__ __launch_bounds__(256, 2) void convb_dma_kernel(const ConvBArgs a, co
     convb_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
   } else {
     if constexpr (TN == 2) {   // 64-position wave tiles: whole 16-byte blocks per lane
+      if (a.lean) {   // (ksplit == 1 here: Ep carries the folded shift)
+        convb_epilogue_lean<TM, true>(a, acc, m0 + wm * TM * 32, m0, n0 + wn * 64 + lane, half, Ep, BMP_E, a.d_sout);
+        return;
+      }
       if (a.wide) {
         convb_epilogue_wide<TM>(a, acc, m0 + wm * TM * 32, m0, n0 + wn * 64 + lane, half, Ep, BMP_E, a.d_sout);
         return;
@@ -1242,7 +1269,6 @@ struct SpanPArgs {
   // sums + the reduce launch): a whole-tensor split-K is t_main = 0, a plain launch t_tail = 0, and a launch whose tile
   // count leaves a partial last round per CU splits just that remainder -- e.g. res4's 784 tiles on 256 CUs: 768 + 16 x 8
   int t_main, t_tail, kb, nitems;
-  int lean;                        // 1: whole tiles end in convb_epilogue_lean (act only, BN/bias + ReLU)
   FastDiv d_sout, d_hw, d_w, d_ks, d_kd, d_tail;
 };
 
@@ -1286,7 +1312,7 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
   const int m0 = mblk * BM;
   int item = L;                                    // item k of this workgroup = L + k * grid
   if (item >= pa.nitems) return;                   // (fewer items than workgroups: uniform exit, before any barrier)
-  convb_stage_params<BMP>(a, m0, Ep, pa.lean != 0);
+  convb_stage_params<BMP>(a, m0, Ep, a.lean != 0);
 #ifndef ECO_EMU
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Ep's ds_writes retired before the first (non-draining) barrier
 #endif
@@ -1481,6 +1507,7 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
 #endif
           newest = cnt;
           sched_fence();
+          if (g == cur.g_begin && t2 == 4) ECO_TS(28);   // DMA issued
           const uint4* Ab = Aw + abuf * kCbs * BMP + a_lane;
           const uint4* Bb = brow + xx;
           uint4 af[2][TM], bf[2][TN];
@@ -1499,6 +1526,7 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
 #endif
           };
           read_frags(0, 0);
+          if (g == cur.g_begin && t2 == 4) ECO_TS(29);   // first fragments landed (the stamp waits lgkmcnt(0))
 #pragma unroll
           for (int ks = 0; ks < kCbs / 2; ++ks) {
             if (ks + 1 < kCbs / 2) read_frags((ks + 1) & 1, ks + 1);
@@ -1524,6 +1552,7 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
 #endif
             sched_fence();
           }
+          if (g == cur.g_begin && t2 == 4) ECO_TS(30);   // MFMAs issued
         });
       }
       sbuf ^= 1;
@@ -1543,8 +1572,8 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
       if (a.ws_frag) stores = convb_store_partial_frag<TM>(a, acc, cur.slice, cur.tile, wave, lane, rws);   // (counted: stepped over)
       else convb_store_partial<TM, TN>(a, acc, cur.slice, m0, cur.n0 + wave * 64, half, l31);   // (compiler-counted stores: the next wait drains them)
     } else
-    if (pa.lean)
-      stores = convb_epilogue_lean<TM>(a, acc, m0, m0, cur.n0 + wave * 64 + lane, half, Ep, BMP, pa.d_sout);
+    if (a.lean)
+      stores = convb_epilogue_lean<TM, false>(a, acc, m0, m0, cur.n0 + wave * 64 + lane, half, Ep, BMP, pa.d_sout);
     else
 #ifdef ECO_SPANP_TS
       stores = convb_epilogue_wide<TM>(a, acc, m0, m0, cur.n0 + wave * 64 + lane, half, Ep, BMP, pa.d_sout,
@@ -2099,7 +2128,6 @@ static int launch_convb_spanp(const ConvBArgs& a, const eco_convb_plan* plan, hi
   pa.kb = a.ksplit > 1 ? a.ksplit : a.ws_slices > 1 ? plan->tail_ksplit : 1;
   pa.t_main = pa.ntiles - pa.t_tail;
   pa.nitems = pa.t_main + pa.t_tail * pa.kb;
-  pa.lean = (a.wide && a.act.ptr && !a.raw.ptr && !a.residual.ptr && !a.act2.ptr && a.nseg == 0 && a.relu) ? 1 : 0;
   pa.d_sout = fastdiv_make((unsigned)a.s_out);
   pa.d_hw = fastdiv_make((unsigned)(a.Hi * a.Wi));
   pa.d_w = fastdiv_make((unsigned)a.Wi);
@@ -2207,6 +2235,9 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
   bool views_fit = view_fits(ep->residual) && view_fits(ep->raw) && view_fits(ep->act) && view_fits(ep->act2);
   for (int sgi = 0; sgi < ep->nseg; ++sgi) views_fit = views_fit && view_fits(ep->seg_act[sgi]);
   a.wide = (ns == 1 && views_fit) ? 1 : 0;
+  {   // one destination per 32-row tile, bias + BN (+ ReLU per segment), nothing else: the lean epilogue
+    a.lean = (a.wide && a.act.ptr && !a.raw.ptr && !a.residual.ptr && !a.act2.ptr) ? 1 : 0;
+  }
   a.d_sout = fastdiv_make((unsigned)a.s_out);
   // whole-tensor split: the fragment layout when the epilogue it ends in is the 16-byte one, every instance of the
   // launched kernel has 64-position wave tiles (all bf16 ones) and the padded workspace fits plan and descriptor
@@ -2246,6 +2277,7 @@ extern "C" int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* p
                   "convb: plan needs a %ld-byte workspace", (long)plan->ws_bytes);
     }
     if (persistent) {
+      if (a.nseg > 0) a.lean = 0;   // (its lean epilogue is the segment-free instance)
       switch (plan->bm) {
         case 128: rc = launch_convb_spanp<4>(a, plan, s); break;
         case 96: rc = launch_convb_spanp<3>(a, plan, s); break;

@@ -233,6 +233,14 @@ def test_convb_span_kernel(backend, dt, n, cin, cout, in_sp, num_cu):
         assert plan.span_pieces == 0
 
 
+@pytest.mark.parametrize("case", [6, 7, 0, 2])
+@pytest.mark.parametrize("bn", [True, False], ids=["bn_relu", "bias_only"])
+def test_convb_single_destination(backend, case, bn):
+    """One destination and nothing else: the lean epilogue of the LDS-DMA kernel's 64-position wave tiles (cases 6, 7), with
+    ReLU (max(y, 0)) and without (max(y, -inf)); cases 0 and 2 take the general epilogue on the same arguments."""
+    run_convb(backend, BF16, *CONVS[case], seed=9, bn=bn, raw=False)
+
+
 @pytest.mark.parametrize("n,cin,cout,in_sp,num_cu", SPANS, ids=[f"s{i}" for i in range(len(SPANS))])
 def test_convb_span_kernel_single_destination(backend, n, cin, cout, in_sp, num_cu):
     """One destination, bias + BN + ReLU, no raw copy and no residual: the persistent kernel's lean epilogue

@@ -65,6 +65,7 @@ for name in sys.argv[1:] or list(CASES):
                 for tap in range(6):
                     line += f" t{tap}: wait {d(r[1 + 3 * tap])}->{d(r[2 + 3 * tap])} bar {d(r[3 + 3 * tap])} |"
                 line += f" next epi {d(r[19])}"
+                line += f" || tap4: bar {d(r[15])} dma {d(r[28])} frags {d(r[29])} mfma_issued {d(r[30])} next wait {d(r[16])}"
                 e = t[k - 1]
                 line += " || epilogue: " + " ".join(f"{(int(e[21 + q]) - int(e[19])) / 100:.1f}" for q in range(7) if e[21 + q])
                 print(line)
