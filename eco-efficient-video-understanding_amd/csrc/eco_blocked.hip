@@ -1995,6 +1995,18 @@ extern "C" int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t
     if (sp > 8) sp = 8;
     if (sp > plan->nstages / 4) sp = plan->nstages / 4;
     if (plan->span_pieces && sp > plan->nstages / 9) sp = plan->nstages / 9;   // the span kernel splits whole groups
+    if (plan->pgrid > 0 && sp >= 2) {
+      // persistent form: the slots walk ceil(tiles * s / slots) rounds of items, an item = ceil(groups / s) groups of nine
+      // taps + ~14 taps' worth of set-up and partial-sum stores, the reduce launch ~3 taps per slice.  res5 (196 tiles, 48
+      // groups, 512 slots): s = 2 -> 1 round x 230, s = 5 -> 2 x 104 (measured 0.199 -> 0.188 ms; 0.21 at 4, 0.19 at 6)
+      const long groups = plan->nstages / 9, smax = groups < 8 ? groups : 8;
+      long best = sp, best_cost = -1;
+      for (long c = 2; c <= smax; ++c) {
+        const long cost = ceil_div(tiles * c, (long)plan->pgrid) * (ceil_div(groups, c) * 9 + 14) + 3 * c;
+        if (best_cost < 0 || cost < best_cost) { best = c; best_cost = cost; }
+      }
+      sp = best;
+    }
     if (sp >= 2) {
       plan->ksplit = (int)sp;
       plan->ws_bytes = (int64_t)sp * tiles * bm * plan->bn * 4;   // whole tiles: the fragment layout of the partial sums
