@@ -114,6 +114,30 @@ __device__ __forceinline__ void glds16(const uint4* gptr, uint4* lds_wave_base) 
 // soffset takes part in the range check): zero padding is a per-lane select of kBufOob, no zero page, no second address.
 // num_records is 32-bit and kBufOob + soffset must not wrap: tensors above 2 GB stay on the glds16 kernels.
 constexpr unsigned kBufOob = 0x80000000u;
+// 16-byte loads through a raw buffer descriptor (wave-uniform base / size, per-lane byte offset).  Range check as the
+// hardware's (tools/ubench/bufld_check.hip, MI355X): per dword against num_records at the END of the range (a load that
+// runs over it returns its in-range dwords and zeros), on the 32-bit offset without wrap-around (a "negative" offset is
+// out of range as a whole, also the dwords that would land at 0 and above).  A compiler builtin: its vmcnt is tracked.
+#ifdef ECO_EMU
+struct BufRd { const char* base; unsigned bytes; };
+__device__ __forceinline__ BufRd make_buf_rd(const void* p, unsigned bytes) { return BufRd{(const char*)p, bytes}; }
+__device__ __forceinline__ uint4 gld16_buf(const BufRd& r, unsigned voff) {
+  unsigned q[4] = {0u, 0u, 0u, 0u};
+  for (int i = 0; i < 4; ++i)
+    if ((unsigned long long)voff + 4 * i + 4 <= r.bytes && emu::check_access(r.base + voff + 4 * i, 4, false)) memcpy(&q[i], r.base + voff + 4 * i, 4);
+  return make_uint4(q[0], q[1], q[2], q[3]);
+}
+#else
+typedef __amdgpu_buffer_rsrc_t BufRd;
+__device__ __forceinline__ BufRd make_buf_rd(const void* p, unsigned bytes) {   // (p, bytes: wave-uniform)
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 gld16_buf(const BufRd& r, unsigned voff) {
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+  const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+#endif
 #ifdef ECO_EMU
 struct BufRsrc { const char* base; unsigned bytes; };
 __device__ __forceinline__ BufRsrc make_buf_rsrc(const void* p, unsigned bytes) { return BufRsrc{(const char*)p, bytes}; }

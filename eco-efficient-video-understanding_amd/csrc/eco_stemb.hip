@@ -85,6 +85,20 @@ __device__ __forceinline__ uint4 lds_ld16_a4(const unsigned char* p) {
 #endif
 }
 
+#ifdef ECO_STEMB_TS   // probe builds (tools/exp/stemb_ts.py): cycle stamps of waves 0 and 3 of the first 64 workgroups
+__device__ unsigned long long eco_stemb_ts[64 * 2 * 8 * 16];
+extern "C" int eco_stemb_ts_read(void* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(eco_stemb_ts), sizeof(eco_stemb_ts));
+}
+#define ECO_SBTS(slot)                                                                                             \
+  do {                                                                                                             \
+    if ((wave == 0 || wave == 3) && ts_item < 8 && lane == 0)                                                      \
+      ts_l[((wave ? 1 : 0) * 8 + ts_item) * 16 + (slot)] = __builtin_readcyclecounter();                           \
+  } while (0)
+#else
+#define ECO_SBTS(slot) do { } while (0)
+#endif
+
 // TMC = cout / 32 (1 or 2 m-tiles; every wave holds all channels of its 128 columns)
 template <int TMC>
 __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
   constexpr int XS_BYTES = kSbRows * kSbRowBytes;          // 14976
   constexpr int W_VECS = kSbSteps * 2 * COUT;              // 16-byte vectors of packed weights
   constexpr int STAGE_LD = kSbNPos + 3;                    // 496: staging row of one channel
-  constexpr int XU = (kSbRows + 3) / 4, WU = (W_VECS + 255) / 256;
+  constexpr int XU4 = (kSbRows + 15) / 16, WU = (W_VECS + 255) / 256;
   ECO_DYNAMIC_LDS(lds);
   unsigned char* const Xs = (unsigned char*)lds;           // bf16 [3][39][64]
   uint4* const Ws = (uint4*)(Xs + XS_BYTES);               // [11][2][COUT], resident for the workgroup's lifetime
@@ -104,6 +118,11 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
   const int wave = uniform(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int tpf = a.tiles_h * a.tiles_w;
+#ifdef ECO_STEMB_TS
+  __shared__ unsigned long long ts_l[2 * 8 * 16];
+  int ts_item = 0;
+  for (int q = tid; q < 2 * 8 * 16; q += 256) ts_l[q] = 0ull;
+#endif
 
 #pragma unroll
   for (int u = 0; u < WU; ++u) {
@@ -119,31 +138,60 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
 
   // A wave takes whole patch rows (lane = column): the row arithmetic is scalar, a lane's address is base + lane,
   // and every load is in flight before the first one is waited for.
-  float xv[XU];
+  // A patch row is 64 columns: sixteen lanes take four columns each (one 16-byte load, 4-byte aligned: the patch starts
+  // three columns left of a multiple of four), a wave four rows per instruction, the workgroup sixteen -- eight loads and
+  // eight 8-byte LDS stores per thread and patch.  One column per lane (thirty 4-byte loads and thirty ds_write_b16 per
+  // thread) cost ~230 cycles per load instruction wherever it was placed in the patch's schedule -- 6-9 k of a patch's
+  // 26 k cycles (round-4 cycle stamps, tools/exp/stemb_ts.py): the address path takes a wave-instruction at a time, 256
+  // bytes or 1 KB alike.  The loads go through a buffer descriptor over the frame (no branches: a load inside a divergent
+  // branch is waited for on the spot, eight memory latencies in a row): rows outside the image take an out-of-range
+  // offset and read zeros, columns outside it are zeroed by a per-patch lane mask (the four columns of a lane straddle
+  // the border at column 0 and at column W only); the one load that would start before the frame (channel 0, row 0,
+  // columns -3..0) is moved three columns right and its first element handed to column 0.
+  uint4 xv[XU4];          // as loaded: the masks below are applied when the patch is stored, a patch period later -- a select
+  unsigned xmask = 0u;    // next to the load would wait for the load (bits 0-3: columns inside the image; 4 + u: `before`)
+  const int lrow = 4 * wave + (lane >> 4), lcol = 4 * (lane & 15);
   auto load_patch = [&](int patch) {
     const int f = patch / tpf, t = patch - f * tpf;
     const int by = t / a.tiles_w, bx = t - by * a.tiles_w;
-    const int ih0 = 4 * kSbPH * by - 3, iw0 = 4 * kSbPW * bx - 3;     // first input row / column
-    const float* xf = a.x + (long)f * 3 * a.H * a.W;
-    const int w = iw0 + lane;
-    const bool wok = (unsigned)w < (unsigned)a.W;
+    const int ih0 = 4 * kSbPH * by - 3;                     // first input row / column
+    const BufRd rx = make_buf_rd(a.x + (long)f * 3 * a.H * a.W, (unsigned)(3 * a.H * a.W) * 4u);
+    const int w = 4 * kSbPW * bx - 3 + lcol;
+    const bool m0 = (unsigned)w < (unsigned)a.W, m1 = (unsigned)(w + 1) < (unsigned)a.W,
+               m2 = (unsigned)(w + 2) < (unsigned)a.W, m3 = (unsigned)(w + 3) < (unsigned)a.W;
+    unsigned mk = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);
+    int lr = lrow;
+    ECO_OPAQUE(lr);   // (per patch: hoisted out of the patch loop, the eight rows' channel / row terms were spilled, and a spill
+                      // reload between two loads waits for every load before it -- the memory counter retires in order)
 #pragma unroll
-    for (int u = 0; u < XU; ++u) {
-      const int row = wave + 4 * u;                        // (c, rr), wave-uniform
-      const int c = row / kSbIR, h = ih0 + row - c * kSbIR;
-      const bool ok = wok && row < kSbRows && (unsigned)h < (unsigned)a.H;
+    for (int u = 0; u < XU4; ++u) {
+      const int row = 16 * u + lr;                         // (c, rr)
+      const int c = (row >= kSbIR) + (row >= 2 * kSbIR), h = ih0 + row - c * kSbIR;
+      const bool rok = row < kSbRows && (unsigned)h < (unsigned)a.H;
+      const int e = (c * a.H + h) * a.W + w;               // element of the frame (one frame is below 2^29 elements)
+      const bool before = rok && e < 0;                    // (c = 0, h = 0, w = -3: only column 0 exists)
+      const unsigned voff = !rok ? kBufOob : (unsigned)(before ? e + 3 : e) * 4u;
+      mk |= before ? 16u << u : 0u;
 #if defined(ECO_STEMB_PROBE) && (ECO_STEMB_PROBE & 8)    // bit 3: no global loads of the frames
-      xv[u] = ok ? (float)row : 0.0f;
+      xv[u] = make_uint4(voff, 1u, 2u, 3u);
 #else
-      xv[u] = ok ? ld(xf + ((long)c * a.H + h) * a.W + w) : 0.0f;
+      xv[u] = gld16_buf(rx, voff);
 #endif
     }
+    xmask = mk;
   };
   auto store_patch = [&]() {
-    unsigned short* const xs = (unsigned short*)Xs;
+    uint2* const xs = (uint2*)Xs;                          // a row = sixteen 8-byte units
+    const unsigned mk = xmask;
 #pragma unroll
-    for (int u = 0; u < XU; ++u)
-      if (wave + 4 * u < kSbRows) xs[(wave + 4 * u) * kSbIQ + lane] = (unsigned short)f32_to_bf16_bits(xv[u]);
+    for (int u = 0; u < XU4; ++u)
+      if (16 * u + lrow < kSbRows) {
+        const uint4 q = xv[u];
+        const float v0 = (mk & 1u) ? __builtin_bit_cast(float, q.x) : 0.0f, v1 = (mk & 2u) ? __builtin_bit_cast(float, q.y) : 0.0f,
+                    v2 = (mk & 4u) ? __builtin_bit_cast(float, q.z) : 0.0f,
+                    v3 = (mk & 8u) ? __builtin_bit_cast(float, (mk & (16u << u)) ? q.x : q.w) : 0.0f;
+        xs[(16 * u + lrow) * (kSbIQ / 4) + (lane & 15)] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
   };
 
   // ---- this lane's four position columns: conv position p = wave*128 + j*32 + l31 -> patch byte 2r*128 + 4q ----
@@ -175,10 +223,17 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
   load_patch(patch);
   store_patch();
   if (patch + (int)gridDim.x < a.total) load_patch(patch + (int)gridDim.x);
+#if !defined(ECO_EMU) && !defined(ECO_STEMB_NOSTAGGER)
+  // Workgroups that start together stay in step: every CU fetched its next patch in the same ~7 k cycles of a 24 k-cycle
+  // patch period -- 16 MB asked of HBM at once, every wave waiting at its load instructions, the memory idle for the rest
+  // (round-4 cycle stamps).  The eight XCDs start their patch loops an eighth of a period apart instead.
+  for (int q = (int)(blockIdx.x & 7u); q > 0; --q) __builtin_amdgcn_s_sleep(47);   // ~3 k cycles a step
+#endif
   __syncthreads();
 
   while (true) {
     const int next = patch + (int)gridDim.x;               // its words are in flight (or landed) in xv
+    ECO_SBTS(0);
 
     f32x16 acc[TMC][4];
 #pragma unroll
@@ -223,14 +278,23 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
       sched_fence();
     });
 #endif
+    ECO_SBTS(1);
     __syncthreads();   // every wave is done with Xs: the next patch may land
+    ECO_SBTS(2);
     if (next < a.total) {
+#ifdef ECO_STEMB_TS
+#pragma unroll
+      for (int u = 0; u < XU4; ++u) asm volatile("" ::"v"(xv[u].x), "v"(xv[u].y), "v"(xv[u].z), "v"(xv[u].w));   // the loads' wait, on its own
+      ECO_SBTS(13);
+#endif
       store_patch();
-      // the patch after it: its loads have the whole epilogue below and the next reduction to land (xv is free until
-      // then: no register cost at the reduction's peak, where xv is live anyway)
-      if (next + (int)gridDim.x < a.total) load_patch(next + (int)gridDim.x);
+      ECO_SBTS(14);
     }
+    // the patch after it: its loads have the whole epilogue below and the next reduction to land (xv is live across the
+    // reduction either way)
+    if (next < a.total && next + (int)gridDim.x < a.total) load_patch(next + (int)gridDim.x);
 
+    ECO_SBTS(3);
     // ---- per 16 channels: bias / BN on the accumulators into the stage, 3x3 stride-2 max over it, ReLU, pooled store.
     // A thread's nine window offsets are fixed per patch (taps outside the conv image -- the MAX window is clipped to
     // it, pooling_layer.cpp:207-212 -- re-read tap (0,0), which a stored output always has). ----
@@ -255,8 +319,9 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
       for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
     if (a.total >= 0) { if (next >= a.total) break; patch = next; continue; }
 #endif
-#pragma unroll
-    for (int i = 0; i < TMC; ++i) {
+    ECO_SBTS(4);
+    static_for<TMC>([&](auto I) __attribute__((always_inline)) {
+      constexpr int i = decltype(I)::value;
 #pragma unroll
       for (int rp = 0; rp < 8; ++rp) {                     // accumulator registers 2rp, 2rp + 1: two consecutive channels
         const int row = (rp & 1) + 4 * (rp >> 1);          // + 2*half: this lane's pair row within the 16
@@ -267,7 +332,9 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
           if (j < 3 || last_col_ok)
             sw0[row * STAGE_LD + soff[j]] = pack_bf16x2(acc[i][j][2 * rp] * sc.x + sh2.x, acc[i][j][2 * rp + 1] * sc.y + sh2.y);
       }
+      ECO_SBTS(5 + 4 * i);
       __syncthreads();
+      ECO_SBTS(6 + 4 * i);
 #if defined(ECO_STEMB_PROBE) && (ECO_STEMB_PROBE & 4)    // bit 2: stage written, no pooling / stores
       if (a.total < 0)
 #endif
@@ -294,11 +361,21 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
           st(yp0 + (4 * i + 2 * it) * yblk, make_uint4(o[0], o[1], o[2], o[3]));
         }
       }
+      ECO_SBTS(7 + 4 * i);
       __syncthreads();
-    }
+      ECO_SBTS(8 + 4 * i);
+    });
+#ifdef ECO_STEMB_TS
+    ++ts_item;
+#endif
     if (next >= a.total) break;
     patch = next;
   }
+#ifdef ECO_STEMB_TS
+  __syncthreads();
+  if (blockIdx.x < 64)
+    for (int q = tid; q < 2 * 8 * 16; q += 256) eco_stemb_ts[blockIdx.x * (2 * 8 * 16) + q] = ts_l[q];
+#endif
 }
 
 }  // namespace eco
