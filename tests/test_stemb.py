@@ -24,7 +24,7 @@ def _reference(x, w, b, sc, sh, bn, relu):
 
 # max_wg: cap on the persistent workgroups (0 = two per CU); small caps make one workgroup walk several patches
 @pytest.mark.parametrize("n,H,W,cout,bn,relu,max_wg", [(2, 64, 64, 64, True, 1, 0), (2, 64, 64, 64, True, 1, 3),
-                                                       (1, 75, 52, 32, True, 0, 1), (3, 40, 36, 64, False, 1, 2),
+                                                       (1, 75, 52, 32, True, 0, 1), (3, 40, 36, 64, False, 1, 2), (2, 41, 50, 32, True, 1, 2), (1, 37, 43, 64, True, 0, 0),
                                                        (1, 224, 224, 64, True, 1, 0), (2, 224, 224, 64, True, 1, 5)])
 def test_stemb_matches_layer_sequence(backend, n, H, W, cout, bn, relu, max_wg):
     if H == 224 and backend.kind == "emu":
