@@ -1728,6 +1728,33 @@ __global__ __launch_bounds__(256) void poolb_k3_kernel(const PoolBArgs a) {
         ok[dh][dw] = (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi;
         v[dh][dw] = load_block<NS>(a.x, xb + (ok[dh][dw] ? (long)h * a.Wi + w : 0l));
       }
+    if constexpr (NS == 1 && METHOD == ECO_POOL_MAX) {
+      // bf16 MAX without leaving bf16: x -> x ^ ((x >> 15) & 0x7fff) (arithmetic shift per 16-bit half) maps the
+      // sign-magnitude patterns onto two's-complement order and is its own inverse, so the window is eight packed signed
+      // 16-bit maxima per dword (v_pk_max_i16) -- five VALU instructions per loaded dword where unpacking two values to
+      // fp32, two v_max and the in-image selects took eight, and no conversion back.  The maximum of bf16 values is one of
+      // them: bit-identical to the fp32 route.
+      typedef short s16x2 __attribute__((ext_vector_type(2)));
+      auto key = [](unsigned x) {
+        const s16x2 q = __builtin_bit_cast(s16x2, x);
+        return __builtin_bit_cast(s16x2, x ^ (__builtin_bit_cast(unsigned, q >> 15) & 0x7fff7fffu));
+      };
+      const s16x2 lowest = {(short)-32768, (short)-32768};
+      s16x2 m[4] = {lowest, lowest, lowest, lowest};
+#pragma unroll
+      for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) {
+          const unsigned q[4] = {v[dh][dw].v.x, v[dh][dw].v.y, v[dh][dw].v.z, v[dh][dw].v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m[e] = __builtin_elementwise_max(m[e], ok[dh][dw] ? key(q[e]) : lowest);
+        }
+      unsigned o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = __builtin_bit_cast(unsigned, key(__builtin_bit_cast(unsigned, m[e])));
+      st((uint4*)a.y + i, make_uint4(o[0], o[1], o[2], o[3]));
+      continue;
+    }
     float r[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] = METHOD == ECO_POOL_MAX ? -FLT_MAX : 0.0f;
