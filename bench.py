@@ -207,6 +207,7 @@ def main() -> None:
 
     # ---- roofline: per-launch HIP-event times on the launch stream ----
     peak_mfma = PEAK_MFMA_TFLOPS[args.dtype]
+    workload_key = f"{args.variant}/{args.segments}/{B}/{args.dtype}"   # as tools/summarize_profiles.py names its PMC passes
     prof = net._engine.profile(args.profile_iters)
     # grouped by kernel FAMILY (the template name without its arguments), each family listing its instances: the choice of
     # the "dominant" kernel must not depend on whether a launch site spells out its template arguments
@@ -244,17 +245,26 @@ def main() -> None:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")) as f:
             tr = json.load(f)
         src_now = hip.load().source_digest()
-        rows = {k: v for k, v in tr["kernels"].items() if k.split("<")[0] == dom_name}
-        if tr.get("src_sha256") is None or tr.get("src_sha256") != src_now:
+        # traffic per launch belongs to the launch size it was counted on: only the PMC passes of THIS workload qualify
+        if workload_key == tr.get("workload", "lite/16/32/f32"):
+            tk, tsrc = tr["kernels"], tr["source"]
+        elif workload_key in tr.get("workloads", {}):
+            tk, tsrc = tr["workloads"][workload_key]["kernels"], tr["workloads"][workload_key]["source"]
+        else:
+            tk, tsrc = None, None
+        rows = {k: v for k, v in (tk or {}).items() if k.split("<")[0] == dom_name}
+        if tk is None:
+            roofline["traffic_unit"] = f"null: no PMC passes of workload {workload_key} in profiles/hbm_traffic_latest.json"
+        elif tr.get("src_sha256") is None or tr.get("src_sha256") != src_now:
             roofline["traffic_unit"] = ("null: profiles/hbm_traffic_latest.json was collected on a build of other sources "
                                         f"({str(tr.get('src_sha256'))[:12]} != {src_now[:12]}); re-run tools/profile_round.sh")
         elif rows:
             # launch-weighted mean over the family's instances (PMC rows carry their launch counts)
             w = sum(c.get("launches", 1) for c in rows.values())
             roofline["traffic"] = round(sum(c["hbm_bytes_per_launch"] * c.get("launches", 1) for c in rows.values()) / w / 1e9, 4)
-            roofline["traffic_unit"] = "GB per launch (PMC, " + tr["source"] + ", same sources " + src_now[:12] + ")"
+            roofline["traffic_unit"] = "GB per launch (PMC, " + tsrc + ", same sources " + src_now[:12] + ")"
         else:
-            roofline["traffic_unit"] = f"null: no PMC row for {dom_name} in {tr['source']}"
+            roofline["traffic_unit"] = f"null: no PMC row for {dom_name} in {tsrc}"
     except Exception as e:  # no summary committed, unreadable file, ...
         roofline["traffic_unit"] = f"null: {type(e).__name__}: {e}"
     executed = sum(p["flops"] for p in prof)

@@ -51,6 +51,17 @@ def main():
             with open(p) as fi, open(os.path.join(out_dir, f"{tag}_{nm}"), "w") as fo:
                 fo.write("".join(l for l in fi if "amdgpu.ids" not in l))
     summary = summarize_traffic(src, "", os.path.join(out_dir, f"{tag}_pmc_hbm_traffic.csv"), "python bench.py")
+    # the other profiled workloads (bench.py's key: variant/segments/clips per GPU/dtype): traffic per launch belongs to the
+    # launch SIZE it was counted on -- a bench line of another workload gets null, not these figures
+    others = {}
+    if os.path.exists(os.path.join(src, "pmc_fetch_bf16")):
+        others["lite/32/32/bf16"] = {"source": f"profiles/{tag}_bf16_pmc_hbm_traffic.csv",
+                                     "kernels": summarize_traffic(src, "_bf16", os.path.join(out_dir, f"{tag}_bf16_pmc_hbm_traffic.csv"),
+                                                                  "python bench.py --segments 32 --dtype bf16")}
+    if os.path.exists(os.path.join(src, "pmc_fetch_full")):
+        others["full/16/32/f32"] = {"source": f"profiles/{tag}_full_pmc_hbm_traffic.csv",
+                                    "kernels": summarize_traffic(src, "_full", os.path.join(out_dir, f"{tag}_full_pmc_hbm_traffic.csv"),
+                                                                 "python bench.py --variant full")}
     sha = os.path.join(src, "src.sha256")
     with open(os.path.join(out_dir, "hbm_traffic_latest.json"), "w") as f:
         json.dump({"source": f"profiles/{tag}_pmc_hbm_traffic.csv",
@@ -58,20 +69,16 @@ def main():
                    # `roofline.traffic` while the running library reports the same digest -- a rebuild of identical
                    # sources keeps the field, an edited kernel drops it
                    "src_sha256": open(sha).read().strip().splitlines()[-1] if os.path.exists(sha) else None,
-                   "kernels": summary}, f, indent=1)
+                   "workload": "lite/16/32/f32",
+                   "kernels": summary, "workloads": others}, f, indent=1)
     sq = os.path.join(src, "pmc_sq", "bench_counter_collection.csv")
     if os.path.exists(sq):
         summarize_sq(sq, os.path.join(out_dir, f"{tag}_pmc_sq.csv"))
-    # configs[4] (bf16, N=32): the same three counter passes
-    if os.path.exists(os.path.join(src, "pmc_fetch_bf16")):
-        summarize_traffic(src, "_bf16", os.path.join(out_dir, f"{tag}_bf16_pmc_hbm_traffic.csv"),
-                          "python bench.py --segments 32 --dtype bf16")
+    # configs[4] (bf16, N=32): the same three counter passes (traffic: above)
     sqb = os.path.join(src, "pmc_sq_bf16", "bench_counter_collection.csv")
     if os.path.exists(sqb):
         summarize_sq(sqb, os.path.join(out_dir, f"{tag}_bf16_pmc_sq.csv"), "python bench.py --segments 32 --dtype bf16")
     # configs[3] (ECO-Full)
-    if os.path.exists(os.path.join(src, "pmc_fetch_full")):
-        summarize_traffic(src, "_full", os.path.join(out_dir, f"{tag}_full_pmc_hbm_traffic.csv"), "python bench.py --variant full")
     sqf = os.path.join(src, "pmc_sq_full", "bench_counter_collection.csv")
     if os.path.exists(sqf):
         summarize_sq(sqf, os.path.join(out_dir, f"{tag}_full_pmc_sq.csv"), "python bench.py --variant full")
