@@ -11,7 +11,7 @@ from eco_amd import hip
 lib = hip.load()
 raw = ctypes.CDLL(hip.LIB_PATH)
 CASES = {"conv2_3x3": (1024, 64, 192, (56, 56), (3, 3), (1, 1), (1, 1)),
-         "res3b_1": (32, 128, 128, (16, 28, 28), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+         "res3b_1": (32, 128, 128, (32, 28, 28), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
          "inc3a_3x3": (1024, 64, 64, (28, 28), (3, 3), (1, 1), (1, 1))}
 NUM_CU = int(os.environ.get("TS_NUM_CU", "0")) or None
 for name in sys.argv[1:] or list(CASES):
@@ -25,7 +25,12 @@ for name in sys.argv[1:] or list(CASES):
     wp = np.zeros(plan.wp_vecs * 8, np.uint16)
     lib.convb_pack_weights(g, plan, w.ctypes.data, wp.ctypes.data)
     wpd = torch.from_numpy(wp.view(np.int16)).cuda()
-    x = torch.randn(n * cin * S, device="cuda").to(torch.bfloat16)
+    x = torch.randn(n * cin * S, device="cuda")
+    if os.environ.get("TS_RELU"):
+        x = torch.relu(x)        # half zeros, as behind a ReLU: the clock the power limit holds is higher
+    if os.environ.get("TS_ZERO"):
+        x = torch.zeros_like(x)  # no toggling in the operands: what the clock does without the matrix pipes' switching power
+    x = x.to(torch.bfloat16)
     y = torch.empty(n * cout * S, device="cuda", dtype=torch.bfloat16)
     b = torch.zeros(cout, device="cuda"); sc = torch.ones(cout, device="cuda"); sh = torch.zeros(cout, device="cuda")
     ep = hip.ConvEpilogue()
@@ -47,9 +52,9 @@ for name in sys.argv[1:] or list(CASES):
     b0 = ts[:, 0]                       # wave 0 of every recorded block
     first = b0[:, 0, 1]
     last = np.array([max(int(b0[q, k, 20]) for k in range(8) if b0[q, k, 20] >= b0[q, 0, 1]) for q in range(64)])
-    print('   first', first[:4], 'last', last[:4])
     span = int(last.max() - first[first > 0].min())
     us = e0.elapsed_time(e1) * 1e3
+    print(f"   block 0: first tap wait -> last epilogue end {int(last[0] - first[0])} ticks over a {us:.1f} us launch = {(last[0] - first[0]) / us / 1e3:.2f} ticks / ns")
     print(f"   first tap wait -> last epilogue end over the 64 recorded blocks: {span / 1e3:.1f} k ticks; launch {us:.1f} us -> >= {span / us:.0f} ticks/us")
     for blk in (0, 9):
         for wv in (0,):
