@@ -31,6 +31,8 @@
 #include <string.h>
 
 #define ECO_GLDS_READFIRSTLANE 1   // see eco_device.h, glds16
+#include <atomic>
+
 #include "eco_common.h"
 
 namespace eco {
@@ -829,6 +831,7 @@ __global__ __launch_bounds__(256, 2) void convb_kernel(const ConvBArgs a) {
 // ds_read of each stage).
 template <int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void convb_dma_kernel(const ConvBArgs a, const uint4* zero_page) {
+  ECO_CLOCK("dma");
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int BMP = (BM + 63) / 64 * 64;   // weight rows staged per block (whole 64-lane pieces)
@@ -1269,11 +1272,15 @@ struct SpanPArgs {
   // sums + the reduce launch): a whole-tensor split-K is t_main = 0, a plain launch t_tail = 0, and a launch whose tile
   // count leaves a partial last round per CU splits just that remainder -- e.g. res4's 784 tiles on 256 CUs: 768 + 16 x 8
   int t_main, t_tail, kb, nitems;
+  // Dynamic items (null: item k of a workgroup = L + k * grid): ctr[m] = tickets handed out for M-block m, ctr[4] =
+  // workgroups that have left; zero before the launch, zeroed again by the last workgroup to leave.
+  unsigned* ctr;
   FastDiv d_sout, d_hw, d_w, d_ks, d_kd, d_tail;
 };
 
 template <int TM>
 __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, const SpanPArgs pa, int span_pieces) {
+  ECO_CLOCK("spanp");
   constexpr int TN = 2;
   constexpr int BM = 32 * TM, BN = 256;
   constexpr int BMP = (BM + 63) / 64 * 64;
@@ -1310,8 +1317,27 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
   const int L = ((bx / (8 * a.nblk_m)) * 8 + bx % 8) * a.nblk_m + (bx / 8) % a.nblk_m;
   const int mblk = L % a.nblk_m;                   // (grid and ntiles are multiples of nblk_m: every item of L has this M-block)
   const int m0 = mblk * BM;
-  int item = L;                                    // item k of this workgroup = L + k * grid
-  if (item >= pa.nitems) return;                   // (fewer items than workgroups: uniform exit, before any barrier)
+  // The first item of a workgroup is L.  After it: item k = L + k * grid (pa.ctr null), or the next item of this
+  // M-block nobody has taken yet -- id (grid / nblk_m + ticket) * nblk_m + mblk, tickets from pa.ctr[mblk].  The two
+  // workgroups of a CU (blocks b and b + grid/2) share its SIMDs wave for wave and the instruction arbiter prefers the
+  // older wave: with equal shares the first-dispatched workgroup ran its items at the speed of a lone wave and its partner
+  // on what was left (res3b_1: 6.25 items in 424 us against 6.0 in 538 us, the last 114 us alone; res4: two items against
+  // one -- tools/exp/clock_probe2.sh).  Taking items as they come, both finish together, and a K-split tail's short items
+  // go last by themselves.
+  int item = L;
+  const bool dynamic = pa.ctr != nullptr;
+  auto leave = [&]() {     // (one lane) count this workgroup out; the last one out clears the launch's counters
+    if (dynamic && tid == 0) {
+      const unsigned gone = counter_fetch_add(pa.ctr + 4, 1u);
+      if (gone == (unsigned)grid - 1u) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) counter_store(pa.ctr + q, 0u);
+      }
+    }
+  };
+  if (item >= pa.nitems) { leave(); return; }      // (fewer items than workgroups: uniform exit, before any barrier)
+  __shared__ int next_id[1];                       // id of the item after this one (written by thread 0)
+  const int id0 = (grid / a.nblk_m) * a.nblk_m + mblk;   // ticket 0's id
   convb_stage_params<BMP>(a, m0, Ep, a.lean != 0);
 #ifndef ECO_EMU
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Ep's ds_writes retired before the first (non-draining) barrier
@@ -1443,11 +1469,20 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
   int newest = APW;          // pieces issued after the ones the next tap needs
   int stores = 0;            // store instructions of the previous item's epilogue, still in front of the next wait
   int sbuf = 0;
+#if defined(ECO_SPANP_PRIO) && !defined(ECO_EMU)
+  // The two workgroups of a CU (blocks b and b + grid/2) share its SIMDs wave for wave, and the instruction arbiter
+  // prefers the older wave: the first-dispatched workgroup ran its items at the speed of a lone wave (res3b_1: 6.25 items in
+  // 424 us) and the other one on what was left (6.0 items in 538 us, the last 114 us alone -- tools/exp/clock_probe2.sh).
+  // They take the higher wave priority in turns, tap by tap (item by item left the workgroup with more items on the low
+  // turn while its partner was still there: res4 +10 %).
+  const int prio_half = bx >= grid / 2 ? 1 : 0;
+#endif
 
   for (;;) {
-    // the item after this one (uniform)
-    const int nitem = item + grid;
-    const bool have_next_item = nitem < pa.nitems;
+    // the item after this one (uniform): by arithmetic, or -- dynamic -- read from next_id behind the first barrier of this
+    // item's last group (wave 0 draws and publishes it ahead of that barrier)
+    int nitem = item + grid;
+    bool have_next_item = nitem < pa.nitems;
     Item nxt = cur;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1462,7 +1497,7 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
       bool have_next = true;
       int ncg = cg, nz = z + 1;
       if (nz == a.kd) { nz = 0; ++ncg; }
-      if (last_group) {
+      auto resolve_next = [&]() {                      // the next item's lane state and first (channel group, depth tap)
         have_next = have_next_item;
         if (have_next_item) {
 #if !(ECO_SPANP_PROBE & 64)      // bit 6 = no per-item index arithmetic (the first item's lane state is reused: wrong results)
@@ -1471,10 +1506,12 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
           ncg = (int)fastdiv((unsigned)nxt.g_begin, pa.d_kd);
           nz = nxt.g_begin - ncg * a.kd;
         }
-      }
-      const unsigned nsv0 = last_group ? nxt.spv[0] : cur.spv[0], nsv1 = last_group ? nxt.spv[1] : cur.spv[1];
-      const int nsd0 = last_group ? nxt.spd[0] : cur.spd[0], nsd1 = last_group ? nxt.spd[1] : cur.spd[1];
-      const int stage0 = cg * a.taps + z * T2, nstage0 = ncg * a.taps + nz * T2;
+      };
+      if (last_group && !dynamic) resolve_next();
+      unsigned nsv0 = last_group ? nxt.spv[0] : cur.spv[0], nsv1 = last_group ? nxt.spv[1] : cur.spv[1];
+      int nsd0 = last_group ? nxt.spd[0] : cur.spd[0], nsd1 = last_group ? nxt.spd[1] : cur.spd[1];
+      const int stage0 = cg * a.taps + z * T2;
+      int nstage0 = ncg * a.taps + nz * T2;
       // three kernel rows, the three taps of a row unrolled (ring slot = column because 3 % NB == 0): compile-time LDS
       // immediates without nine copies of the body competing for registers
 #pragma unroll 1
@@ -1487,14 +1524,42 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
           constexpr int xx = decltype(xc)::value;
           constexpr int abuf = xx;                     // t2 % NB with t2 = 3y + xx
           const int t2 = 3 * y + xx;
+#if defined(ECO_SPANP_PRIO) && !defined(ECO_EMU)
+          if ((xx ^ y ^ prio_half) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
           if (g == cur.g_begin && t2 < 6) ECO_TS(1 + 3 * t2);
           if (stores) { wait_newest_behind_stores(newest, stores); stores = 0; }
           else wait_newest(newest);
           if (g == cur.g_begin && t2 < 6) ECO_TS(2 + 3 * t2);
+          // Dynamic items: the next item's ticket is drawn here, at the first tap of this item's last group -- the last moment
+          // that keeps the next item's span and first weights in flight under this group -- by wave 0 on the scalar unit
+          // (s_atomic_add: ~600 cycles, nothing in the vector memory counter; the other waves meet it at the barrier below).
+          // Drawn an item ahead, every workgroup had reserved its second item before any work was done and res4 (1.5 items
+          // per workgroup) ran 28 % slower than with static shares; the compiler's own returning atomic is waited for with
+          // vmcnt(0) where it is issued.
+          if (xx == 0 && y == 0 && last_group && dynamic && wave == 0) {
+#ifdef ECO_EMU
+            if (tid == 0)
+#endif
+            {
+              const unsigned ticket = counter_draw_wave(pa.ctr + mblk);
+              if (lane == 0) next_id[0] = id0 + (int)ticket * a.nblk_m;
+            }
+#ifndef ECO_EMU
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // written before the (non-draining) barrier below
+#endif
+          }
 #if !(ECO_SPANP_PROBE & 1)      // probe builds (tools/exp): bit 0 = no barrier per tap
           wg_barrier_nodrain();
 #endif
           if (g == cur.g_begin && t2 < 6) ECO_TS(3 + 3 * t2);
+          if (xx == 0 && y == 0 && last_group && dynamic) {   // behind this barrier thread 0's next_id[0] is visible
+            nitem = uniform(next_id[0]);
+            have_next_item = nitem < pa.nitems;
+            resolve_next();
+            nsv0 = nxt.spv[0]; nsv1 = nxt.spv[1]; nsd0 = nxt.spd[0]; nsd1 = nxt.spd[1];
+            nstage0 = ncg * a.taps + nz * T2;
+          }
           int cnt = 0;
 #if ECO_SPANP_PROBE & 2         // bit 1 = no operand DMA after the prologue
           if (a.ntot < 0) {
@@ -1589,6 +1654,7 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
     cur = nxt;
     item = nitem;
   }
+  leave();
 #ifdef ECO_SPANP_TS
   __syncthreads();
   if (bx < 64)
@@ -2061,6 +2127,17 @@ extern "C" int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t
       (void)tail_pos;
     }
   }
+#ifdef ECO_CONVB_KSPLIT_ENV   // experiment builds only (tools/exp): the K-split tail as "tiles,slices" from the environment
+  if (plan->span_pieces && plan->pgrid > 0 && plan->ksplit == 1 && getenv("ECO_CONVB_TAIL")) {
+    long r = 0, kb = 1;
+    if (sscanf(getenv("ECO_CONVB_TAIL"), "%ld,%ld", &r, &kb) == 2 && r > 0 && r < tiles && kb >= 2 && kb <= 8 &&
+        kb <= plan->nstages / 9 && r % ceil_div(g->cout, bm) == 0 && tiles > plan->pgrid) {
+      plan->tail_tiles = (int)r;
+      plan->tail_ksplit = (int)kb;
+      plan->ws_bytes = (int64_t)kb * r * bm * plan->bn * 4;
+    }
+  }
+#endif
 #ifdef ECO_CONVB_KSPLIT_ENV   // experiment builds only (tools/exp): split-K factor of span plans from the environment
   if (plan->span_pieces && getenv("ECO_CONVB_KSPLIT")) {
     long sp = atol(getenv("ECO_CONVB_KSPLIT"));
@@ -2149,6 +2226,35 @@ static int launch_convb_span(const ConvBArgs& a, int span_pieces, hipStream_t st
   return check_launch("eco_convb_forward");
 }
 
+// Work counters of the persistent kernel's dynamic item distribution: 256 launches' worth (a launch takes the next slot;
+// its last workgroup clears it again), zero at module load.  A launch sequence number picks the slot, so launches in
+// flight on different streams use different slots; a captured graph keeps the slots it was captured with.
+#ifdef ECO_EMU
+static unsigned eco_spanp_counters[256 * 8];
+static unsigned* spanp_counter_slot() {
+  static std::atomic<unsigned> seq{0};
+  return eco_spanp_counters + 8 * (seq.fetch_add(1) % 256u);
+}
+#else
+__device__ unsigned eco_spanp_counters[256 * 8];
+static unsigned* spanp_counter_slot() {
+  static unsigned* base[64] = {nullptr};
+  static std::atomic<unsigned> seq{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!base[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(eco_spanp_counters)) != hipSuccess) return nullptr;
+    base[dev] = (unsigned*)p;
+  }
+  return base[dev] + 8 * (seq.fetch_add(1) % 256u);
+}
+#endif
+static bool spanp_dynamic() {
+  static const int on = [] { const char* e = getenv("ECO_SPANP_DYNAMIC"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on != 0;
+}
+
 // The persistent form (convb_spanp_kernel): 2 workgroups per CU walk the (slice, tile) items.
 static bool spanp_enabled() {
   static const int on = [] { const char* e = getenv("ECO_SPANP"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -2167,6 +2273,14 @@ static int launch_convb_spanp(const ConvBArgs& a, const eco_convb_plan* plan, hi
   pa.kb = a.ksplit > 1 ? a.ksplit : a.ws_slices > 1 ? plan->tail_ksplit : 1;
   pa.t_main = pa.ntiles - pa.t_tail;
   pa.nitems = pa.t_main + pa.t_tail * pa.kb;
+  // dynamic items where a draw (~600 cycles of one wave, once per item) is small against what it balances: long items (the
+  // trunk: >= 54 taps) or many per workgroup (conv2_3x3: 49); the 18-27-tap inception launches (six items per workgroup, no
+  // measurable difference between the two workgroups of a CU) keep their static shares
+  {
+    const long groups_per_item = (long)(a.nstages / a.taps) * a.kd / (pa.kb > 1 && pa.t_main == 0 ? pa.kb : 1);
+    const bool worth = groups_per_item * 9 >= 54 || (long)pa.nitems >= 16l * plan->pgrid;
+    pa.ctr = (spanp_dynamic() && worth && a.nblk_m <= 4 && plan->pgrid % a.nblk_m == 0) ? spanp_counter_slot() : nullptr;
+  }
   pa.d_sout = fastdiv_make((unsigned)a.s_out);
   pa.d_hw = fastdiv_make((unsigned)(a.Hi * a.Wi));
   pa.d_w = fastdiv_make((unsigned)a.Wi);

@@ -616,6 +616,7 @@ __device__ __forceinline__ void conv_reduce_segment(const ConvKernelArgs& a, int
 
 template <int TM, int TN, int WM, int WN, int KC, int MODE>
 __global__ __launch_bounds__(256, (TM * TN <= 4 ? 3 : 2)) void conv_mfma_kernel(const ConvKernelArgs a0) {
+  ECO_CLOCK("conv_mfma");
   const ConvKernelArgs a = batch_args(a0);
   constexpr bool CTAP = MODE == ECO_CONV_MODE_CTAP;
   constexpr int BM = 32 * TM * WM;
@@ -1141,6 +1142,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 4 : TM * TN <= 6 ? 3 : 2)) voi
 // single tap), same epilogue and views as conv_mfma_kernel.
 template <int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv_point_kernel(const ConvKernelArgs a) {
+  ECO_CLOCK("conv_point");
   constexpr int KC = 16;
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;

@@ -399,6 +399,34 @@ __device__ __forceinline__ void ld_partial_tiles4(const float* p, float4 (&q)[4]
 #endif
 }
 
+// Device-scope fetch-and-add / store on a work counter (one lane calls it).
+__device__ __forceinline__ unsigned counter_fetch_add(unsigned* p, unsigned v) {
+#ifdef ECO_EMU
+  return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST);   // (workgroups run on several host threads)
+#else
+  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// The same for a whole wave at once, on the scalar unit (s_atomic_add, returning form; p wave-uniform): ~600 cycles round
+// trip for a wave on its own (tools/ubench/satomic_check.hip), nothing in the vector memory counter.  The wait is part of
+// the statement: the compiler must not copy the result register before the value is in it.
+__device__ __forceinline__ unsigned counter_draw_wave(unsigned* p) {
+#ifdef ECO_EMU
+  return __atomic_fetch_add(p, 1u, __ATOMIC_SEQ_CST);   // (called by one fiber of the workgroup)
+#else
+  unsigned t = 1u;
+  asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(p) : "memory");
+  return t;
+#endif
+}
+__device__ __forceinline__ void counter_store(unsigned* p, unsigned v) {
+#ifdef ECO_EMU
+  __atomic_store_n(p, v, __ATOMIC_SEQ_CST);
+#else
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 __device__ __forceinline__ void flag_publish(int* flag, int value) {
 #ifdef ECO_EMU
   __atomic_store_n(flag, value, __ATOMIC_SEQ_CST);
@@ -432,6 +460,34 @@ __device__ __forceinline__ void flag_wait(const int* flag, int value) {
 #else
 #define ECO_OPAQUE(v) asm volatile("" : "+v"(v))
 #define ECO_OPAQUE64(v) asm volatile("" : "+v"(v))
+#endif
+
+// Probe builds (-DECO_CLOCK_PROBE, tools/exp/clock_probe.sh): the shader clock a kernel actually ran at, from inside it --
+// workgroup 0's first thread reads the shader-cycle counter (s_memtime) and the constant 100 MHz real-time counter
+// (s_memrealtime) when it starts and when it ends and prints both differences.
+#if defined(ECO_CLOCK_PROBE) && !defined(ECO_EMU)
+struct ClockProbe {
+  unsigned long long t0, r0;
+  const char* name;
+  bool on;
+  // (ECO_CLOCK_PROBE = 2: also the first thread of the middle and the last workgroup, with absolute real-time stamps --
+  // do the workgroups of a launch start and end together?)
+  __device__ __forceinline__ ClockProbe(const char* n)
+      : name(n), on(threadIdx.x == 0 && (blockIdx.x == 0 || (ECO_CLOCK_PROBE > 1 && (blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1)))) {
+    if (on) { t0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  }
+  __device__ __forceinline__ ~ClockProbe() {
+    if (on) {
+      const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+      const unsigned long long dt = __builtin_readcyclecounter() - t0, dr = r1 - r0;
+      if (ECO_CLOCK_PROBE > 1) printf("CLKB %s %u %u %llu %llu %llu\n", name, (unsigned)blockIdx.x, (unsigned)gridDim.x, r0, r1, dt);
+      else printf("CLK %s %llu %llu\n", name, dt, dr);
+    }
+  }
+};
+#define ECO_CLOCK(name) ClockProbe eco_clock_probe_(name)
+#else
+#define ECO_CLOCK(name) do { } while (0)
 #endif
 
 // XCD-aware workgroup remap (MI355X: 8 XCDs, hardware places block b on XCD b % 8, each

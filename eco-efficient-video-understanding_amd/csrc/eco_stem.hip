@@ -98,6 +98,7 @@ struct StemArgs {
 // TMC = cout / 32 (1 or 2 m-tiles; every wave holds all channels of its 128 columns)
 template <int TMC>
 __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
+  ECO_CLOCK("stem");
   constexpr int COUT = 32 * TMC;
   constexpr int IN_ROWS = 3 * kStemIR;                   // 117 patch rows of 63 words
   constexpr int IN_WORDS = IN_ROWS * kStemIQ;            // 7371

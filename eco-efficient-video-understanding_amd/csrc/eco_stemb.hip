@@ -106,6 +106,7 @@ extern "C" int eco_stemb_ts_read(void* host) {
 // TMC = cout / 32 (1 or 2 m-tiles; every wave holds all channels of its 128 columns)
 template <int TMC>
 __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
+  ECO_CLOCK("stemb");
   constexpr int COUT = 32 * TMC;
   constexpr int XS_BYTES = kSbRows * kSbRowBytes;          // 14976
   constexpr int W_VECS = kSbSteps * 2 * COUT;              // 16-byte vectors of packed weights

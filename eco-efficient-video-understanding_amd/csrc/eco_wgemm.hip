@@ -45,6 +45,7 @@ struct WGemmArgs {
 // The three buffers of a stage: A [8][BMP][2], B [8][BN][2] floats.
 template <int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void wgemm_kernel(const WGemmArgs a) {
+  ECO_CLOCK("wgemm");
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int BMP = (BM + 63) / 64 * 64;
@@ -566,6 +567,7 @@ struct WFusedArgs {
 #endif
 template <int KP, int VEC>
 __global__ __launch_bounds__(256, ECO_WFUSED_OCC) void wfused_kernel(const WFusedArgs a) {
+  ECO_CLOCK("wfused");
   const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   constexpr int CH = 16;                 // k-pairs per chunk
   constexpr int NCH = KP / CH;           // chunks per point

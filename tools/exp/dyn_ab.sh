@@ -1,0 +1,21 @@
+mkdir -p gpurun_out/dyn
+for r in 1 2; do for d in 0 1; do
+  ECO_SPANP_DYNAMIC=$d python tools/eco_time.py --iterations 8 --segments 32 --dtype bf16 2>/dev/null | grep -v amdgpu > gpurun_out/dyn/d${d}_$r.txt
+  echo "== dynamic=$d $r $(grep Average gpurun_out/dyn/d${d}_$r.txt | cut -c1-40)"
+done; done
+python - <<'PY'
+import re
+def load(p):
+    d = {}
+    for l in open(p):
+        m = re.match(r"\s*(.*?)\s+forward:\s+([\d.]+) ms", l)
+        if m: d[m.group(1).split('+')[0].split(' ')[0]] = float(m.group(2))
+    return d
+t = {v: [load(f"gpurun_out/dyn/d{v}_{r}.txt") for r in (1, 2)] for v in (0, 1)}
+for k in t[0][0]:
+    a = min(q[k] for q in t[0]); b = min(q[k] for q in t[1])
+    if "3x3" in k or "res" in k: print(f"{k:34s} static {a:.4f}  dynamic {b:.4f}  {100 * (b - a) / a:+.1f}%")
+print("sum", sum(min(q[k] for q in t[0]) for k in t[0][0]), sum(min(q[k] for q in t[1]) for k in t[0][0]))
+PY
+timeout 900 python -m pytest tests/test_blocked.py tests/test_siblings.py tests/test_eco_full_size.py tests/test_reference_logits.py -m gpu -x -q 2>&1 | tail -3
+for i in 1 2; do python bench.py --segments 32 --dtype bf16 --no-cpu-baseline --no-extra-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench bf16', d['value'], d['ms_per_step'])"; done
