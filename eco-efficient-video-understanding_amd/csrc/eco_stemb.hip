@@ -34,6 +34,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "eco_common.h"
 
 namespace eco {
@@ -71,6 +73,8 @@ struct StemBArgs {
   int n, H, W, cout, Ho, Wo, PHo, PWo;
   int relu, tiles_h, tiles_w;
   int total;             // patches (n * tiles_h * tiles_w); a workgroup takes patch blockIdx.x, + gridDim.x, ...
+  unsigned* ctr;         // ... or, given a work counter (ctr[0] tickets, ctr[1] workgroups gone; zero before the launch, zeroed
+                         // again by the last workgroup to leave), blockIdx.x and then whatever patch is next when it asks
 };
 
 // sixteen bytes from a 4-byte aligned LDS address (a position's columns start at an even bf16 index)
@@ -226,10 +230,35 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
   const unsigned stage_mask = a.relu ? 0x7fff7fffu : 0xffffffffu;   // (max(-0, +0) may be -0: its sign bit would win an unsigned maximum)
   const int cblocks = a.cout / 8;
 
+  // Patches: the first is blockIdx.x; after it either every gridDim.x-th, or -- dynamic -- the next one nobody has taken
+  // (patch gridDim.x + ticket), drawn by wave 0 on the scalar unit when the patch's loads are about to be issued (two patches
+  // ahead of its reduction) and passed through LDS behind a barrier the loop has anyway.  The two workgroups of a CU do not
+  // run at the same speed (the instruction arbiter prefers the older wave): with equal shares block b finished its 56
+  // patches in 421 us and block b + 256 in 510 us (tools/exp/clock_probe2.sh).
+  const bool dynamic = a.ctr != nullptr;
+  __shared__ int next_patch;
+  auto draw = [&]() {      // wave 0; the value is read behind the next barrier
+    if (dynamic && wave == 0) {
+#ifdef ECO_EMU
+      if (tid == 0)
+#endif
+      {
+        const unsigned t = counter_draw_wave(a.ctr);
+        if (lane == 0) next_patch = (int)gridDim.x + (int)t;
+      }
+    }
+  };
   int patch = (int)blockIdx.x;
+  int next = patch + (int)gridDim.x;
+  if (dynamic) {
+    draw();
+    __syncthreads();
+    next = uniform(next_patch);
+    __syncthreads();       // (read before the next draw overwrites it)
+  }
   load_patch(patch);
   store_patch();
-  if (patch + (int)gridDim.x < a.total) load_patch(patch + (int)gridDim.x);
+  if (next < a.total) load_patch(next);
 #if !defined(ECO_EMU) && !defined(ECO_STEMB_NOSTAGGER)
   // Workgroups that start together stay in step: every CU fetched its next patch in the same ~7 k cycles of a 24 k-cycle
   // patch period -- 16 MB asked of HBM at once, every wave waiting at its load instructions, the memory idle for the rest
@@ -239,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
   __syncthreads();
 
   while (true) {
-    const int next = patch + (int)gridDim.x;               // its words are in flight (or landed) in xv
+    // (the words of `next` are in flight, or landed, in xv)
     ECO_SBTS(0);
 
     f32x16 acc[TMC][4];
@@ -286,8 +315,10 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
     });
 #endif
     ECO_SBTS(1);
+    if (next < a.total) draw();   // the patch after `next`
     __syncthreads();   // every wave is done with Xs: the next patch may land
     ECO_SBTS(2);
+    const int next2 = !dynamic ? next + (int)gridDim.x : next < a.total ? uniform(next_patch) : a.total;
     if (next < a.total) {
 #ifdef ECO_STEMB_TS
 #pragma unroll
@@ -299,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
     }
     // the patch after it: its loads have the whole epilogue below and the next reduction to land (xv is live across the
     // reduction either way)
-    if (next < a.total && next + (int)gridDim.x < a.total) load_patch(next + (int)gridDim.x);
+    if (next < a.total && next2 < a.total) load_patch(next2);
 
     ECO_SBTS(3);
     // ---- per 16 channels: bias / BN on the accumulators into the stage, 3x3 stride-2 max over it, ReLU, pooled store.
@@ -324,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
     for (int i = 0; i < TMC; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-    if (a.total >= 0) { if (next >= a.total) break; patch = next; continue; }
+    if (a.total >= 0) { if (next >= a.total) break; patch = next; next = next2; continue; }
 #endif
     ECO_SBTS(4);
     static_for<TMC>([&](auto I) __attribute__((always_inline)) {
@@ -391,6 +422,11 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
 #endif
     if (next >= a.total) break;
     patch = next;
+    next = next2;
+  }
+  if (dynamic && tid == 0) {   // count this workgroup out; the last one out clears the launch's counters
+    const unsigned gone = counter_fetch_add(a.ctr + 1, 1u);
+    if (gone == gridDim.x - 1u) { counter_store(a.ctr, 0u); counter_store(a.ctr + 1, 0u); }
   }
 #ifdef ECO_STEMB_TS
   __syncthreads();
@@ -417,6 +453,30 @@ static unsigned short stemb_bf16(float f) {   // round to nearest even, as the d
   memcpy(&u, &f, 4);
   return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
+
+// Work counters of the dynamic patch distribution (as eco_spanp_counters in eco_blocked.hip): a launch takes the next of 256
+// slots, its last workgroup clears it again.
+#ifdef ECO_EMU
+static unsigned eco_stemb_counters[256 * 2];
+static unsigned* stemb_counter_slot() {
+  static std::atomic<unsigned> seq{0};
+  return eco_stemb_counters + 2 * (seq.fetch_add(1) % 256u);
+}
+#else
+__device__ unsigned eco_stemb_counters[256 * 2];
+static unsigned* stemb_counter_slot() {
+  static unsigned* base[64] = {nullptr};
+  static std::atomic<unsigned> seq{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!base[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(eco_stemb_counters)) != hipSuccess) return nullptr;
+    base[dev] = (unsigned*)p;
+  }
+  return base[dev] + 2 * (seq.fetch_add(1) % 256u);
+}
+#endif
 
 extern "C" int64_t eco_stemb_weight_elems(int32_t cout) { return (int64_t)kSbSteps * 2 * cout * 8; }
 
@@ -453,6 +513,8 @@ extern "C" int eco_stemb_forward(const float* x, const void* wp, const float* bi
   // persistent workgroups, two per CU: the weights are loaded once per workgroup, not once per patch
   const long cap = max_workgroups ? max_workgroups : 2l * current_device_num_cu();
   const long grid = total < cap ? total : cap;
+  static const int dyn = [] { const char* e = getenv("ECO_STEMB_DYNAMIC"); return (e && e[0] == '0') ? 0 : 1; }();
+  a.ctr = (dyn && total > 2 * grid) ? stemb_counter_slot() : nullptr;   // (worth a draw per patch only with several patches per workgroup)
   const size_t lds = (size_t)kSbRows * kSbRowBytes + (size_t)kSbSteps * 2 * cout * 16 + sizeof(float) * (size_t)(2 * cout + 16 * (kSbNPos + 3));
   hipStream_t s = (hipStream_t)stream;
   if (cout == 64) ECO_RAISE_DYNAMIC_LDS(stemb_kernel<2>, "stemb");
