@@ -250,6 +250,32 @@ def test_convb_span_kernel_single_destination(backend, n, cin, cout, in_sp, num_
     run_convb(backend, BF16, n, cin, cout, in_sp, k, (1,) * len(in_sp), (1,) * len(in_sp), num_cu=num_cu, seed=5, raw=False)
 
 
+def test_convb_dynamic_items_counter_slots_are_reusable(backend):
+    """The persistent kernel draws its items from a per-launch counter slot that its last workgroup clears (256 slots,
+    taken in turn): 260 launches of a two-items-per-workgroup case walk every slot once and the first four twice -- a slot
+    left dirty would make a later launch skip items."""
+    case = (4, 64, 32, (4, 16, 16), 1)       # 16 tiles on 8 workgroups, 6 groups of 9 taps: dynamic shares
+    n, cin, cout, in_sp, num_cu = case
+    k = (3, 3, 3)
+    plan = run_convb(backend, BF16, n, cin, cout, in_sp, k, (1, 1, 1), (1, 1, 1), num_cu=num_cu, seed=11, raw=False)
+    assert plan.pgrid == 8 and plan.ksplit == 1
+    rng = np.random.default_rng(12)
+    x = quant(rng.normal(size=(n, cin) + in_sp).astype(np.float32), BF16)
+    w = quant((rng.normal(size=(cout, cin) + k) / np.sqrt(cin * 27)).astype(np.float32), BF16)
+    g = hip.conv_geom(n, cin, cout, in_sp, k, (1, 1, 1), (1, 1, 1), in_sp)
+    wp = np.zeros(plan.wp_vecs * 8, np.uint16)
+    backend.lib.convb_pack_weights(g, plan, w.ctypes.data, wp.ctypes.data)
+    S = int(np.prod(in_sp))
+    xd, wd = dev_blocked(backend, x, BF16), backend.dev(wp)
+    y = empty_blocked(backend, (n, cout) + in_sp, BF16)
+    ep = hip.ConvEpilogue()
+    ep.bias = None; ep.residual = hip.null_view(); ep.raw = hip.null_view(); ep.bn_scale = None; ep.bn_shift = None; ep.relu = 0
+    ep.act = hip.View(bptr(backend, y, BF16), (cout // 8) * S, 0, S, 1)
+    for _ in range(260):
+        backend.lib.convb_forward(g, plan, bptr(backend, xd, BF16), backend.ptr(wd), ep, None)
+    check(host_blocked(backend, y, (n, cout) + in_sp, BF16), orc.convolution(x, w, None, k, (1, 1, 1), (1, 1, 1)), BF16, "after 260 launches")
+
+
 def test_convb_rejects_unblocked_geometries(backend):
     g = hip.conv_geom(1, 20, 32, (4, 4), (1, 1), (1, 1), (0, 0), (4, 4))
     with pytest.raises(hip.EcoError, match="multiple of the 8-channel block"):
