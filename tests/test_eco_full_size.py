@@ -117,6 +117,26 @@ def test_hipgraph_replay_matches_eager():
 
 
 @pytest.mark.gpu
+def test_hipgraph_replay_bf16_with_dynamic_items():
+    """The bf16 path under hipGraph replay: the persistent kernels draw their items from counter slots chosen at capture
+    time and cleared by each launch's last workgroup, so every replay starts from zeroed counters -- logits bit-identical to
+    the eager run over five replays (which workgroup computes a tile changes, what it computes does not)."""
+    import torch
+    proto = models.eco_lite_deploy(num_segments=16, num_clips=4)
+    spec = NetSpec.from_prototxt(proto)
+    params = fillers.synthetic_params(spec)
+    net = Net(proto, params=params, dtype="bf16")
+    net.blobs["data"].tensor.copy_(torch.from_numpy(fillers.synthetic_frames(64)).cuda())
+    net.forward_device()
+    torch.cuda.synchronize()
+    eager = net.blobs["fc8"].tensor.clone()
+    for _ in range(5):
+        net.forward_device(graph=True)
+        torch.cuda.synchronize()
+        assert torch.equal(net.blobs["fc8"].tensor, eager)
+
+
+@pytest.mark.gpu
 def test_caffe_time_style_report():
     """tools/eco_time.py (`caffe time` for the HIP path) runs and reports every launch of the fused plan."""
     import subprocess, sys, os
