@@ -1635,7 +1635,13 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
     ECO_TS(19);
     if (cur.slice >= 0) {
       if (a.ws_frag) stores = convb_store_partial_frag<TM>(a, acc, cur.slice, cur.tile, wave, lane, rws);   // (counted: stepped over)
-      else convb_store_partial<TM, TN>(a, acc, cur.slice, m0, cur.n0 + wave * 64, half, l31);   // (compiler-counted stores: the next wait drains them)
+      else {   // (compiler-counted stores: the next wait drains them.  The row offset is made opaque here: as a loop invariant its
+               // 128 row addresses were computed when the kernel starts and spilled -- 60 scratch stores per workgroup for a
+               // fallback path)
+        int m0p = m0;
+        ECO_OPAQUE(m0p);
+        convb_store_partial<TM, TN>(a, acc, cur.slice, m0p, cur.n0 + wave * 64, half, l31);
+      }
     } else
     if (a.lean)
       stores = convb_epilogue_lean<TM, false>(a, acc, m0, m0, cur.n0 + wave * 64 + lane, half, Ep, BMP, pa.d_sout);
