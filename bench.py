@@ -240,33 +240,12 @@ def main() -> None:
     # profiler on itself, so this is the figure of the last profiled build: reported only when that build was made from
     # the SOURCES the running library was made from (eco_source_digest(), compiled in by csrc/Makefile: a rebuild of
     # identical sources keeps the field; the .so's bytes are not compared), else null with the reason.
-    roofline["traffic"] = None
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")) as f:
             tr = json.load(f)
-        src_now = hip.load().source_digest()
-        # traffic per launch belongs to the launch size it was counted on: only the PMC passes of THIS workload qualify
-        if workload_key == tr.get("workload", "lite/16/32/f32"):
-            tk, tsrc = tr["kernels"], tr["source"]
-        elif workload_key in tr.get("workloads", {}):
-            tk, tsrc = tr["workloads"][workload_key]["kernels"], tr["workloads"][workload_key]["source"]
-        else:
-            tk, tsrc = None, None
-        rows = {k: v for k, v in (tk or {}).items() if k.split("<")[0] == dom_name}
-        if tk is None:
-            roofline["traffic_unit"] = f"null: no PMC passes of workload {workload_key} in profiles/hbm_traffic_latest.json"
-        elif tr.get("src_sha256") is None or tr.get("src_sha256") != src_now:
-            roofline["traffic_unit"] = ("null: profiles/hbm_traffic_latest.json was collected on a build of other sources "
-                                        f"({str(tr.get('src_sha256'))[:12]} != {src_now[:12]}); re-run tools/profile_round.sh")
-        elif rows:
-            # launch-weighted mean over the family's instances (PMC rows carry their launch counts)
-            w = sum(c.get("launches", 1) for c in rows.values())
-            roofline["traffic"] = round(sum(c["hbm_bytes_per_launch"] * c.get("launches", 1) for c in rows.values()) / w / 1e9, 4)
-            roofline["traffic_unit"] = "GB per launch (PMC, " + tsrc + ", same sources " + src_now[:12] + ")"
-        else:
-            roofline["traffic_unit"] = f"null: no PMC row for {dom_name} in {tsrc}"
+        roofline["traffic"], roofline["traffic_unit"] = traffic_from_summary(tr, workload_key, dom_name, hip.load().source_digest())
     except Exception as e:  # no summary committed, unreadable file, ...
-        roofline["traffic_unit"] = f"null: {type(e).__name__}: {e}"
+        roofline["traffic"], roofline["traffic_unit"] = None, f"null: {type(e).__name__}: {e}"
     executed = sum(p["flops"] for p in prof)
     roofline.update({
         "kernel": dom_name, "largest_instance": dom_inst, "launches_per_step": dom["launches"],
@@ -403,6 +382,28 @@ def reference_logits(gen, N, frames, params, clips=1, blas_threads: bool = True)
     outs = [eco_oracle.forward(spec1, params, {"data": frames[c * N:(c + 1) * N]}, conv_impl=conv)[spec1.outputs[0]]
             for c in idx]
     return np.concatenate(outs, 0)
+
+
+def traffic_from_summary(tr, workload_key, family, src_now):
+    """(GB per launch or None, unit / reason) for kernel `family` from profiles/hbm_traffic_latest.json (`tr`).  Reported only
+    when the summary was collected (a) on a library built from the sources the running one was built from (`src_now` =
+    eco_source_digest()) and (b) on THIS workload (variant/segments/clips per GPU/dtype): bytes per launch belong to the
+    launch size they were counted on.  Launch-weighted mean over the family's instances."""
+    if workload_key == tr.get("workload", "lite/16/32/f32"):
+        tk, tsrc = tr["kernels"], tr["source"]
+    elif workload_key in tr.get("workloads", {}):
+        tk, tsrc = tr["workloads"][workload_key]["kernels"], tr["workloads"][workload_key]["source"]
+    else:
+        return None, f"null: no PMC passes of workload {workload_key} in profiles/hbm_traffic_latest.json"
+    if tr.get("src_sha256") is None or tr.get("src_sha256") != src_now:
+        return None, ("null: profiles/hbm_traffic_latest.json was collected on a build of other sources "
+                      f"({str(tr.get('src_sha256'))[:12]} != {src_now[:12]}); re-run tools/profile_round.sh")
+    rows = {k: v for k, v in tk.items() if k.split("<")[0] == family}
+    if not rows:
+        return None, f"null: no PMC row for {family} in {tsrc}"
+    w = sum(c.get("launches", 1) for c in rows.values())
+    gb = round(sum(c["hbm_bytes_per_launch"] * c.get("launches", 1) for c in rows.values()) / w / 1e9, 4)
+    return gb, "GB per launch (PMC, " + tsrc + ", same sources " + src_now[:12] + ")"
 
 
 def parity_record(got, ref, dtype: str, what: str, clips=None) -> dict:

@@ -39,3 +39,24 @@ def test_baseline_config_names():
     assert bench.baseline_config("lite", 32, 32, "bf16", 1).startswith("BASELINE.json configs[4]")
     assert bench.baseline_config("lite", 4, 1, "f32", 1).startswith("BASELINE.json configs[0]")
     assert bench.baseline_config("lite", 8, 3, "f32", 1) == "not a BASELINE.json configuration"
+
+
+def test_traffic_is_reported_only_for_the_profiled_sources_and_workload():
+    """bench.py's roofline.traffic: the PMC summary must belong to the running library's sources AND to the line's workload."""
+    import bench
+    tr = {"source": "profiles/rXX_pmc_hbm_traffic.csv", "src_sha256": "a" * 64, "workload": "lite/16/32/f32",
+          "kernels": {"eco::wgemm_kernel<4, 2, 1, 4>": {"hbm_bytes_per_launch": 2.0e9, "launches": 1},
+                      "eco::wgemm_kernel<2, 2, 2, 2>": {"hbm_bytes_per_launch": 1.0e9, "launches": 3},
+                      "eco::stem_kernel<2>": {"hbm_bytes_per_launch": 0.5e9, "launches": 1}},
+          "workloads": {"lite/32/32/bf16": {"source": "profiles/rXX_bf16_pmc_hbm_traffic.csv",
+                                            "kernels": {"eco::convb_spanp_kernel<4>": {"hbm_bytes_per_launch": 0.6e9, "launches": 9}}}}}
+    gb, unit = bench.traffic_from_summary(tr, "lite/16/32/f32", "eco::wgemm_kernel", "a" * 64)
+    assert gb == 1.25 and "rXX_pmc_hbm_traffic" in unit                 # launch-weighted over the family's instances
+    gb, unit = bench.traffic_from_summary(tr, "lite/32/32/bf16", "eco::convb_spanp_kernel", "a" * 64)
+    assert gb == 0.6 and "bf16" in unit
+    gb, unit = bench.traffic_from_summary(tr, "lite/16/1/f32", "eco::wgemm_kernel", "a" * 64)      # one clip: other launch sizes
+    assert gb is None and "no PMC passes of workload lite/16/1/f32" in unit
+    gb, unit = bench.traffic_from_summary(tr, "lite/16/32/f32", "eco::wgemm_kernel", "b" * 64)     # an edited kernel
+    assert gb is None and "other sources" in unit
+    gb, unit = bench.traffic_from_summary(tr, "lite/32/32/bf16", "eco::wgemm_kernel", "a" * 64)    # family not in that pass
+    assert gb is None and "no PMC row" in unit
