@@ -82,6 +82,11 @@ struct ConvBArgs {
   int ws_frag, ws_tile0, ws_ntl;
   int wide;            // 1: every destination view ends below 2 GB -> the 16-byte-store epilogue (convb_epilogue_wide)
   int lean;            // 1 (needs wide): one destination per 32-row tile, bias + BN + ReLU only -> convb_epilogue_lean
+  // LDS-DMA kernel, descriptor form (dma_buf = 1: input + dma_bias and the packed weights end below 2 GB): a position
+  // piece is fetched at descriptor offset lane register + SGPR, the lane register = (its position's first tap + dma_bias)
+  // in bytes -- dma_bias blocks, the padding's reach, keep it non-negative where the first tap lies before the tensor
+  int dma_buf;
+  unsigned dma_x_bytes, dma_wp_bytes, dma_bias;
   FastDiv d_sout;      // position -> image by multiply-high
 };
 
@@ -891,6 +896,19 @@ __global__ __launch_bounds__(256, 2) void convb_dma_kernel(const ConvBArgs a, co
   const uint4* const xv = (const uint4*)a.x;
   // out-of-image taps read the zero page: one integer select per piece (no divergent second instruction)
   const long zoff = (long)(((intptr_t)zero_page_ptr(zero_page) - (intptr_t)xv) / 16);
+  // descriptor form (a.dma_buf; as the persistent span kernel's glds16_buf): no 64-bit lane arithmetic and no zero page --
+  // a piece is SGPR base + SGPR offset + one lane register that stays put for the workgroup's lifetime, and a tap outside
+  // the image is an out-of-range offset that writes zeros
+  const BufRsrc rxb = make_buf_rsrc((const char*)a.x - a.dma_bias, a.dma_x_bytes + a.dma_bias);
+  const BufRsrc rwb = make_buf_rsrc(a.wp, a.dma_wp_bytes);
+  const unsigned xvo = (unsigned)(in_base * 16 + (long)a.dma_bias);   // (dma_buf: 0 <= in_base * 16 + bias < 2^31)
+  unsigned wvo[A_PER_WAVE];
+#pragma unroll
+  for (int q = 0; q < A_PER_WAVE; ++q) {
+    const int piece = wave + 4 * q, row = piece / (BMP / 64), mc = piece % (BMP / 64);
+    wvo[q] = (unsigned)(row * a.mpad + m0 + mc * 64 + lane) * 16u;
+  }
+  const unsigned wstage16 = (unsigned)(kCbs * a.mpad) * 16u;
 
   // the stage whose DMA is issued next: uniform (cg, tap) walk
   int l_cg = s_begin / a.taps, l_tap = s_begin - l_cg * a.taps;
@@ -901,6 +919,21 @@ __global__ __launch_bounds__(256, 2) void convb_dma_kernel(const ConvBArgs a, co
     // all-ones where the tap is inside the image.  Opaque to the optimiser: a recognisable select gets turned
     // into a divergent branch with one copy of the DMA instruction in each arm, and then a wave with both kinds
     // of lanes issues more pieces than wait_dma_all_but<P> accounts for.
+    if (a.dma_buf) {
+      const unsigned vo = ((mask >> l_tap) & 1ull) ? xvo : kBufOob;
+#pragma unroll
+      for (int q = 0; q < B_PER_WAVE; ++q) {
+        const int kb = kb0 + q * KB_STEP;
+        const int cb = min(l_cg * kCbs + kb, a.cblocks - 1);   // zero-weight padding group: any finite data
+        glds16_buf(rxb, vo, (unsigned)((toff + (long)cb * a.cb_stride_in) * 16), Bb + kb * BN + chunk * 64);
+      }
+#pragma unroll
+      for (int q = 0; q < A_PER_WAVE; ++q) {
+        const int piece = wave + 4 * q;       // piece = row * (BMP/64) + m-chunk
+        const int row = piece / (BMP / 64), mc = piece % (BMP / 64);
+        glds16_buf(rwb, wvo[q], (unsigned)l_stage * wstage16, Ab + row * BMP + mc * 64);
+      }
+    } else {
     long sel = -(long)((mask >> l_tap) & 1ull);
     ECO_OPAQUE64(sel);
 #pragma unroll
@@ -915,6 +948,7 @@ __global__ __launch_bounds__(256, 2) void convb_dma_kernel(const ConvBArgs a, co
       const int piece = wave + 4 * q;       // piece = row * (BMP/64) + m-chunk
       const int row = piece / (BMP / 64), mc = piece % (BMP / 64);
       glds16(a.wp + ((long)l_stage * kCbs + row) * a.mpad + m0 + mc * 64 + lane, Ab + row * BMP + mc * 64);
+    }
     }
     ++l_stage;
     ++l_tap;
@@ -936,17 +970,24 @@ __global__ __launch_bounds__(256, 2) void convb_dma_kernel(const ConvBArgs a, co
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   auto compute = [&](const uint4* Ab, const uint4* Bb) {
+    // both k-steps' fragments are read before the first one's products issue (the second read's latency passes under
+    // eight MFMAs: the strided 3x3x3 launches -4 % on top of the descriptor form)
+    uint4 af[kCbs / 2][TM], bf[kCbs / 2][TN];
 #pragma unroll
     for (int ks = 0; ks < kCbs / 2; ++ks) {
-      uint4 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = Ab[(2 * ks + half) * BMP + (wm * TM + i) * 32 + l31];
+      for (int i = 0; i < TM; ++i) af[ks][i] = Ab[(2 * ks + half) * BMP + (wm * TM + i) * 32 + l31];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = Bb[(2 * ks + half) * BN + (wn * TN + j) * 32 + l31];
+      for (int j = 0; j < TN; ++j) bf[ks][j] = Bb[(2 * ks + half) * BN + (wn * TN + j) * 32 + l31];
+    }
+    sched_fence();
+#pragma unroll
+    for (int ks = 0; ks < kCbs / 2; ++ks) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16_bf16(af[ks][i], bf[ks][j], acc[i][j]);
+      sched_fence();
     }
   };
   // One stage: its own pieces (issued two stages ago) have landed once at most the newest stage's P are pending.
@@ -2210,9 +2251,22 @@ static const uint4* device_zero_page() {
 }
 
 template <int TM, int TN, int WM, int WN>
-static int launch_convb_dma(const ConvBArgs& a, hipStream_t stream) {
+static int launch_convb_dma(const ConvBArgs& a0, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, BMP = (BM + 63) / 64 * 64;
   const uint4* zp = device_zero_page();
+  ConvBArgs a = a0;
+  {   // descriptor-addressed DMA where the 32-bit offsets reach: the input (plus the padding's reach in front of it) and the
+      // packed weights below 2 GB; ECO_CONVB_DMA_BUF=0 keeps the flat form (A/B runs)
+    static const int on = [] { const char* e = getenv("ECO_CONVB_DMA_BUF"); return (e && e[0] == '0') ? 0 : 1; }();
+    const long x_bytes = (long)a.ntot / a.s_out * a.img_stride_in * 16;
+    const long bias = (((long)a.pd * a.Hi + a.ph) * a.Wi + a.pw) * 16;
+    const long wp_bytes = (long)a.nstages * kCbs * a.mpad * 16;
+    const long lim = (1l << 31) - (1l << 20);
+    a.dma_buf = (on && x_bytes + bias < lim && wp_bytes < lim) ? 1 : 0;
+    a.dma_x_bytes = a.dma_buf ? (unsigned)x_bytes : 0u;
+    a.dma_wp_bytes = a.dma_buf ? (unsigned)wp_bytes : 0u;
+    a.dma_bias = a.dma_buf ? (unsigned)bias : 0u;
+  }
   ECO_REQUIRE((((uintptr_t)a.x | (uintptr_t)a.wp) & 15) == 0, "convb: input and packed weights must be 16-byte aligned");
   const int grid = a.nblk_m * a.nblk_n * a.ksplit;
   static_assert(3 * kCbs * (BMP + BN) * 16 <= 160 * 1024, "three stage buffers must fit the CU's LDS");
