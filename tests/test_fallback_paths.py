@@ -1,0 +1,28 @@
+"""The forms the library falls back to (or can be switched to for A/B runs) still compute the same thing: the flat
+(64-bit address) DMA of the LDS-DMA kernel, static item / patch shares in the persistent kernels, the round-3 per-tile span
+kernel.  The switches are read once per process, so each setting runs a few emulator tests of tests/test_blocked.py and
+tests/test_stemb.py in a child process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = [
+    ({"ECO_CONVB_DMA_BUF": "0"}, ["tests/test_blocked.py", "-k", "convb_matches_oracle and bf16 or single_destination"]),
+    ({"ECO_SPANP_DYNAMIC": "0"}, ["tests/test_blocked.py", "-k", "span_kernel and bf16"]),
+    ({"ECO_SPANP": "0"}, ["tests/test_blocked.py", "-k", "span_kernel and bf16 and (s0 or s1 or s4)"]),
+    ({"ECO_STEMB_DYNAMIC": "0"}, ["tests/test_stemb.py"]),
+]
+
+
+@pytest.mark.parametrize("env,args", CASES, ids=[next(iter(e)) for e, _ in CASES])
+def test_switched_forms_match_the_oracle(env, args):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "not gpu", "-p", "no:cacheprovider"] + args,
+                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
