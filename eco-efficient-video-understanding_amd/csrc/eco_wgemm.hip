@@ -30,6 +30,7 @@
 namespace eco {
 
 constexpr int kWgP = 36;   // F(4x4,3x3): 6x6 transform points
+constexpr int kWgP3 = 216; // F(4x4x4,3x3x3): 6x6x6 transform points (the GEMM only sees more, shorter problems)
 constexpr int kWgKp = 8;             // k-pairs (16 reduction elements) per stage
 
 struct WGemmArgs {
@@ -725,7 +726,8 @@ using namespace eco;
 
 static int wgemm_check_plan(const eco_wgemm_plan* p) {
   ECO_REQUIRE(p != nullptr, "wgemm: null plan");
-  ECO_REQUIRE(p->points == kWgP, "wgemm: only F(4x4,3x3) (36 transform points) is supported, got %d", p->points);
+  ECO_REQUIRE(p->points == kWgP || (p->points == kWgP3 && p->kd == 1),
+              "wgemm: F(4x4,3x3) (36 transform points) or, with kd = 1, F(4x4x4,3x3x3) (216) is supported, got %d", p->points);
   ECO_REQUIRE(p->n > 0 && p->cin > 0 && p->cin % 16 == 0 && p->cout > 0 && p->d > 0 && p->th > 0 && p->tw > 0 &&
                   (p->kd == 1 || p->kd == 3),
               "wgemm: bad problem (n=%d cin=%d cout=%d d=%d tiles %dx%d kd=%d; cin must be a multiple of 16)", p->n, p->cin,
@@ -792,6 +794,9 @@ extern "C" int eco_wgemm_plan_create(int32_t n, int32_t cin, int32_t cout, int32
   // 128-wide tiles keep three workgroups per CU instead of two in flight (measured over the seven 2-D GEMMs of the
   // configs[1] step: 2.07 -> 1.98 ms).
   if (plan->nstages <= 6 && plan->ksplit == 1) plan->bn = 128;
+  // F(4x4x4,3x3x3): six times as many problems with a third of the reduction each -- the same trade (measured on the three
+  // trunk stages at 32 clips: 0.446 / 0.267 ms with 256-wide tiles, 0.421 / 0.254 with 128-wide ones)
+  if (points == kWgP3 && plan->ksplit == 1) plan->bn = 128;
   const long nb = (long)n * th * tw;
   const int pd = kd / 2;
   plan->mblocks = (int)ceil_div(cout, bm);

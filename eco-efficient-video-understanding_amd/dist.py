@@ -148,18 +148,19 @@ def plan_rank_cpus(gpu_pci_ids: Sequence[Optional[str]], allowed: Iterable[int],
         groups.setdefault(cand, []).append(r)          # () = "no information" (or none of its CPUs allowed)
     plan: List[List[int]] = [[] for _ in range(n)]
     claimed: Set[int] = set()
-    for cand, ranks in groups.items():
+    overflow: List[int] = []                           # ranks of nodes with fewer allowed cores than ranks (round-4 advisor:
+    for cand, ranks in groups.items():                 # adding them to `groups` here changed the dict under its own iteration)
         if not cand:
             continue
         cores = physical_cores(cand, sysfs)
-        if len(cores) < len(ranks):                    # fewer cores than ranks on this node: fall through to the even split
-            groups.setdefault((), []).extend(ranks)
+        if len(cores) < len(ranks):                    # fewer cores than ranks on this node: they join the even split below
+            overflow.extend(ranks)
             continue
         for i, r in enumerate(ranks):
             mine = cores[len(cores) * i // len(ranks):len(cores) * (i + 1) // len(ranks)]
             plan[r] = sorted(c for core in mine for c in core)
             claimed.update(plan[r])
-    rest = sorted(groups.get((), []))
+    rest = sorted(groups.get((), []) + overflow)
     if rest:
         free = [c for c in allowed if c not in claimed] or allowed
         cores = physical_cores(free, sysfs)

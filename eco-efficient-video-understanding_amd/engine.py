@@ -141,6 +141,12 @@ class Engine:
         # -> 26.57 / 26.19 / 26.26 / 26.75 ms per step -- above 128 the unfused GEMM's larger tiles win)
         self.wfused_max_cin = 128
         self.wgemm = True          # F(4x4,3x3) GEMMs on the dedicated dense kernel (False: round-1 gather-kernel route)
+        # 3x3x3 layers: nest the minimal-filtering algorithm over depth as well, F(4x4x4,3x3x3) (csrc/eco_wino3.hip): half
+        # the transformed-domain multiplies of F(4x4,3x3) + direct depth taps, V / M 1.33x / 1.5x larger.  Taken where the
+        # depth tiles (4 planes) waste little (8*ceil(D/4) <= 3*D: D = 3, 4, 6, 7, 8, ...) and a transform point still has
+        # wino3_min_positions tile positions (at one clip res4 / res5 have 32 / 4: they stay on the 2-D route)
+        self.wino3 = True
+        self.wino3_min_positions = 128
         self.stem = True           # conv1 + BN + ReLU + pool1 as one launch (False: conv kernel + pooling kernel)
         self.siblings = True       # 1x1 convs reading the same bottom as one launch (fp32 path)
         # AVE pool 3x3/1/1 -> 1x1 conv (inception_3a/3b pool + pool_proj): both maps are linear, so the conv runs first
@@ -233,7 +239,14 @@ class Engine:
                     self.lib.stem_pack_weights(w.ctypes.data, L.geom["cout"], swp.ctypes.data)
                     self.alloc.upload(st["stem_wp"], swp)
                 wn = st.get("wino")
-                if wn is not None and wn.get("kind") == "wgemm":   # u[p] = (G g G^T)[p] packed for the dense GEMM kernel
+                if wn is not None and wn.get("kind") == "wgemm3":  # u[p] = ((G x G x G) g)[p], 216 points, K = cin
+                    cout, cin = L.geom["cout"], L.geom["cin"]
+                    u = np.empty((216, cout, cin, 1), np.float32)
+                    self.lib.wino3_weight_transform(w.ctypes.data, cout, cin, u.ctypes.data)
+                    up = np.zeros(wn["up_elems"], np.float32)
+                    self.lib.wgemm_pack_weights(wn["plan"], u.ctypes.data, up.ctypes.data)
+                    self.alloc.upload(wn["up"], up)
+                elif wn is not None and wn.get("kind") == "wgemm":   # u[p] = (G g G^T)[p] packed for the dense GEMM kernel
                     cout, cin, kd = L.geom["cout"], L.geom["cin"], wn["kd"]
                     u = np.empty((36, cout, cin, kd), np.float32)
                     self.lib.wino_weight_transform(w.ctypes.data, cout, cin, kd, 4, u.ctypes.data)
@@ -521,6 +534,15 @@ class Engine:
             return n * D * -(-H // 4) * -(-W // 4) >= self.wino_min_tiles
         return True
 
+    def _wino3_pays(self, n: int, D: int, TH: int, TW: int) -> bool:
+        """F(4x4x4,3x3x3) instead of F(4x4,3x3) + direct depth taps for a 3x3x3 layer on n x D x (4 TH) x (4 TW) volumes?"""
+        TD = -(-D // 4)
+        if not self.wino3 or 8 * TD > 3 * D:
+            return False
+        if self.winograd is True and n * TD * TH * TW < self.wino3_min_positions:   # an explicit winograd=4 overrides
+            return False
+        return self.lib.wino3_lds_bytes(n, TH, TW) <= 152 * 1024
+
     def _plan_wino(self, L: LayerSpec, st: dict) -> None:
         g = L.geom
         n, D, H, W, kd = self._wino_dims(L)
@@ -530,6 +552,18 @@ class Engine:
         T = M + 2
         TH, TW = -(-H // M), -(-W // M)
         old = st.get("wino")
+        if M == 4 and self.wgemm and kd == 3 and self._wino3_pays(n, D, TH, TW):
+            # F(4x4x4,3x3x3): the same dense GEMM kernel on 216 points with K = cin; transforms in csrc/eco_wino3.hip
+            TD = -(-D // 4)
+            plan = self.lib.wgemm_plan(n, g["cin"], g["cout"], TD, TH, TW, 1, self.num_cu, points=216)
+            wn = dict(kind="wgemm3", plan=plan, M=4, points=216, TD=TD, TH=TH, TW=TW, kd=kd, fused=False,
+                      v_elems=plan.v_elems, m_elems=plan.m_elems, up_elems=plan.u_elems)
+            if old is not None and old.get("kind") == "wgemm3" and old.get("up_elems") == plan.u_elems:
+                wn["up"] = old["up"]
+            else:
+                wn["up"] = self.alloc.empty(plan.u_elems, np.float32)
+            st["wino"] = wn
+            return
         if M == 4 and self.wgemm:
             # F(4x4,3x3) on the dedicated dense GEMM (csrc/eco_wgemm.hip): pair-interleaved depth-major V, LDS-DMA staging
             plan = self.lib.wgemm_plan(n, g["cin"], g["cout"], D, TH, TW, kd, self.num_cu)
@@ -570,6 +604,25 @@ class Engine:
         x = self._ptr(L.bottoms[0])
         v = self.alloc.ptr(self._wino_buf_v_elems)
         m = self.alloc.ptr(self._wino_buf_m_elems) if getattr(self, "_wino_m_elems", 0) else None
+        if wn["kind"] == "wgemm3":
+            plan, up = wn["plan"], self.alloc.ptr(wn["up"])
+            self._keep.append((plan, ep))
+            pos = n * wn["TD"] * wn["TH"] * wn["TW"]                # positions per transform point
+            v_bytes, m_bytes = 4 * 216 * cin * pos, 4 * 216 * plan.ksplit * cout * pos
+            x_bytes, w_bytes = 4 * n * cin * D * H * W, 4 * 27 * cin * cout
+            tag = "F(4x4x4,3x3x3)"
+            self._add(i, f"{label} [winograd {tag} input transform]", lambda s, plan=plan, x=x, v=v, D=D, H=H, W=W:
+                      lib.wino3_input_forward(plan, x, v, D, H, W, s),
+                      {"kernel": "eco::wino3_input_kernel", "flops": 0, "bytes": x_bytes + v_bytes})
+            self._add(i, f"{label} [216 transformed-domain GEMMs, K = {cin}]", lambda s, plan=plan, v=v, up=up, m=m:
+                      lib.wgemm_forward(plan, v, up, m, s),
+                      {"kernel": hip.wgemm_kernel_name(plan), "flops": 2 * 216 * pos * cout * cin,
+                       "useful_flops": 2 * 216 * (n * D * H * W / 64.0) * cout * cin,
+                       "bytes": v_bytes + 4 * 216 * cout * cin + m_bytes})
+            self._add(i, f"{label} [winograd {tag} output transform]", lambda s, plan=plan, m=m, D=D, H=H, W=W, ep=ep:
+                      lib.wino3_output_forward(plan, m, D, H, W, ep, s),
+                      {"kernel": "eco::wino3_output_kernel", "flops": 0, "bytes": m_bytes + nbytes - x_bytes - w_bytes})
+            return
         if wn["kind"] == "wgemm":
             plan, up = wn["plan"], self.alloc.ptr(wn["up"])
             self._keep.append((plan, ep))

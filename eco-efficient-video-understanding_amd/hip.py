@@ -21,7 +21,7 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 17
+ABI_VERSION = 18
 MAX_SEG = 3   # ECO_MAX_SEG: extra output segments of a sibling launch
 DT_BF16 = 1
 DT_F32X3 = 3
@@ -231,6 +231,12 @@ _SIGNATURES = {
     "eco_wgemm_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eco_wino_output_dm_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_int32, C.c_int32,
                                              C.POINTER(ConvEpilogue), C.c_void_p]),
+    "eco_wino3_weight_transform": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "eco_wino3_lds_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "eco_wino3_input_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_void_p]),
+    "eco_wino3_output_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                           C.POINTER(ConvEpilogue), C.c_void_p]),
     "eco_convb_plan_create": (C.c_int, [C.POINTER(ConvGeom), C.c_int32, C.c_int32, C.POINTER(ConvBPlan)]),
     "eco_convb_pack_weights": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvBPlan), C.c_void_p, C.c_void_p]),
     "eco_convb_forward": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvBPlan), C.c_void_p, C.c_void_p,
@@ -372,11 +378,26 @@ class EcoLib:
         self._check(self._dll.eco_wfused_forward(C.byref(plan), v, up, h, w, C.byref(ep), stream))
 
     # -- Winograd F(4x4,3x3) on the dedicated transformed-domain GEMM (csrc/eco_wgemm.hip) --
-    def wgemm_plan(self, n, cin, cout, d, th, tw, kd, num_cu: Optional[int] = None) -> "WGemmPlan":
+    def wgemm_plan(self, n, cin, cout, d, th, tw, kd, num_cu: Optional[int] = None, points: int = 36) -> "WGemmPlan":
+        """points = 36: F(4x4,3x3), d = depth planes, kd depth taps direct; points = 216: F(4x4x4,3x3x3), d = depth TILES,
+        kd = 1 (csrc/eco_wino3.hip)."""
         p = WGemmPlan()
-        self._check(self._dll.eco_wgemm_plan_create(n, cin, cout, d, th, tw, kd, 36, 0 if num_cu is None else int(num_cu),
+        self._check(self._dll.eco_wgemm_plan_create(n, cin, cout, d, th, tw, kd, points, 0 if num_cu is None else int(num_cu),
                                                     C.byref(p)))
         return p
+
+    # -- Winograd F(4x4x4,3x3x3): the 3-D trunk's transforms around the same GEMM (csrc/eco_wino3.hip) --
+    def wino3_weight_transform(self, w_host: int, cout: int, cin: int, u_host: int) -> None:
+        self._check(self._dll.eco_wino3_weight_transform(w_host, cout, cin, u_host))
+
+    def wino3_lds_bytes(self, n: int, th: int, tw: int) -> int:
+        return int(self._dll.eco_wino3_lds_bytes(n, th, tw))
+
+    def wino3_input_forward(self, p: "WGemmPlan", x: int, v: int, d: int, h: int, w: int, stream=None) -> None:
+        self._check(self._dll.eco_wino3_input_forward(C.byref(p), x, v, d, h, w, stream))
+
+    def wino3_output_forward(self, p: "WGemmPlan", m: int, d: int, h: int, w: int, ep: ConvEpilogue, stream=None) -> None:
+        self._check(self._dll.eco_wino3_output_forward(C.byref(p), m, d, h, w, C.byref(ep), stream))
 
     def wgemm_pack_weights(self, p: "WGemmPlan", u_host: int, up_host: int) -> None:
         self._check(self._dll.eco_wgemm_pack_weights(C.byref(p), u_host, up_host))

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 17
+#define ECO_ABI_VERSION 18
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -338,7 +338,7 @@ int eco_stemb_forward(const float* x, const void* wp, const float* bias, const f
 typedef struct eco_wgemm_plan {
   int32_t n, cin, cout, d, th, tw; /* clips/images, channels, depth, tiles per plane (ceil(H/4), ceil(W/4))   */
   int32_t kd;                      /* 1 (2-D 3x3) or 3 (3x3x3, depth taps direct)                             */
-  int32_t points;                  /* 36                                                                      */
+  int32_t points;                  /* 36; 216 = F(4x4x4,3x3x3) below (kd = 1, d = depth TILES)                */
   int32_t bm, bn;                  /* block tile: output channels x positions                                 */
   int32_t nstages;                 /* (cin/16) * kd stages of 16 reduction elements                           */
   int32_t ksplit;                  /* split-K slices (rows of m)                                              */
@@ -368,6 +368,26 @@ int64_t eco_wfused_weight_elems(const eco_wgemm_plan* plan);
 int eco_wfused_pack_weights(const eco_wgemm_plan* plan, const float* u, float* up); /* HOST */
 int eco_wfused_forward(const eco_wgemm_plan* plan, const float* v, const float* up, int32_t h, int32_t w,
                        const eco_conv_epilogue* ep, void* stream);
+
+/* ---- Winograd F(4x4x4,3x3x3) for the 3-D trunk (csrc/eco_wino3.hip, ABI v18) ---------------------------------
+ *
+ * The stride-1 pad-1 3x3x3 convolutions (res3a_2 ... res5b_2, models_ECO_Lite/kinetics/deploy.prototxt:1162-1660)
+ * with the minimal-filtering algorithm nested over depth as well: 216 multiplies per input channel and 4x4x4 output
+ * tile instead of the 432 of the F(4x4,3x3) + direct-depth-taps route above; the depth axis of every trunk stage is
+ * a multiple of 4 at num_segments 16 / 32, other depths are padded per tile.  Same three steps, same GEMM kernel:
+ *   plan = eco_wgemm_plan_create(n, cin, cout, ceil(D/4), ceil(H/4), ceil(W/4), kd = 1, points = 216, ...)
+ *   v[p][cin/2][r][2], m[p][slice][cout][r]   p = (pz*6 + py)*6 + px, r = ((td*n + b)*th + ty)*tw + tx
+ *   up = eco_wgemm_pack_weights(u), u = eco_wino3_weight_transform(w)       u[216][cout][cin] = (G x G x G) w
+ *   eco_wino3_input_forward(x -> v); eco_wgemm_forward(v, up -> m); eco_wino3_output_forward(m -> y, epilogue)
+ * The two transforms keep a group of images' planes in LDS: eco_wino3_lds_bytes(n, th, tw) must not exceed 152 KB
+ * (planes up to ~56x56); they fail with ECO_ERR_INVALID otherwise.  Results equal eco_conv_forward's up to fp32
+ * rounding (cudnn_conv_layer.cu:15-65 leaves the algorithm to cuDNN). */
+int eco_wino3_weight_transform(const float* w, int32_t cout, int32_t cin, float* u); /* HOST */
+int64_t eco_wino3_lds_bytes(int32_t n, int32_t th, int32_t tw);
+int eco_wino3_input_forward(const eco_wgemm_plan* plan, const float* x, float* v, int32_t d, int32_t h, int32_t w,
+                            void* stream);
+int eco_wino3_output_forward(const eco_wgemm_plan* plan, const float* m, int32_t d, int32_t h, int32_t w,
+                             const eco_conv_epilogue* ep, void* stream);
 
 /* ---- channel-blocked ("NC8") path on the bf16 matrix cores (csrc/eco_blocked.hip) -------------------------
  *

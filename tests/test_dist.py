@@ -301,6 +301,27 @@ def test_rank_cpus_respect_the_allowed_mask_and_fall_back_without_numa_informati
     assert ed.parse_cpulist("0-3,8-11,16\n") == [0, 1, 2, 3, 8, 9, 10, 11, 16] and ed.parse_cpulist("") == []
 
 
+def test_rank_cpus_when_a_numa_node_has_fewer_allowed_cores_than_ranks(tmp_path):
+    """Round-4 advisor finding: three GPUs on one node whose cpuset allows two physical cores -- with NUMA information
+    present and no rank in the "no information" group yet -- raised `dictionary changed size during iteration`."""
+    from eco_amd import dist as ed
+    sysfs, pci = _fake_sysfs(tmp_path, sockets=1, cores_per_socket=8, smt=2, gpus_per_socket=3)
+    plan = ed.plan_rank_cpus(pci, [0, 1, 8, 9], sysfs)                  # cores 0 and 1, both threads
+    assert len(plan) == 3 and all(p == [0, 1, 8, 9] for p in plan)      # shared: nobody is left without CPUs
+    # a second node that HAS enough cores keeps its own share; the crowded node's ranks split what is left
+    sysfs2, pci2 = _fake_sysfs(tmp_path / "b", sockets=2, cores_per_socket=4, smt=1, gpus_per_socket=2)
+    plan = ed.plan_rank_cpus(pci2, [0, 4, 5, 6, 7], sysfs2)             # node 0: one core for two ranks; node 1: four
+    assert plan[2] == [4, 5] and plan[3] == [6, 7]
+    assert plan[0] == [0] and plan[1] == [0]
+    # and pin_rank does not raise there
+    import os
+    before = os.sched_getaffinity(0)
+    try:
+        assert ed.pin_rank(0, pci, sysfs) is not None
+    finally:
+        os.sched_setaffinity(0, before)
+
+
 def test_pin_rank_sets_affinity(tmp_path):
     import os
     from eco_amd import dist as ed

@@ -179,6 +179,37 @@ layer { name: "cat" type: "Concat" bottom: "c1_bn" bottom: "c2" top: "cat" }
     assert relerr(net.forward()["cat"], ref2["cat"]) < 2e-4
 
 
+def test_trunk_takes_the_3d_winograd_route_where_depth_tiles_by_four(backend):
+    """num_segments = 16: the res5 stage has 4 planes -> F(4x4x4,3x3x3) (csrc/eco_wino3.hip) on its three stride-1 convs
+    (the only stage wide enough in this reduced net), residual + BN + ReLU + raw epilogue included; wino3 = False and
+    num_segments = 4 (one plane) keep the F(4x4,3x3) + direct-depth-taps route.  All against the oracle."""
+    proto = mini("lite", num_segments=16, num_clips=2)
+    spec = NetSpec.from_prototxt(proto)
+    params = fillers.synthetic_params(spec, seed=11)
+    x = fillers.synthetic_frames(32, 32, 32, seed=5)
+    ref = orc.forward(spec, params, {"data": x}, keep="all", fast_pool=False)
+    net = make_net(backend, proto, params, True, winograd=4)
+    labels = net.op_labels()
+    w3 = [l for l in labels if "F(4x4x4,3x3x3)" in l]
+    assert len(w3) == 6 and sum("216 transformed-domain GEMMs, K = 64" in l for l in labels) == 3, labels
+    assert "res5b_2+res5b+res5b_bn+res5b_relu [winograd F(4x4x4,3x3x3) output transform]" in w3
+    net.blobs["data"].data[...] = x
+    out = net.forward()["fc8"].copy()
+    assert relerr(out, ref["fc8"]) < TOL
+    for name in ("res5a", "res5b_bn", "res5b_1_bn"):
+        if name in net._engine.tensors:
+            got = net.blobs[name].data
+            assert relerr(got, ref[name].reshape(got.shape)) < TOL, name
+    net._engine.wino3 = False
+    net._engine.build()
+    assert not any("F(4x4x4" in l for l in net.op_labels()) and sum("F(4x4,3x3)" in l for l in net.op_labels()) == 6
+    net.blobs["data"].data[...] = x
+    out2 = net.forward()["fc8"]
+    assert relerr(out2, ref["fc8"]) < TOL and relerr(out2, out) < TOL
+    one_plane = make_net(backend, mini("lite"), fillers.synthetic_params(NetSpec.from_prototxt(mini("lite"))), True, winograd=4)
+    assert not any("F(4x4x4" in l for l in one_plane.op_labels())
+
+
 def test_reshape_grows_winograd_buffers(backend):
     """net.reshape() to a larger clip batch re-plans the Winograd route (transformed-volume scratch, batched
     plans, per-point weights) and still matches the oracle; shrinking back reuses the storage."""

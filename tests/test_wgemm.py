@@ -164,3 +164,103 @@ def test_wfused_rejects_other_shapes(backend):
     plan = lib.wgemm_plan(1, 64, 48, 1, 4, 4, 1, None)        # cout not a multiple of 32
     with pytest.raises(hip.EcoError, match="multiples of 32"):
         lib.wfused_forward(plan, 0, 0, 16, 16, hip.ConvEpilogue())
+
+
+# ---- Winograd F(4x4x4,3x3x3): the 3-D trunk's route (csrc/eco_wino3.hip) around the same GEMM kernel ---------------------
+W3_CASES = [  # n, cin, cout, (D,H,W), num_cu
+    (2, 16, 32, (4, 8, 8), None),        # one depth tile, planes tile by 4: 16-byte accesses throughout
+    (1, 32, 96, (8, 7, 7), None),        # res5-like 7x7 planes (scalar accesses), two depth tiles, bm = 96
+    (3, 16, 64, (6, 14, 14), None),      # ragged depth (6 -> two tiles, second half empty), W % 4 == 2: 8-byte accesses
+    (1, 64, 32, (4, 28, 28), None),      # res3-like 28x28 planes: 49 tiles per image, one image per workgroup
+    (5, 16, 160, (2, 5, 9), 1),          # D < 4, odd planes, image groups with a ragged last group, two M-blocks, tiny "device"
+    (9, 32, 32, (4, 4, 4), None),        # one tile per image: eight images per workgroup, last group ragged
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,dims,num_cu", W3_CASES, ids=[f"w3_{i}" for i in range(len(W3_CASES))])
+@pytest.mark.parametrize("mode", ["plain", "fused", "views"])
+def test_wino3_route_matches_direct_conv(backend, n, cin, cout, dims, num_cu, mode):
+    D, H, W = dims
+    rng = np.random.default_rng(cin + cout + H + D)
+    x = rng.normal(size=(n, cin, D, H, W)).astype(np.float32)
+    w = (rng.normal(size=(cout, cin, 3, 3, 3)) / np.sqrt(cin * 27)).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    v = orc.convolution(x, w, b, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    lib = backend.lib
+    TD, TH, TW = -(-D // 4), -(-H // 4), -(-W // 4)
+    plan = lib.wgemm_plan(n, cin, cout, TD, TH, TW, 1, num_cu, points=216)
+    assert plan.points == 216 and plan.q == TD * n * TH * TW and plan.nstages == cin // 16
+    u = np.empty((216, cout, cin, 1), np.float32)
+    lib.wino3_weight_transform(w.ctypes.data, cout, cin, u.ctypes.data)
+    up = np.empty(plan.u_elems, np.float32)
+    lib.wgemm_pack_weights(plan, u.ctypes.data, up.ctypes.data)
+    vbuf, mbuf = backend.empty((plan.v_elems,)), backend.empty((plan.m_elems,))
+    S = D * H * W
+    ep = hip.ConvEpilogue()
+    ep.bias = backend.ptr(backend.dev(b))
+    ep.residual, ep.raw, ep.act, ep.act2 = hip.null_view(), hip.null_view(), hip.null_view(), hip.null_view()
+    ep.bn_scale = ep.bn_shift = None
+    ep.relu = 0
+    tol = 1e-4 * np.abs(v).max()     # three nested F(4,3) transforms: measured 1-2e-5 of the largest output
+    lib.wino3_input_forward(plan, backend.ptr(backend.dev(x)), backend.ptr(vbuf), D, H, W)
+    lib.wgemm_forward(plan, backend.ptr(vbuf), backend.ptr(backend.dev(up)), backend.ptr(mbuf))
+    shp = (1, -1, 1, 1, 1)
+    if mode == "plain":
+        y_raw = backend.empty(v.shape)
+        ep.raw = hip.plain_view(backend.ptr(y_raw), cout, S)
+        lib.wino3_output_forward(plan, backend.ptr(mbuf), D, H, W, ep)
+        assert np.abs(backend.host(y_raw, v.shape) - v).max() <= tol
+        return
+    res = rng.normal(size=v.shape).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
+    ep.residual = hip.plain_view(backend.ptr(backend.dev(res)), cout, S)
+    ep.bn_scale, ep.bn_shift = backend.ptr(backend.dev(sc)), backend.ptr(backend.dev(sh))
+    ref_raw = v + res
+    if mode == "fused":        # bias + Eltwise residual + raw store + BN + ReLU
+        y_raw, y_act = backend.empty(v.shape), backend.empty(v.shape)
+        ep.relu = 1
+        ep.raw = hip.plain_view(backend.ptr(y_raw), cout, S)
+        ep.act = hip.plain_view(backend.ptr(y_act), cout, S)
+        lib.wino3_output_forward(plan, backend.ptr(mbuf), D, H, W, ep)
+        assert np.abs(backend.host(y_raw, v.shape) - ref_raw).max() <= tol
+        assert np.abs(backend.host(y_act, v.shape) - np.maximum(ref_raw * sc.reshape(shp) + sh.reshape(shp), 0)).max() <= tol
+        return
+    # views: no ReLU (negative values survive), the activated output into a channel slice of a wider tensor and, a second
+    # time, into another one; no raw output
+    c0, ctot = 3, cout + 5
+    big = backend.dev(np.full((n, ctot, D, H, W), 7.0, np.float32))
+    big2 = backend.dev(np.full((n, ctot, D, H, W), -3.0, np.float32))
+    ep.act = hip.View(backend.ptr(big, c0 * S), ctot * S, 0, S, 1)
+    ep.act2 = hip.View(backend.ptr(big2, 1 * S), ctot * S, 0, S, 1)
+    lib.wino3_output_forward(plan, backend.ptr(mbuf), D, H, W, ep)
+    ref_act = ref_raw * sc.reshape(shp) + sh.reshape(shp)
+    assert (ref_act < 0).any()
+    got, got2 = backend.host(big, (n, ctot, D, H, W)), backend.host(big2, (n, ctot, D, H, W))
+    assert np.abs(got[:, c0:c0 + cout] - ref_act).max() <= tol and np.abs(got2[:, 1:1 + cout] - ref_act).max() <= tol
+    assert (got[:, :c0] == 7.0).all() and (got[:, c0 + cout:] == 7.0).all()
+    assert (got2[:, :1] == -3.0).all() and (got2[:, 1 + cout:] == -3.0).all()
+
+
+def test_wino3_weight_transform_is_the_kronecker_cube_of_g(backend):
+    """u[(pz, py, px)] = sum G[pz][kz] G[py][ky] G[px][kx] w[kz][ky][kx] (Lavin & Gray 2015, F(4,3)), in float64."""
+    G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                  [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]])
+    rng = np.random.default_rng(5)
+    w = rng.normal(size=(3, 2, 3, 3, 3)).astype(np.float32)
+    u = np.empty((216, 3, 2), np.float32)
+    backend.lib.wino3_weight_transform(w.ctypes.data, 3, 2, u.ctypes.data)
+    ref = np.einsum("az,by,cx,oizyx->abcoi", G, G, G, w.astype(np.float64)).reshape(216, 3, 2)
+    assert np.abs(u - ref).max() < 1e-6
+
+
+def test_wino3_rejects_wrong_plans(backend):
+    lib = backend.lib
+    p36 = lib.wgemm_plan(1, 32, 32, 4, 2, 2, 3)
+    with pytest.raises(hip.EcoError, match="216"):
+        lib.wino3_input_forward(p36, 0, 0, 4, 8, 8)
+    p = lib.wgemm_plan(1, 32, 32, 1, 2, 2, 1, None, points=216)
+    with pytest.raises(hip.EcoError, match="tiles"):
+        lib.wino3_input_forward(p, 0, 0, 8, 8, 8)       # two depth tiles, plan has one
+    with pytest.raises(hip.EcoError, match="kd"):
+        lib.wgemm_plan(1, 32, 32, 1, 2, 2, 3, None, points=216)
+    assert lib.wino3_lds_bytes(32, 7, 7) == 6 * 2 * 1 * 30 * 36 * 4
