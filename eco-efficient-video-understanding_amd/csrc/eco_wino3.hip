@@ -59,6 +59,26 @@ __device__ __forceinline__ void w3_at(const float (&m)[6], float (&y)[4]) {
   y[3] = t2 + 8.0f * t4 + m[5];
 }
 
+// A 16-byte LDS read that IS one ds_read_b128: from dynamic LDS with run-time row pitches the compiler splits a float4
+// load into two ds_read2_b32 (it cannot see the 16-byte alignment the layout guarantees).  Not tracked by the compiler's
+// wait counts: lds_wait(values) before the first use.
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 lds_ld16(const float* p) {
+#ifdef ECO_EMU
+  return *(const f4*)p;
+#else
+  f4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)p));
+  return v;
+#endif
+}
+// (the values are in/out operands of the wait: nothing that reads them may be scheduled ahead of it)
+__device__ __forceinline__ void lds_wait(f4& a, f4& b, f4& c) {
+#ifndef ECO_EMU
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
+#endif
+}
+
 struct Wino3InArgs {
   const float* x;   // [n][cin][D][H][W]
   float* v;         // V3
@@ -151,11 +171,20 @@ __global__ __launch_bounds__(512) void wino3_input_kernel(const Wino3InArgs a) {
     for (int e = 0; e < 2; ++e) {
       const float* src = zd + pz * pstride + ((e * a.GB + bl) * a.PH + 4 * th) * a.PW + 4 * tw + 3;
       float t1[6][6];
+      // a window row = columns 4 tw + 3 ... 4 tw + 8 of the parked plane: three aligned 16-byte reads (the two single
+      // columns as 4-byte reads at a lane stride of 16 bytes are 4-way bank conflicts)
+      f4 lo[6], mid[6], hi[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        lo[i] = lds_ld16(src + i * a.PW - 3);
+        mid[i] = lds_ld16(src + i * a.PW + 1);
+        hi[i] = lds_ld16(src + i * a.PW + 5);
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) lds_wait(lo[i], mid[i], hi[i]);
 #pragma unroll
       for (int i = 0; i < 6; ++i) {        // rows of the window: transform along w
-        const float* rp = src + i * a.PW;
-        const float4 mid = *(const float4*)(rp + 1);
-        const float row[6] = {rp[0], mid.x, mid.y, mid.z, mid.w, rp[5]};
+        const float row[6] = {lo[i].w, mid[i].x, mid[i].y, mid[i].z, mid[i].w, hi[i].x};
         w3_bt(row, t1[i]);
       }
 #pragma unroll

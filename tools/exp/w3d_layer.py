@@ -5,7 +5,7 @@ import numpy as np
 import torch
 from eco_amd import hip
 
-lib = hip.EcoLib(hip.LIB_PATH)
+lib = hip.EcoLib(os.environ.get("ECO_LIB", hip.LIB_PATH))
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 shapes = [("res3", 128, 128, 16, 28, 28), ("res4", 256, 256, 8, 14, 14), ("res5", 512, 512, 4, 7, 7)]
