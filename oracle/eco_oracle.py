@@ -8,15 +8,28 @@ fallback: it fails loudly when the HIP library is missing.
 What this is: a NumPy fp32 restatement of the reference's (caffe_3d) layer
 arithmetic for the layers on the ECO inference path, written from the
 reference sources cited per function.  The reference itself cannot be built in
-this image (needs protobuf+protoc, glog, gflags, boost, HDF5, LMDB/LevelDB,
-OpenCV, a CBLAS; and its CPU path cannot execute 5-D BN / 3-D pooling at all:
-layers/bn_layer.cpp:70-73, layers/pooling_layer.cpp:177-201), so parity is
-pinned against the golden vectors of the reference's own unit tests
-(tests/test_oracle_golden.py; fixtures in tests/golden/) -- GEMM, naive-loop
-convolution (2-D and 3-D), 2-D/3-D pooling known answers, BN inference formula,
-concat/eltwise/reshape/inner-product properties -- and cross-checked against an
-independent torch-CPU implementation.  Whole-net logits have no recorded
-reference output anywhere ("parity by construction").
+this image as a whole (needs protobuf+protoc, glog, gflags, boost, HDF5,
+LMDB/LevelDB, OpenCV, a CBLAS; and its CPU path cannot execute 5-D BN / 3-D
+pooling at all: layers/bn_layer.cpp:70-73, layers/pooling_layer.cpp:177-201).
+PINNED, in three ways:
+  * against the golden vectors of the reference's own unit tests
+    (tests/test_oracle_golden.py; fixtures in tests/golden/) -- GEMM, naive-loop
+    convolution (2-D and 3-D), 2-D/3-D pooling known answers, BN inference
+    formula, concat/eltwise/reshape/inner-product properties;
+  * layer by layer against the reference's OWN object code: eleven reference
+    .cpp files compiled unmodified into oracle/_ref/libeco_ref.so
+    (oracle/Makefile; tests/test_oracle_ref.py: bit-identical on im2col, the
+    ConvolutionLayer forward, MAX pooling, BN, Permute, Eltwise, Concat, ReLU,
+    Reshape; fp32 rounding on AVE pooling and InnerProduct);
+  * whole-net logits against EXECUTED reference code at full width:
+    tests/golden/reference_logits.json (generator make_reference_logits.py: the
+    reference's deploy prototxt files walked layer by layer through those
+    compiled classes) holds ECO-Lite N=4 (BASELINE configs[0]), N=8 x 2 clips,
+    N=16 (configs[1]'s clip geometry), N=32 (configs[4]'s) and ECO-Full N=4;
+    tests/test_reference_logits.py compares this module with it (2-3e-7 of
+    the largest logit, every blob's fingerprint at 2e-5) and, on the GPU, the
+    HIP path directly.
+An independent torch-CPU implementation cross-checks every op as well.
 
 Third-party arithmetic the reference delegates to (not under /root/reference):
 CBLAS ``cblas_sgemm`` (ATLAS/OpenBLAS/MKL, unpinned; call sites

@@ -179,12 +179,26 @@ CASES = [
          baseline="configs[3] graph at the configs[0] clip geometry"),
     dict(key="eco_lite_n8_b2", file="models_ECO_Lite/kinetics/deploy.prototxt", num_segments=8, num_clips=2,
          baseline="two clips, depth-2 global_pool window (clip independence through reference code)"),
+    # the clip geometries of the headline configurations, one clip each (round 5): the 3-D trunk at 16 / 8 / 4 planes
+    # (32 / 16 / 8), i.e. the depths at which the HIP path nests the minimal-filtering algorithm over depth as well
+    dict(key="eco_lite_n16_b1", file="models_ECO_Lite/kinetics/deploy.prototxt", num_segments=16, num_clips=1,
+         baseline="BASELINE.json configs[1] / configs[2] clip geometry (the authors' own num_segments), one clip"),
+    dict(key="eco_lite_n32_b1", file="models_ECO_Lite/kinetics/deploy.prototxt", num_segments=32, num_clips=1,
+         baseline="BASELINE.json configs[4] clip geometry (r2Dto3D 32x96x28x28, global_pool 8x7x7), one clip"),
 ]
 
 
 def main():
+    """No arguments: regenerate every net.  `--add`: keep the nets the committed JSON already holds (bit for bit) and
+    compute only the missing ones."""
     assert eco_ref.has_conv_layer(), "oracle/_ref lacks the compiled ConvolutionLayer: make -C oracle"
     seed_params, seed_frames = 2024, 77
+    have = {}
+    if "--add" in sys.argv[1:] and os.path.exists(OUT):
+        with open(OUT) as f:
+            old = json.load(f)
+        assert (old["seed_params"], old["seed_frames"], old["recipe"]) == (seed_params, seed_frames, ref_params.RECIPE)
+        have = old["nets"]
     out = dict(generator="tests/golden/make_reference_logits.py", recipe=ref_params.RECIPE, seed_params=seed_params,
                seed_frames=seed_frames, blas="SciPy bundled OpenBLAS (cblas_sgemm), threads = library default",
                compiled=["util/im2col.cpp", "layers/base_conv_layer.cpp", "layers/conv_layer.cpp", "layers/bn_layer.cpp",
@@ -192,6 +206,10 @@ def main():
                          "layers/eltwise_layer.cpp", "layers/reshape_layer.cpp", "layers/permute_layer.cpp",
                          "layers/inner_product_layer.cpp"], nets={})
     for c in CASES:
+        if c["key"] in have:
+            out["nets"][c["key"]] = have[c["key"]]
+            print("%-16s kept from the committed fixture" % c["key"])
+            continue
         net, edits = load_net(c["file"], c["num_segments"], c["num_clips"])
         blobs, stats, plist, notes, dt = forward(net, seed_params, seed_frames)
         fc8 = blobs["fc8"]

@@ -195,7 +195,12 @@ def test_eco_full_c4_n16_b32():
     assert np.abs(outp - out[perm]).max() < 1e-5 * scale
 
 
-BF16_TOL = 3e-2   # bf16 storage: 2^-9 relative rounding per stored activation / weight, ~40 stored tensors deep
+# bf16 storage: 2^-9 relative rounding per stored activation / weight, ~40 stored tensors deep: a random walk of that depth
+# gives ~6 * 2^-9 = 1.2e-2 of a logit's OWN magnitude; against the LARGEST logit the measured worst case is 3.9e-3.  Round 4
+# stated 3e-2 (7.7x the measurement: a tile-edge bug corrupting a fraction of a percent of outputs would have passed).
+BF16_TOL = 1e-2     # vs the plain fp32 reference, of the largest logit
+BF16_TOL_Q = 3e-3   # vs the reference evaluated with the SAME storage rounding (accumulation order / double rounding only:
+                    # measured 9.2e-4)
 
 
 def test_eco_lite_c5_bf16_n32():
@@ -203,7 +208,7 @@ def test_eco_lite_c5_bf16_n32():
     per GPU.  The oracle stays fp32; two comparisons for clip 0: (a) against the oracle run with the same storage
     rounding (weights and every stored activation rounded to bf16 where the blocked path rounds) -- what remains
     is accumulation order and double rounding; (b) FOUR clips (0, 11, 20, 31) against the plain fp32 oracle within the
-    stated bf16 tolerance (3e-2 of the largest logit; measured values, top-1 and top-5 agreement printed).  Then the clip-independence / permutation properties at
+    stated bf16 tolerance (1e-2 of the largest logit, 3e-3 for (a); measured values, top-1 and top-5 agreement printed).  Then the clip-independence / permutation properties at
     the full batch."""
     from eco_amd import blocked
     N, B = 32, 32
@@ -243,7 +248,7 @@ def test_eco_lite_c5_bf16_n32():
     print(f"bf16 N=32: rel err vs rounding-aware oracle (clip 0) {e_q:.3e}; vs fp32 oracle over clips 0/11/20/31 worst "
           f"{worst:.3e}, top-1 equal {top1} (else a reference near-tie within 2x the error), top-5 overlap {top5}; "
           f"max|logit| {np.abs(ref).max():.1f}")
-    assert e_q < BF16_TOL and min(top5) >= 4
+    assert e_q < BF16_TOL_Q and min(top5) >= 4
     net1 = Net(models.eco_lite_deploy(num_segments=N, num_clips=1), params=params, dtype="bf16")
     alone = net1.forward(data=x[17 * N:18 * N])["fc8"]
     # a single clip gets other split-K factors: another fp32 summation order, so a stored bf16 value may round

@@ -59,6 +59,8 @@ def build_case(fx, key):
     x = ref_params.frames(shp[0], shp[2], shp[3], seed=fx["seed_frames"])
     return proto, spec, params, x, c
 
+BF16_TOL = 1e-2   # of the largest logit (round 4 stated 3e-2 against a measured 4e-3: 7.7x slack)
+
 
 def check_logits(got, c, tol=TOL):
     ref = np.asarray(c["fc8"], np.float32)
@@ -73,7 +75,7 @@ def check_logits(got, c, tol=TOL):
 
 
 # ---- CPU: the NumPy restatement (and the product's graph layer it consumes) against executed reference code --------------
-@pytest.mark.parametrize("key", ["eco_lite_n4_b1", "eco_full_n4_b1"])
+@pytest.mark.parametrize("key", ["eco_lite_n4_b1", "eco_full_n4_b1", "eco_lite_n16_b1"])
 def test_oracle_matches_compiled_reference_at_full_width(key):
     fx = load_fixture()
     proto, spec, params, x, c = build_case(fx, key)
@@ -91,7 +93,10 @@ def test_oracle_matches_compiled_reference_at_full_width(key):
 
 def test_fixture_covers_every_layer_type_and_records_its_limits():
     fx = load_fixture()
-    assert set(fx["nets"]) >= {"eco_lite_n4_b1", "eco_full_n4_b1", "eco_lite_n8_b2"}
+    assert set(fx["nets"]) >= {"eco_lite_n4_b1", "eco_full_n4_b1", "eco_lite_n8_b2", "eco_lite_n16_b1", "eco_lite_n32_b1"}
+    # the headline clip geometries (configs[1] / configs[4]) went through the reference's own code as well
+    assert fx["nets"]["eco_lite_n16_b1"]["input_shape"] == [16, 3, 224, 224]
+    assert fx["nets"]["eco_lite_n32_b1"]["input_shape"] == [32, 3, 224, 224]
     assert "layers/conv_layer.cpp" in fx["compiled"] and "layers/base_conv_layer.cpp" in fx["compiled"]
     for key, c in fx["nets"].items():
         assert c["notes"] == {"bn5d": 11, "pool3d_global": 1}, (key, c["notes"])   # what reference CPU code cannot run
@@ -122,7 +127,7 @@ def test_committed_fixture_is_what_the_generator_produces():
 
 # ---- GPU: the HIP path against executed reference code, directly --------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("key", ["eco_lite_n4_b1", "eco_full_n4_b1", "eco_lite_n8_b2"])
+@pytest.mark.parametrize("key", ["eco_lite_n4_b1", "eco_full_n4_b1", "eco_lite_n8_b2", "eco_lite_n16_b1", "eco_lite_n32_b1"])
 def test_hip_logits_match_compiled_reference(key):
     from eco_amd.net import Net
     fx = load_fixture()
@@ -132,6 +137,9 @@ def test_hip_logits_match_compiled_reference(key):
     # sizes (a single short clip would otherwise run those convolutions directly)
     for fuse, wino in ((True, True), (False, True), (True, 4), (True, 2)):
         net = Net(proto, params=params, fuse=fuse, winograd=wino)
+        if key in ("eco_lite_n16_b1", "eco_lite_n32_b1") and fuse and wino == 4:
+            # the headline geometries: every trunk stage is on the F(4x4x4,3x3x3) route here (csrc/eco_wino3.hip)
+            assert sum("F(4x4x4,3x3x3)" in l for l in net.op_labels()) == 2 * 9, net.op_labels()   # 9 convs: input + output transform
         out = net.forward(data=x)["fc8"].copy()
         worst = max(worst, check_logits(out, c))
         seen = 0
@@ -151,14 +159,16 @@ def test_hip_logits_match_compiled_reference(key):
 
 @pytest.mark.gpu
 def test_hip_bf16_logits_vs_compiled_reference():
-    """The blocked bf16 path (configs[4] arithmetic) on the configs[0] fixture: stated bf16 tolerance 3e-2,
-    top-1 equal; two clips (eco_lite_n8_b2)."""
+    """The blocked bf16 path (configs[4] arithmetic) against executed reference code: the configs[0] fixture, two clips
+    (eco_lite_n8_b2), and -- round 5 -- the configs[4] clip geometry itself (eco_lite_n32_b1) and configs[1]'s.  Stated
+    bf16 tolerance 1e-2 of the largest logit (measured 2-4e-3), top-1 equal."""
     from eco_amd.net import Net
     fx = load_fixture()
-    for key in ("eco_lite_n4_b1", "eco_lite_n8_b2"):
+    for key in ("eco_lite_n4_b1", "eco_lite_n8_b2", "eco_lite_n16_b1", "eco_lite_n32_b1"):
         proto, spec, params, x, c = build_case(fx, key)
         out = Net(proto, params=params, dtype="bf16").forward(data=x)["fc8"].copy()
         ref = np.asarray(c["fc8"], np.float32)
         err = float(np.abs(out - ref).max() / np.abs(ref).max())
-        assert err < 3e-2, err
+        print(f"{key}: bf16 vs compiled reference code, fc8 rel err {err:.2e}")
+        assert err < BF16_TOL, (key, err)
         assert (out.argmax(axis=1) == ref.argmax(axis=1)).all()
