@@ -2,6 +2,8 @@
 // (Caffe::SetDevice / DeviceQuery, caffe_3d/src/caffe/common.cpp:140-190).
 #include <string.h>
 
+#include <mutex>
+
 #include "eco_common.h"
 
 namespace eco {
@@ -18,6 +20,26 @@ int fail(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+int counter_slot_index(void* stream) {
+  static std::mutex mu;
+  static void* seen[64];
+  static int nseen = 0;
+  static unsigned cap_seq = 0;
+  std::lock_guard<std::mutex> lock(mu);
+#ifndef ECO_EMU
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive)
+    return 64 + (int)(cap_seq++ % 192u);
+#else
+  (void)cap_seq;
+#endif
+  for (int i = 0; i < nseen; ++i)
+    if (seen[i] == stream) return i;
+  if (nseen == 64) return -1;
+  seen[nseen] = stream;
+  return nseen++;
 }
 
 }  // namespace eco
@@ -103,3 +125,14 @@ extern "C" int eco_device_pci_bus_id(int device, char* pci, size_t len) {
 }
 
 #endif
+
+// the two counter arrays (eco_blocked.hip, eco_stemb.hip)
+namespace eco {
+int spanp_counters_reset(void* stream);
+int stemb_counters_reset(void* stream);
+}
+extern "C" int eco_counters_reset(void* stream) {
+  clear_error();
+  if (int rc = eco::spanp_counters_reset(stream)) return rc;
+  return eco::stemb_counters_reset(stream);
+}

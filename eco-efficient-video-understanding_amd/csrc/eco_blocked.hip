@@ -309,26 +309,13 @@ __device__ __forceinline__ unsigned view_lane_offset(const eco_view& v, int img,
 template <int TM>
 __device__ __forceinline__ int convb_epilogue_wide(const ConvBArgs& a, f32x16 (&acc)[TM][2], int mw, int m0, int n_lane,
                                                    int half, const float* Ep, int EPS, const FastDiv& d_sout
-#ifdef ECO_SPANP_TS
-                                                   , unsigned long long* tsp = nullptr
-#endif
                                                    ) {
-#ifdef ECO_SPANP_TS
-#define ECO_TSE(k) do { if (tsp) tsp[21 + (k)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define ECO_TSE(k) do { } while (0)
-#endif
-  ECO_TSE(0);
   const bool has_res = a.residual.ptr != nullptr;
   const bool has_raw = a.raw.ptr != nullptr, has_act = a.act.ptr != nullptr, has_act2 = has_act && a.act2.ptr != nullptr;
   const bool ok = n_lane < a.ntot;
   const unsigned nn = ok ? (unsigned)n_lane : 0u;
   const int img = (int)fastdiv(nn, d_sout), sp = (int)(nn - (unsigned)img * (unsigned)a.s_out);
-#ifdef ECO_EPI_PROBE_NOSTORE             // probe builds (tools/exp): every store fails its range check -- issued, never written
-  constexpr unsigned kAll = 0u;
-#else
   constexpr unsigned kAll = 0x7fffffffu;   // (range check = the lane predicate only: valid offsets are below 2 GB by plan)
-#endif
   const unsigned v_raw = has_raw ? view_lane_offset(a.raw, img, sp, ok) : kBufOob;
   const unsigned v_act2 = has_act2 ? view_lane_offset(a.act2, img, sp, ok) : kBufOob;
   const BufRsrc r_raw = make_buf_rsrc(a.raw.ptr, kAll), r_act2 = make_buf_rsrc(a.act2.ptr, kAll);
@@ -346,10 +333,8 @@ __device__ __forceinline__ int convb_epilogue_wide(const ConvBArgs& a, f32x16 (&
                                              : make_uint4(0u, 0u, 0u, 0u);
       }
   }
-  ECO_TSE(1);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    ECO_TSE(2 + i);
     // the destination of this 32-row tile (wave-uniform): `act`, or a sibling's own tensor (values selected, never a
     // run-time index into the kernel argument struct: that would copy it to scratch memory)
     const int mt = mw + i * 32;
@@ -479,11 +464,7 @@ __device__ __forceinline__ int convb_epilogue_lean(const ConvBArgs& a, f32x16 (&
   const bool ok = n_lane < a.ntot;
   const unsigned nn = ok ? (unsigned)n_lane : 0u;
   const int img = (int)fastdiv(nn, d_sout), sp = (int)(nn - (unsigned)img * (unsigned)a.s_out);
-#ifdef ECO_EPI_PROBE_NOSTORE
-  constexpr unsigned kAll = 0u;
-#else
   constexpr unsigned kAll = 0x7fffffffu;
-#endif
   const unsigned v_plain = ok ? (unsigned)(view_base(a.act, img, sp) * 16) : kBufOob;
   float4 ps[2][4], ph[2][4];
   auto load_params = [&](int i, int slot) {
@@ -1186,16 +1167,8 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
           else if (sp_pieces == kCbs) wait_dma_all_but<2 * A_PER_WAVE + kCbs>();
           else wait_dma_all_but<2 * A_PER_WAVE + 2 * kCbs>();
         }
-#if !defined(ECO_SPAN_PROBE) || !(ECO_SPAN_PROBE & 1)   // probe builds (tools/exp): bit 0 = no barrier per tap
         wg_barrier_nodrain();
-#endif
-#if defined(ECO_SPAN_PROBE) && (ECO_SPAN_PROBE & 2)     // bit 1 = no operand DMA after the prologue
-        if (a.ntot < 0)
-#endif
         if (t2 == 0 && next_group) issue_span(g + 1, sbuf ^ 1);
-#if defined(ECO_SPAN_PROBE) && (ECO_SPAN_PROBE & 2)
-        if (a.ntot < 0)
-#endif
         if (s + D < total) {
           const int t2n = (t2 + D) % T2;
           issue_weights(t2 + D < T2 ? g : g + 1, t2n, (abuf + D) % kSpanNbuf);
@@ -1214,18 +1187,10 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
         // eight MFMAs of k-step ks.
         uint4 af[2][TM], bf[2][TN];
         auto read_frags = [&](int slot, int ks) {
-#if defined(ECO_SPAN_PROBE) && (ECO_SPAN_PROBE & 8)     // bit 3 = no fragment reads (operands = whatever the registers hold)
-#pragma unroll
-          for (int i = 0; i < TM; ++i) { af[slot][i] = make_uint4(0x3f803f80u, 0u, 0u, 0u); ECO_OPAQUE(af[slot][i].y); }
-#pragma unroll
-          for (int j = 0; j < TN; ++j) { bf[slot][j] = make_uint4(0x3f803f80u, 0u, 0u, 0u); ECO_OPAQUE(bf[slot][j].y); }
-          (void)Ab; (void)Bb; (void)ks;
-#else
 #pragma unroll
           for (int i = 0; i < TM; ++i) af[slot][i] = Ab[(2 * ks + half) * BMP + (wm * TM + i) * 32 + l31];
 #pragma unroll
           for (int j = 0; j < TN; ++j) bf[slot][j] = Bb[(2 * ks + half) * SPAN + (wn * TN + j) * 32 + l31];
-#endif
         };
         read_frags(0, 0);
 #pragma unroll
@@ -1234,22 +1199,13 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
           sched_fence();
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-#if !defined(ECO_SPAN_PROBE) || !(ECO_SPAN_PROBE & 4)     // bit 2 = no tap masks on the fragments
             uint4& q = bf[ks & 1][j];
             q = make_uint4(q.x & okm[j], q.y & okm[j], q.z & okm[j], q.w & okm[j]);
-#endif
           }
-#if defined(ECO_SPAN_PROBE) && (ECO_SPAN_PROBE & 32)    // bit 5 = no MFMAs (the skeleton alone: DMA, waits, barriers, reads, masks)
-#pragma unroll
-          for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[ks & 1][i].x), "v"(af[ks & 1][i].y), "v"(af[ks & 1][i].z), "v"(af[ks & 1][i].w));
-#pragma unroll
-          for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bf[ks & 1][j].x), "v"(bf[ks & 1][j].y), "v"(bf[ks & 1][j].z), "v"(bf[ks & 1][j].w));
-#else
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16_bf16(af[ks & 1][i], bf[ks & 1][j], acc[i][j]);
-#endif
           sched_fence();
         }
         abuf = abuf == kSpanNbuf - 1 ? 0 : abuf + 1;
@@ -1257,15 +1213,6 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
     }
   }
   if (total <= 0) __syncthreads();   // (no stage ran: Ep has not been published by a barrier yet)
-#if defined(ECO_SPAN_PROBE) && (ECO_SPAN_PROBE & 16)      // bit 4 = no epilogue (accumulators kept live, nothing stored)
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
-  if (a.ntot < 0)
-#endif
   if (a.ksplit > 1)
     convb_store_partial<TM, TN>(a, acc, slice, m0 + wm * TM * 32, n0 + wn * TN * 32, half, l31);
   else
@@ -1290,22 +1237,6 @@ __global__ __launch_bounds__(256, 2) void convb_span_kernel(const ConvBArgs a, c
 //     issue slot actually issued.
 // Tiles: 32*TM channels x 256 positions, four waves side by side in N, as before.  Items = (slice, tile); with split-K an
 // item ends in partial sums instead of the epilogue.
-#ifndef ECO_SPANP_PROBE
-#define ECO_SPANP_PROBE 0
-#endif
-#ifdef ECO_SPANP_TS   // probe builds (tools/exp/spanp_ts.py): cycle stamps of waves 0 and 3 of the first 64 workgroups
-__device__ unsigned long long eco_spanp_ts[64 * 2 * 8 * 32];
-extern "C" int eco_spanp_ts_read(void* host) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(eco_spanp_ts), sizeof(eco_spanp_ts));
-}
-#define ECO_TS(slot)                                                                                              \
-  do {                                                                                                            \
-    if ((wave == 0 || wave == 3) && ts_item < 8 && lane == 0)                                                     \
-      ts_l[((wave ? 1 : 0) * 8 + ts_item) * 32 + (slot)] = __builtin_readcyclecounter();                          \
-  } while (0)
-#else
-#define ECO_TS(slot) do { } while (0)
-#endif
 struct SpanPArgs {
   unsigned x_bytes, wp_bytes;
   int ntiles;                      // nblk_m * nblk_n
@@ -1332,11 +1263,6 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
   static_assert(T2 % NB == 0, "a group must start at ring slot 0");
 
   __shared__ __attribute__((aligned(16))) float Ep[3 * BMP];   // bias / BN scale / BN shift of this workgroup's rows
-#ifdef ECO_SPANP_TS
-  __shared__ unsigned long long ts_l[2 * 8 * 32];
-  int ts_item = 0;
-  for (int q = (int)threadIdx.x; q < 2 * 8 * 32; q += 256) ts_l[q] = 0ull;
-#endif
   ECO_DYNAMIC_LDS(lds_f);
   uint4* const Aw = (uint4*)lds_f;                 // [NB][kCbs][BMP]
   uint4* const Bsp = Aw + NB * kCbs * BMP;         // [2][kCbs][SPITCH]
@@ -1541,9 +1467,7 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
       auto resolve_next = [&]() {                      // the next item's lane state and first (channel group, depth tap)
         have_next = have_next_item;
         if (have_next_item) {
-#if !(ECO_SPANP_PROBE & 64)      // bit 6 = no per-item index arithmetic (the first item's lane state is reused: wrong results)
           nxt = make_item(nitem);                      // VALU under the DMA / the other workgroup's MFMAs
-#endif
           ncg = (int)fastdiv((unsigned)nxt.g_begin, pa.d_kd);
           nz = nxt.g_begin - ncg * a.kd;
         }
@@ -1568,10 +1492,8 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
 #if defined(ECO_SPANP_PRIO) && !defined(ECO_EMU)
           if ((xx ^ y ^ prio_half) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
-          if (g == cur.g_begin && t2 < 6) ECO_TS(1 + 3 * t2);
           if (stores) { wait_newest_behind_stores(newest, stores); stores = 0; }
           else wait_newest(newest);
-          if (g == cur.g_begin && t2 < 6) ECO_TS(2 + 3 * t2);
           // Dynamic items: the next item's ticket is drawn here, at the first tap of this item's last group -- the last moment
           // that keeps the next item's span and first weights in flight under this group -- by wave 0 on the scalar unit
           // (s_atomic_add: ~600 cycles, nothing in the vector memory counter; the other waves meet it at the barrier below).
@@ -1590,10 +1512,7 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // written before the (non-draining) barrier below
 #endif
           }
-#if !(ECO_SPANP_PROBE & 1)      // probe builds (tools/exp): bit 0 = no barrier per tap
           wg_barrier_nodrain();
-#endif
-          if (g == cur.g_begin && t2 < 6) ECO_TS(3 + 3 * t2);
           if (xx == 0 && y == 0 && last_group && dynamic) {   // behind this barrier thread 0's next_id[0] is visible
             nitem = uniform(next_id[0]);
             have_next_item = nitem < pa.nitems;
@@ -1602,78 +1521,42 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
             nstage0 = ncg * a.taps + nz * T2;
           }
           int cnt = 0;
-#if ECO_SPANP_PROBE & 2         // bit 1 = no operand DMA after the prologue
-          if (a.ntot < 0) {
-#endif
           if (xx == 0 && y == 0 && have_next) { issue_span(nsv0, nsv1, nsd0, nsd1, ncg, nz, sbuf ^ 1); cnt += SPW; }
           if (t2 + 2 < T2) { issue_weights(stage0 + t2 + 2, (xx + 2) % NB); cnt += APW; }
           else if (have_next) { issue_weights(nstage0 + t2 + 2 - T2, (xx + 2) % NB); cnt += APW; }
-#if ECO_SPANP_PROBE & 2
-          }
-#endif
           newest = cnt;
           sched_fence();
-          if (g == cur.g_begin && t2 == 4) ECO_TS(28);   // DMA issued
           const uint4* Ab = Aw + abuf * kCbs * BMP + a_lane;
           const uint4* Bb = brow + xx;
           uint4 af[2][TM], bf[2][TN];
           auto read_frags = [&](int slot, int ks) {
-#if ECO_SPANP_PROBE & 8         // bit 3 = no fragment reads
-#pragma unroll
-            for (int i = 0; i < TM; ++i) { af[slot][i] = make_uint4(0x3f803f80u, 0u, 0u, 0u); ECO_OPAQUE(af[slot][i].y); }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) { bf[slot][j] = make_uint4(0x3f803f80u, 0u, 0u, 0u); ECO_OPAQUE(bf[slot][j].y); }
-            (void)Ab; (void)Bb; (void)ks;
-#else
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[slot][i] = Ab[2 * ks * BMP + i * 32];
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[slot][j] = Bb[2 * ks * SPITCH + j * 32];
-#endif
           };
           read_frags(0, 0);
-          if (g == cur.g_begin && t2 == 4) ECO_TS(29);   // first fragments landed (the stamp waits lgkmcnt(0))
 #pragma unroll
           for (int ks = 0; ks < kCbs / 2; ++ks) {
             if (ks + 1 < kCbs / 2) read_frags((ks + 1) & 1, ks + 1);
             sched_fence();
-#if !(ECO_SPANP_PROBE & 4)      // bit 2 = no tap masks
 #pragma unroll
             for (int j = 0; j < TN; ++j) {   // all-ones where this tap is inside the plane (an AND per dword: no exec-masked reads)
               const unsigned okm = (unsigned)((int)(rmask[j] << (31 - xx)) >> 31);
               uint4& q = bf[ks & 1][j];
               q = make_uint4(q.x & okm, q.y & okm, q.z & okm, q.w & okm);
             }
-#endif
-#if ECO_SPANP_PROBE & 32        // bit 5 = no MFMAs (the skeleton alone)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[ks & 1][i].x), "v"(af[ks & 1][i].y), "v"(af[ks & 1][i].z), "v"(af[ks & 1][i].w));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bf[ks & 1][j].x), "v"(bf[ks & 1][j].y), "v"(bf[ks & 1][j].z), "v"(bf[ks & 1][j].w));
-#else
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
               for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16_bf16(af[ks & 1][i], bf[ks & 1][j], acc[i][j]);
-#endif
             sched_fence();
           }
-          if (g == cur.g_begin && t2 == 4) ECO_TS(30);   // MFMAs issued
         });
       }
       sbuf ^= 1;
       cg = ncg; z = nz;
     }
-#if ECO_SPANP_PROBE & 16          // bit 4 = no epilogue (accumulators kept live, nothing stored)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
-    if (a.ntot < 0)
-#endif
-    ECO_TS(19);
     if (cur.slice >= 0) {
       if (a.ws_frag) stores = convb_store_partial_frag<TM>(a, acc, cur.slice, cur.tile, wave, lane, rws);   // (counted: stepped over)
       else {   // (compiler-counted stores: the next wait drains them.  The row offset is made opaque here: as a loop invariant its
@@ -1687,26 +1570,12 @@ __global__ __launch_bounds__(256, 2) void convb_spanp_kernel(const ConvBArgs a, 
     if (a.lean)
       stores = convb_epilogue_lean<TM, false>(a, acc, m0, m0, cur.n0 + wave * 64 + lane, half, Ep, BMP, pa.d_sout);
     else
-#ifdef ECO_SPANP_TS
-      stores = convb_epilogue_wide<TM>(a, acc, m0, m0, cur.n0 + wave * 64 + lane, half, Ep, BMP, pa.d_sout,
-                                       ((wave == 0 || wave == 3) && ts_item < 8 && lane == 0) ? &ts_l[((wave ? 1 : 0) * 8 + ts_item) * 32] : nullptr);
-#else
       stores = convb_epilogue_wide<TM>(a, acc, m0, m0, cur.n0 + wave * 64 + lane, half, Ep, BMP, pa.d_sout);
-#endif
-    ECO_TS(20);
-#ifdef ECO_SPANP_TS
-    ++ts_item;
-#endif
     if (!have_next_item) break;
     cur = nxt;
     item = nitem;
   }
   leave();
-#ifdef ECO_SPANP_TS
-  __syncthreads();
-  if (bx < 64)
-    for (int q = tid; q < 2 * 8 * 32; q += 256) eco_spanp_ts[bx * (2 * 8 * 32) + q] = ts_l[q];
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2169,9 +2038,7 @@ extern "C" int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t
     if (tiles > cus && r > 0 && kb >= 2 && pays && r % ceil_div(g->cout, bm) == 0) {
       plan->tail_tiles = (int)r;
       plan->tail_ksplit = (int)kb;
-      const long tail_pos = ntot - (ceil_div(ntot, plan->bn) - r / ceil_div(g->cout, bm)) * plan->bn;
       plan->ws_bytes = (int64_t)kb * r * bm * plan->bn * 4;
-      (void)tail_pos;
     }
   }
 #ifdef ECO_CONVB_KSPLIT_ENV   // experiment builds only (tools/exp): the K-split tail as "tiles,slices" from the environment
@@ -2286,20 +2153,18 @@ static int launch_convb_span(const ConvBArgs& a, int span_pieces, hipStream_t st
   return check_launch("eco_convb_forward");
 }
 
-// Work counters of the persistent kernel's dynamic item distribution: 256 launches' worth (a launch takes the next slot;
-// its last workgroup clears it again), zero at module load.  A launch sequence number picks the slot, so launches in
-// flight on different streams use different slots; a captured graph keeps the slots it was captured with.
+// Work counters of the persistent kernel's dynamic item distribution: 256 slots of 8 counters, zero at module load; a launch's
+// last workgroup clears its slot again.  Eager launches take ONE slot per stream (launches of a stream run in order; up to 64
+// streams, then static shares), launches recorded by a stream capture take slots 64 .. 255 in turn and the graph keeps them
+// (round-4 advisor: a sequence number modulo 256 let a replaying graph and eager launches on another stream meet in one slot).
+// The bound that remains is stated in include/eco_hip.h ("work counters"); eco_counters_reset() clears both arrays.
 #ifdef ECO_EMU
 static unsigned eco_spanp_counters[256 * 8];
-static unsigned* spanp_counter_slot() {
-  static std::atomic<unsigned> seq{0};
-  return eco_spanp_counters + 8 * (seq.fetch_add(1) % 256u);
-}
+static unsigned* spanp_counter_base() { return eco_spanp_counters; }
 #else
 __device__ unsigned eco_spanp_counters[256 * 8];
-static unsigned* spanp_counter_slot() {
+static unsigned* spanp_counter_base() {
   static unsigned* base[64] = {nullptr};
-  static std::atomic<unsigned> seq{0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   if (!base[dev]) {
@@ -2307,9 +2172,28 @@ static unsigned* spanp_counter_slot() {
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(eco_spanp_counters)) != hipSuccess) return nullptr;
     base[dev] = (unsigned*)p;
   }
-  return base[dev] + 8 * (seq.fetch_add(1) % 256u);
+  return base[dev];
 }
 #endif
+static unsigned* spanp_counter_slot(void* stream) {
+  unsigned* base = spanp_counter_base();
+  const int slot = counter_slot_index(stream);       // one per stream, or the capture ring; -1: static shares
+  return (base && slot >= 0) ? base + 8 * slot : nullptr;
+}
+namespace eco {
+int spanp_counters_reset(void* stream) {
+  unsigned* base = spanp_counter_base();
+  if (!base) return fail(ECO_ERR_RUNTIME, "counters_reset: no device");
+#ifdef ECO_EMU
+  (void)stream;
+  memset(base, 0, sizeof(unsigned) * 256 * 8);
+#else
+  if (hipMemsetAsync(base, 0, sizeof(unsigned) * 256 * 8, (hipStream_t)stream) != hipSuccess)
+    return fail(ECO_ERR_RUNTIME, "counters_reset: hipMemsetAsync failed");
+#endif
+  return ECO_OK;
+}
+}  // namespace eco
 static bool spanp_dynamic() {
   static const int on = [] { const char* e = getenv("ECO_SPANP_DYNAMIC"); return (e && e[0] == '0') ? 0 : 1; }();
   return on != 0;
@@ -2339,7 +2223,7 @@ static int launch_convb_spanp(const ConvBArgs& a, const eco_convb_plan* plan, hi
   {
     const long groups_per_item = (long)(a.nstages / a.taps) * a.kd / (pa.kb > 1 && pa.t_main == 0 ? pa.kb : 1);
     const bool worth = groups_per_item * 9 >= 54 || (long)pa.nitems >= 16l * plan->pgrid;
-    pa.ctr = (spanp_dynamic() && worth && a.nblk_m <= 4 && plan->pgrid % a.nblk_m == 0) ? spanp_counter_slot() : nullptr;
+    pa.ctr = (spanp_dynamic() && worth && a.nblk_m <= 4 && plan->pgrid % a.nblk_m == 0) ? spanp_counter_slot((void*)stream) : nullptr;
   }
   pa.d_sout = fastdiv_make((unsigned)a.s_out);
   pa.d_hw = fastdiv_make((unsigned)(a.Hi * a.Wi));

@@ -22,6 +22,13 @@ inline int check_launch(const char* what) {
 
 inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
 
+// Work-counter slot (0 .. 255) of a dynamic-share launch on `stream`, or -1 (the launch then takes static shares):
+// eager launches get ONE slot per stream -- launches of a stream run in order, and a launch's last workgroup leaves the
+// slot zero for the next -- for up to 64 distinct streams; launches recorded by a stream capture take slots 64 .. 255 in
+// turn (a captured graph keeps its slots and may be replayed on any stream, next to eager launches).  include/eco_hip.h,
+// "work counters", states the bound this leaves.
+int counter_slot_index(void* stream);
+
 // Compute units of the calling thread's current device (plans with num_cu = 0 are sized for it).
 inline int current_device_num_cu() {
 #ifdef ECO_EMU

@@ -369,7 +369,9 @@ __global__ __launch_bounds__(1024) void global_avgpool_fc_kernel(const float* x,
   const long fstride = (long)c * s;
   // one channel per wave at a time; a lane owns positions lane, lane+64, ... of each of the t frames (no division in
   // the loop, four independent partial sums so that four loads are in flight)
-  // single-frame volumes of at most 256 positions (the 3-D tail: 4 x 7 x 7, 8 x 7 x 7): four channels of the wave at a time,
+  // single-frame volumes of 65 .. 256 positions (the 3-D tail at num_segments 16: 4 x 7 x 7 = 196; the 8 x 7 x 7 = 392 of
+  // num_segments 32 takes the one-channel loop below, as do the c % 16 remainder channels -- whose four partial sums are
+  // combined in another order: same value to fp32 rounding, not bit-identical across c % 16): four channels of the wave at a time,
   // all sixteen loads issued before the first butterfly -- one channel at a time the loop was a chain of L2 round trips
   // (57 us of the 1.2 ms online step for a single clip's 512 x 196 volume, round 3)
   int ch = wave;

@@ -76,12 +76,7 @@ constexpr bool stem_types_ok() {
 }
 static_assert(stem_types_ok(), "every k-step's half-wave offset difference is one of the five known constants");
 
-#if defined(ECO_STEM_PROBE) && (ECO_STEM_PROBE & 4)   // bit 2: per-phase s_memtime stamps of the first patches (tools/exp)
-__device__ unsigned long long g_stem_ts[1024 * 64];
-#define STEM_STAMP(slot) do { if (tid == 0 && stamp_n < 64) g_stem_ts[(long)blockIdx.x * 64 + stamp_n++] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
 #define STEM_STAMP(slot) do { } while (0)
-#endif
 
 struct StemArgs {
   const float* x;        // [n][3][H][W]
@@ -244,7 +239,6 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
     for (int j = 0; j < 4; ++j) bf[0][j] = Xs[pb[stem_type(0)][j] + stem_imm(0)];
     // unrolled over the 74 k-steps with the step as a compile-time constant (a `#pragma unroll` loop leaves the tap
     // tables as run-time arithmetic until after the unroller has priced -- and refused -- the body)
-#if !defined(ECO_STEM_PROBE) || !(ECO_STEM_PROBE & 1)   // probe builds (tools/exp/stem_probe.sh): bit 0 drops the reduction
     static_for<kStemKP>([&](auto KP) __attribute__((always_inline)) {
       constexpr int kp = decltype(KP)::value;
       constexpr int cur = kp & 1;
@@ -262,7 +256,6 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma_32x32x2(af[cur][i], bf[cur][j], acc[i][j]);
       sched_fence();
     });
-#endif
     STEM_STAMP(1);
     __syncthreads();   // every wave is done with Xs: the space becomes the pooling stage
     STEM_STAMP(2);
@@ -284,17 +277,6 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
         woff[dy * 3 + dx] = (r0 + 2 * ph + dy < a.Ho && q0 + 2 * pw + dx < a.Wo)
                                 ? dy * kStemCQ + (dx & 1) * ((kStemCQ + 1) / 2) + (dx >> 1) : 0;
     float* const yp0 = a.y + (((long)f * a.cout + clo) * a.PHo + gph) * a.PWo + gpw;
-#if defined(ECO_STEM_PROBE) && (ECO_STEM_PROBE & 2)   // bit 1 drops the epilogue (the accumulators stay live)
-    if (a.total < 0) {
-#pragma unroll
-      for (int i = 0; i < TMC; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) st(yp0 + (i * 4 + j) * 16 + r, acc[i][j][r]);
-    }
-    if (a.total >= 0) goto epilogue_done;
-#endif
 #pragma unroll
     for (int i = 0; i < TMC; ++i) {
 #pragma unroll
@@ -321,9 +303,6 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
         __syncthreads();
       }
     }
-#if defined(ECO_STEM_PROBE) && (ECO_STEM_PROBE & 2)
-  epilogue_done:
-#endif
     STEM_STAMP(3);
     if (next >= a.total) break;
     store_patch();
@@ -336,12 +315,6 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
 
 using namespace eco;
 
-#if defined(ECO_STEM_PROBE) && (ECO_STEM_PROBE & 4)
-extern "C" int eco_stem_probe_read(unsigned long long* dst) {
-  hipDeviceSynchronize();
-  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stem_ts), sizeof(g_stem_ts));
-}
-#endif
 
 static int stem_dims(int h, int w, int* ho, int* wo, int* pho, int* pwo) {
   *ho = (h + 6 - 7) / 2 + 1;

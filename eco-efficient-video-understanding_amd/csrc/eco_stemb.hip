@@ -93,19 +93,7 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u16x2(unsigned v) { u16x2 r; memcpy(&r, &v, 4); return r; }
 __device__ __forceinline__ unsigned from_u16x2(u16x2 v) { unsigned r; memcpy(&r, &v, 4); return r; }
 
-#ifdef ECO_STEMB_TS   // probe builds (tools/exp/stemb_ts.py): cycle stamps of waves 0 and 3 of the first 64 workgroups
-__device__ unsigned long long eco_stemb_ts[64 * 2 * 8 * 16];
-extern "C" int eco_stemb_ts_read(void* host) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(eco_stemb_ts), sizeof(eco_stemb_ts));
-}
-#define ECO_SBTS(slot)                                                                                             \
-  do {                                                                                                             \
-    if ((wave == 0 || wave == 3) && ts_item < 8 && lane == 0)                                                      \
-      ts_l[((wave ? 1 : 0) * 8 + ts_item) * 16 + (slot)] = __builtin_readcyclecounter();                           \
-  } while (0)
-#else
 #define ECO_SBTS(slot) do { } while (0)
-#endif
 
 // TMC = cout / 32 (1 or 2 m-tiles; every wave holds all channels of its 128 columns)
 template <int TMC>
@@ -127,11 +115,6 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
   const int wave = uniform(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int tpf = a.tiles_h * a.tiles_w;
-#ifdef ECO_STEMB_TS
-  __shared__ unsigned long long ts_l[2 * 8 * 16];
-  int ts_item = 0;
-  for (int q = tid; q < 2 * 8 * 16; q += 256) ts_l[q] = 0ull;
-#endif
 
 #pragma unroll
   for (int u = 0; u < WU; ++u) {
@@ -181,11 +164,7 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
       const bool before = rok && e < 0;                    // (c = 0, h = 0, w = -3: only column 0 exists)
       const unsigned voff = !rok ? kBufOob : (unsigned)(before ? e + 3 : e) * 4u;
       mk |= before ? 16u << u : 0u;
-#if defined(ECO_STEMB_PROBE) && (ECO_STEMB_PROBE & 8)    // bit 3: no global loads of the frames
-      xv[u] = make_uint4(voff, 1u, 2u, 3u);
-#else
       xv[u] = gld16_buf(rx, voff);
-#endif
     }
     xmask = mk;
   };
@@ -295,7 +274,6 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
     for (int i = 0; i < TMC; ++i) af[0][i] = wl[32 * i];
 #pragma unroll
     for (int j = 0; j < 4; ++j) bf[0][j] = lds_ld16_a4(Xs + pb[sb_type(0)][j] + sb_tap(0));
-#if !defined(ECO_STEMB_PROBE) || !(ECO_STEMB_PROBE & 1)   // probe builds (tools/exp): bit 0 drops the reduction
     static_for<kSbSteps>([&](auto S) __attribute__((always_inline)) {
       constexpr int s = decltype(S)::value;
       constexpr int cur = s & 1;
@@ -313,18 +291,12 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma_32x32x16_bf16(af[cur][i], bf[cur][j], acc[i][j]);
       sched_fence();
     });
-#endif
     ECO_SBTS(1);
     if (next < a.total) draw();   // the patch after `next`
     __syncthreads();   // every wave is done with Xs: the next patch may land
     ECO_SBTS(2);
     const int next2 = !dynamic ? next + (int)gridDim.x : next < a.total ? uniform(next_patch) : a.total;
     if (next < a.total) {
-#ifdef ECO_STEMB_TS
-#pragma unroll
-      for (int u = 0; u < XU4; ++u) asm volatile("" ::"v"(xv[u].x), "v"(xv[u].y), "v"(xv[u].z), "v"(xv[u].w));   // the loads' wait, on its own
-      ECO_SBTS(13);
-#endif
       store_patch();
       ECO_SBTS(14);
     }
@@ -350,13 +322,6 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
                                 ? dy * kSbCQ + (dx & 1) * ((kSbCQ + 1) / 2) + (dx >> 1) : 0;
     uint4* const yp0 = a.y + (((long)f * cblocks + clo) * a.PHo + gph) * a.PWo + gpw;   // block clo of m-tile 0
     const long yblk = (long)a.PHo * a.PWo;
-#if defined(ECO_STEMB_PROBE) && (ECO_STEMB_PROBE & 2)    // bit 1: no epilogue at all (the accumulators stay live)
-#pragma unroll
-    for (int i = 0; i < TMC; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-    if (a.total >= 0) { if (next >= a.total) break; patch = next; next = next2; continue; }
-#endif
     ECO_SBTS(4);
     static_for<TMC>([&](auto I) __attribute__((always_inline)) {
       constexpr int i = decltype(I)::value;
@@ -374,9 +339,6 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
       ECO_SBTS(5 + 4 * i);
       __syncthreads();
       ECO_SBTS(6 + 4 * i);
-#if defined(ECO_STEMB_PROBE) && (ECO_STEMB_PROBE & 4)    // bit 2: stage written, no pooling / stores
-      if (a.total < 0)
-#endif
       if (pool_thread) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -417,9 +379,6 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
       __syncthreads();
       ECO_SBTS(8 + 4 * i);
     });
-#ifdef ECO_STEMB_TS
-    ++ts_item;
-#endif
     if (next >= a.total) break;
     patch = next;
     next = next2;
@@ -428,11 +387,6 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
     const unsigned gone = counter_fetch_add(a.ctr + 1, 1u);
     if (gone == gridDim.x - 1u) { counter_store(a.ctr, 0u); counter_store(a.ctr + 1, 0u); }
   }
-#ifdef ECO_STEMB_TS
-  __syncthreads();
-  if (blockIdx.x < 64)
-    for (int q = tid; q < 2 * 8 * 16; q += 256) eco_stemb_ts[blockIdx.x * (2 * 8 * 16) + q] = ts_l[q];
-#endif
 }
 
 }  // namespace eco
@@ -454,19 +408,15 @@ static unsigned short stemb_bf16(float f) {   // round to nearest even, as the d
   return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-// Work counters of the dynamic patch distribution (as eco_spanp_counters in eco_blocked.hip): a launch takes the next of 256
-// slots, its last workgroup clears it again.
+// Work counters of the dynamic patch distribution (as eco_spanp_counters in eco_blocked.hip): one slot per stream (or the
+// capture ring), cleared again by the launch's last workgroup.
 #ifdef ECO_EMU
 static unsigned eco_stemb_counters[256 * 2];
-static unsigned* stemb_counter_slot() {
-  static std::atomic<unsigned> seq{0};
-  return eco_stemb_counters + 2 * (seq.fetch_add(1) % 256u);
-}
+static unsigned* stemb_counter_base() { return eco_stemb_counters; }
 #else
 __device__ unsigned eco_stemb_counters[256 * 2];
-static unsigned* stemb_counter_slot() {
+static unsigned* stemb_counter_base() {
   static unsigned* base[64] = {nullptr};
-  static std::atomic<unsigned> seq{0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   if (!base[dev]) {
@@ -474,9 +424,28 @@ static unsigned* stemb_counter_slot() {
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(eco_stemb_counters)) != hipSuccess) return nullptr;
     base[dev] = (unsigned*)p;
   }
-  return base[dev] + 2 * (seq.fetch_add(1) % 256u);
+  return base[dev];
 }
 #endif
+static unsigned* stemb_counter_slot(void* stream) {
+  unsigned* base = stemb_counter_base();
+  const int slot = counter_slot_index(stream);       // one per stream, or the capture ring; -1: static shares
+  return (base && slot >= 0) ? base + 2 * slot : nullptr;
+}
+namespace eco {
+int stemb_counters_reset(void* stream) {
+  unsigned* base = stemb_counter_base();
+  if (!base) return fail(ECO_ERR_RUNTIME, "counters_reset: no device");
+#ifdef ECO_EMU
+  (void)stream;
+  memset(base, 0, sizeof(unsigned) * 256 * 2);
+#else
+  if (hipMemsetAsync(base, 0, sizeof(unsigned) * 256 * 2, (hipStream_t)stream) != hipSuccess)
+    return fail(ECO_ERR_RUNTIME, "counters_reset: hipMemsetAsync failed");
+#endif
+  return ECO_OK;
+}
+}  // namespace eco
 
 extern "C" int64_t eco_stemb_weight_elems(int32_t cout) { return (int64_t)kSbSteps * 2 * cout * 8; }
 
@@ -514,7 +483,7 @@ extern "C" int eco_stemb_forward(const float* x, const void* wp, const float* bi
   const long cap = max_workgroups ? max_workgroups : 2l * current_device_num_cu();
   const long grid = total < cap ? total : cap;
   static const int dyn = [] { const char* e = getenv("ECO_STEMB_DYNAMIC"); return (e && e[0] == '0') ? 0 : 1; }();
-  a.ctr = (dyn && total > 2 * grid) ? stemb_counter_slot() : nullptr;   // (worth a draw per patch only with several patches per workgroup)
+  a.ctr = (dyn && total > 2 * grid) ? stemb_counter_slot(stream) : nullptr;   // (worth a draw per patch only with several patches per workgroup)
   const size_t lds = (size_t)kSbRows * kSbRowBytes + (size_t)kSbSteps * 2 * cout * 16 + sizeof(float) * (size_t)(2 * cout + 16 * (kSbNPos + 3));
   hipStream_t s = (hipStream_t)stream;
   if (cout == 64) ECO_RAISE_DYNAMIC_LDS(stemb_kernel<2>, "stemb");

@@ -154,15 +154,8 @@ __global__ __launch_bounds__(256, 2) void wgemm_kernel(const WGemmArgs a) {
     if (s_begin + 1 < s_end) issue_stage(1);
     int buf = 0;
     for (int s = s_begin; s < s_end; ++s) {
-#if defined(ECO_WGEMM_PROBE) && (ECO_WGEMM_PROBE & 2)   // probe builds (tools/exp): bit 1 = no barrier / DMA wait per stage
-      if (s == s_begin) { wait_dma_all_but<0>(); wg_barrier_nodrain(); }
-#else
       if (s + 1 < s_end) wait_dma_all_but<P>(); else wait_dma_all_but<0>();
       wg_barrier_nodrain();
-#endif
-#if defined(ECO_WGEMM_PROBE) && (ECO_WGEMM_PROBE & 1)   // bit 0 = no operand DMA after the first two stages
-      if (false)
-#endif
       if (s + 2 < s_end) issue_stage(buf == 0 ? 2 : buf - 1);   // (buf + 2) % 3: last read before this barrier
       sched_fence();
       compute(buf);
@@ -589,24 +582,13 @@ __global__ __launch_bounds__(256, ECO_WFUSED_OCC) void wfused_kernel(const WFuse
 
   float4 ra[R][CH / 4], rb[R][CH / 4];
   auto issue = [&](int slot, int t) {    // chunk t: point index t / NCH = 3*group + k, local point lp = wave + 4*k
-#if defined(ECO_WFUSED_PROBE) && (ECO_WFUSED_PROBE & 1)   // probe builds (tools/exp): bit 0 = every chunk re-reads one of the first R (cache hits)
-    t = t % R;
-#endif
     const int pi = t / NCH, c = t % NCH;
     const int lp = wave + 4 * (pi % 3), rr = lp >= 6 ? 1 : 0;
     const int g = pi / 3;                // group g holds transform rows (1, 2), (3, 4), (0, 5): see the fold below
     const int p = 6 * (g == 0 ? 1 + rr : g == 1 ? 3 + rr : 5 * rr) + lp - 6 * rr;
     // wave-uniform bases (SALU) + this lane's constant byte offset: no per-lane address arithmetic per load
     const float* us = a.u + (long)p * a.u_pstride + ((long)mb * KP + c * CH) * 64;
-#if defined(ECO_WFUSED_PROBE) && (ECO_WFUSED_PROBE & 32)   // bit 5 = waves 2k and 2k+1 load the same V rows (does the L1 merge them?)
-    const int lpv = (wave & ~1) + 4 * (pi % 3), rrv = lpv >= 6 ? 1 : 0;
-    const int pv = 6 * (g == 0 ? 1 + rrv : g == 1 ? 3 + rrv : 5 * rrv) + lpv - 6 * rrv;
-    const float* vs = a.v + (long)pv * a.v_pstride + ((long)(c * (CH / 4)) * a.Q + n0) * 8;
-#elif defined(ECO_WFUSED_PROBE) && (ECO_WFUSED_PROBE & 64)   // bit 6 = ... the same U rows
     const float* vs = a.v + (long)p * a.v_pstride + ((long)(c * (CH / 4)) * a.Q + n0) * 8;
-#else
-    const float* vs = a.v + (long)p * a.v_pstride + ((long)(c * (CH / 4)) * a.Q + n0) * 8;
-#endif
 #pragma unroll
     for (int k4 = 0; k4 < CH / 4; ++k4) ra[slot][k4] = ld_su<float4>(us + k4 * 256, a_voff);
 #pragma unroll
@@ -623,32 +605,15 @@ __global__ __launch_bounds__(256, ECO_WFUSED_OCC) void wfused_kernel(const WFuse
 #pragma unroll
     for (int k4 = 0; k4 < CH / 4; ++k4) {
       const float4 av = ra[t % R][k4], bv = rb[t % R][k4];
-#if defined(ECO_WFUSED_PROBE) && (ECO_WFUSED_PROBE & 2)   // bit 1 = one MFMA per chunk piece instead of four
-      acc = mfma_32x32x2(av.x + av.y + av.z + av.w, bv.x + bv.y + bv.z + bv.w, (t % NCH == 0 && k4 == 0) ? kZero16 : acc);
-#else
       // a point's first product takes the constant 0 as its C operand: no 16 v_mov per point to clear the accumulator
       acc = mfma_32x32x2(av.x, bv.x, (t % NCH == 0 && k4 == 0) ? kZero16 : acc);
       acc = mfma_32x32x2(av.y, bv.y, acc);
       acc = mfma_32x32x2(av.z, bv.z, acc);
       acc = mfma_32x32x2(av.w, bv.w, acc);
-#endif
     }
     sched_fence();
     if constexpr (t + R < T) issue(t % R, t + R);
     sched_fence();
-#if defined(ECO_WFUSED_PROBE) && (ECO_WFUSED_PROBE & 8)     // bit 3 = no LDS parking, no barriers, no fold
-    if constexpr (t % NCH == NCH - 1) {
-      asm volatile("" ::"v"(acc));       // the products stay live, nothing is emitted
-      if constexpr (t == T - 1) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) s4[u][i][j] = acc[(4 * u + i + j) & 15];
-      }
-    }
-#else
     if constexpr (t % NCH == NCH - 1) {
       constexpr int pi = t / NCH;
       const int lp = wave + 4 * (pi % 3);
@@ -667,12 +632,6 @@ __global__ __launch_bounds__(256, ECO_WFUSED_OCC) void wfused_kernel(const WFuse
           for (int j = 0; j < 6; ++j) {
             const float ma = lds[((j * 32) + mrow0 + 8 * u) * 32 + col];
             const float mb2 = lds[(((6 + j) * 32) + mrow0 + 8 * u) * 32 + col];
-#if defined(ECO_WFUSED_PROBE) && (ECO_WFUSED_PROBE & 128)   // bit 7 = half of the partial transform's registers (timing only)
-            if (g == 0) { s4[u][0][j] = ma + mb2; s4[u][1][j] = ma - mb2; }
-            else if (g == 1) { s4[u][0][j] += ma + mb2; s4[u][1][j] += 2.0f * (ma - mb2); }
-            else { s4[u][2][j] = s4[u][0][j] + 4.0f * ma; s4[u][3][j] = s4[u][1][j] + mb2; }
-            continue;
-#endif
             if (g == 0) {          // rows 1, 2
               const float t1 = ma + mb2, t2 = ma - mb2;
               s4[u][0][j] = t1; s4[u][1][j] = t2; s4[u][2][j] = t1; s4[u][3][j] = t2;
@@ -686,19 +645,9 @@ __global__ __launch_bounds__(256, ECO_WFUSED_OCC) void wfused_kernel(const WFuse
         if (g < 2) __syncthreads();
       }
     }
-#endif
   });
   const int tpp = a.o.TH * a.o.TW;
   const int r = n0 + col;
-#if defined(ECO_WFUSED_PROBE) && (ECO_WFUSED_PROBE & 16)   // bit 4 = no second transform half / epilogue / stores
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(s4[u][i][j]));   // the fold stays live
-  if (a.o.NB < 0)
-#endif
   if (r < a.o.NB) {
     const int img = r / tpp, tt = r - img * tpp;
     const int th = tt / a.o.TW, tw = tt - th * a.o.TW;

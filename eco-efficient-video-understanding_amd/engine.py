@@ -642,11 +642,13 @@ class Engine:
                 self._add(i, f"{label} [36 transformed-domain GEMMs, K = {cin}, + winograd {tag} output transform]",
                           lambda s, plan=plan, v=v, up=up, H=H, W=W, ep=ep: lib.wfused_forward(plan, v, up, H, W, ep, s),
                           {"kernel": "eco::wfused_kernel", "flops": 2 * 36 * tiles * cout * cin,
+                           "useful_flops": 2 * 36 * (n * D * H * W / 16.0) * cout * cin,   # without the tiles' overhang
                            "bytes": v_bytes + 4 * 36 * cout * cin + nbytes - 4 * (n * cin * D * H * W + 9 * cin * cout)})
                 return
             self._add(i, f"{label} [36 transformed-domain GEMMs, K = {cin * kd}]", lambda s, plan=plan, v=v, up=up, m=m:
                       lib.wgemm_forward(plan, v, up, m, s),
                       {"kernel": hip.wgemm_kernel_name(plan), "flops": 2 * 36 * tiles * cout * cin * kd,
+                       "useful_flops": 2 * 36 * (n * D * H * W / 16.0) * cout * cin * kd,
                        "bytes": v_bytes + 4 * 36 * cout * cin * kd + m_bytes})
             self._add(i, f"{label} [winograd {tag} output transform]", lambda s, plan=plan, m=m, H=H, W=W, ep=ep:
                       lib.wino_output_dm_forward(plan, m, H, W, ep, s),

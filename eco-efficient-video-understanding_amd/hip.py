@@ -231,6 +231,7 @@ _SIGNATURES = {
     "eco_wgemm_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eco_wino_output_dm_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_int32, C.c_int32,
                                              C.POINTER(ConvEpilogue), C.c_void_p]),
+    "eco_counters_reset": (C.c_int, [C.c_void_p]),
     "eco_wino3_weight_transform": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "eco_wino3_lds_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "eco_wino3_input_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
@@ -385,6 +386,10 @@ class EcoLib:
         self._check(self._dll.eco_wgemm_plan_create(n, cin, cout, d, th, tw, kd, points, 0 if num_cu is None else int(num_cu),
                                                     C.byref(p)))
         return p
+
+    def counters_reset(self, stream=None) -> None:
+        """Zero the work counters of the dynamic-share launches (after a faulted kernel; include/eco_hip.h)."""
+        self._check(self._dll.eco_counters_reset(stream))
 
     # -- Winograd F(4x4x4,3x3x3): the 3-D trunk's transforms around the same GEMM (csrc/eco_wino3.hip) --
     def wino3_weight_transform(self, w_host: int, cout: int, cin: int, u_host: int) -> None:

@@ -18,7 +18,8 @@
  *     allocates, or synchronises: the caller owns memory and the stream
  *     (the reference LOG(FATAL)s instead; `eco_last_error()` carries the text a
  *     CHECK would have printed),
- *   - thread-compatible: no global state except the thread-local error string.
+ *   - thread-compatible: no global state except the thread-local error string -- and the two items declared under
+ *     "Process-level state" below (environment switches read once, the work counters of the dynamic-share launches).
  *
  * A second build of the same sources against a CPU fiber emulator
  * (tests/emu/, libeco_emu.so) exports the identical symbols; it exists only so
@@ -72,6 +73,32 @@ int eco_device_pci_bus_id(int device, char* pci, size_t len);
  * built FROM: two builds of identical sources differ in their bytes, not in this digest.  "unknown" when the library
  * was compiled outside csrc/Makefile.  (v17) */
 const char* eco_source_digest(void);
+
+/* ---- Process-level state (everything the library keeps besides the thread-local error string) --------------------
+ *
+ * ENVIRONMENT SWITCHES.  Read with getenv() the first time the path they guard is taken, then cached for the life of the
+ * process; none changes results beyond fp32 summation order, all select between forms that the tests run against the same
+ * oracle (tests/test_fallback_paths.py, on the emulator and on the GPU).  Unset = the default in brackets.
+ *   ECO_SPANP=0           bf16 stride-1 3x3(x3) convolutions on the per-tile span kernel instead of the persistent one [persistent]
+ *   ECO_SPANP_DYNAMIC=0   the persistent kernel's workgroups take equal static item shares instead of drawing from a counter [dynamic]
+ *   ECO_STEMB_DYNAMIC=0   the same for the fused bf16 stem's patches [dynamic]
+ *   ECO_CONVB_DMA_BUF=0   the LDS-DMA kernel addresses its operands with 64-bit flat addresses instead of buffer descriptors
+ *                         (the form views >= 2 GB fall back to by themselves) [descriptors]
+ *   (ECO_CONVB_TAIL / ECO_CONVB_KSPLIT exist in experiment builds compiled with -DECO_CONVB_KSPLIT_ENV only: tools/exp)
+ *   ECO_STREAMK=1         eco_conv_plan_create: stream-K persistent form of the fp32 gather kernel [split-K + reduce launch]
+ * No other entry point reads the environment.
+ *
+ * WORK COUNTERS.  The persistent bf16 kernels (convb_spanp_kernel, stemb_kernel) draw work items from a counter in
+ * device memory that the launch's last workgroup resets to zero.  The counters live in two module-scope arrays of 256
+ * slots per device.  Slot choice: an eager launch uses the one slot of ITS STREAM (launches of one stream execute in
+ * order), for up to 64 distinct streams per process -- a launch on a 65th stream silently takes static shares instead; a
+ * launch recorded during stream capture takes the next of 192 capture slots, and the captured graph keeps them.
+ * What this guarantees: any number of host threads / streams (<= 64) may launch eagerly at the same time, and captured
+ * graphs may replay next to eager launches on other streams.  What it does not: two graphs that together captured more
+ * than 192 dynamic-share launches may hold the same slot -- replay such graphs one at a time (or from one stream); and a
+ * kernel that faults mid-flight leaves its slot non-zero -- call eco_counters_reset(stream) after recovering the device.
+ * (Round-4 advisor finding; until v17 a sequence number modulo 256 chose the slot.)  (v18) */
+int eco_counters_reset(void* stream);
 
 /* ---- convolution (+ fused bias / residual / BN / ReLU epilogue) -------------------- */
 
@@ -128,6 +155,13 @@ typedef struct eco_view {
  *                                       shift=beta-mean*scale; bn_layer.cpp:93-207,
  *                                       same algebra as python/gen_bn_inference.py:121-134)
  *   act(img,c,sp) = relu ? max(a,0) : a   (layers/relu_layer.cpp:10-20)
+ *                                      NON-FINITE VALUES: +-Inf propagate everywhere.  A NaN reaches `raw` as NaN; in
+ *                                      `act` the activation is evaluated as ONE v_max_f32 against a floor (0 with
+ *                                      ReLU, -FLT_MAX / -Inf without: IEEE maxNum returns the non-NaN operand), so a
+ *                                      NaN pre-activation is stored as that floor, where the reference's std::max
+ *                                      (relu_layer.cpp:17) would keep the NaN.  A caller that uses NaN as a diagnostic
+ *                                      signal should look at `raw` (or run fuse=False: eco_bn_forward /
+ *                                      eco_relu_forward propagate it).
  *   act2(img,c,sp) = the same value       (a second destination of the activated output: the blob feeds both
  *                                          a 2-D consumer and, through r2Dto3D + Permute, the 3-D trunk --
  *                                          inception_3c_double_3x3_1_bn of ECO-Full,
