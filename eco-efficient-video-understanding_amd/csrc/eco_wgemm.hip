@@ -354,6 +354,7 @@ struct WinoOutDmArgs {
   int n, cout, D, H, W, TH, TW;
   int NB, ntot, ksplit;
   long m_pstride;
+  float* pool9;     // wfused_kernel<..., POOL = true>: P9[n][cout][3 TH][3 TW], see wino_pool9_store
 };
 
 template <int VEC>
@@ -445,6 +446,64 @@ __device__ __forceinline__ void wino_output_store(const WinoOutDmArgs& a, const 
         if (a.act2.ptr) st((vec_t*)(a.act2.ptr + o.act2 + sp), ov);
       }
     }
+  }
+}
+
+// The activated tile folded towards a MAX 3x3 stride-2 unpadded pooling that follows the convolution (conv2_3x3 -> pool2,
+// models_ECO_Lite/kinetics/deploy.prototxt:103-128): pooled row 2 th needs tile rows {0, 1, 2}, pooled row 2 th + 1 rows {2, 3}
+// and row 0 of the tile below, pooled row 2 th - 1 row 0 of this tile -- so a 4 x 4 tile contributes to 3 x 3 pooled cells, one of
+// them alone.  The nine partial maxima are stored as a 3 x 3 block of P9[img][ch][3 TH][3 TW] (9 floats per tile instead of the
+// 16 of the tile itself: the conv's own output is never written), and pool9_finish_kernel folds the blocks of neighbouring
+// tiles into the pooled blob.  (Measured and dropped: the eight shared cells as device-scope atomic max straight into the pooled
+// blob -- tools/ubench/atomic_pool.hip: 1.22 ms for conv2_3x3's tiles against 0.43 for storing them whole.)
+// Planes must tile by 4 exactly (H % 4 == 0, W % 4 == 0); only the activated value exists (no raw / residual / second view).
+__device__ __forceinline__ void wino_pool9_store(const WinoOutDmArgs& a, const float (&s4)[4][6], int ch, int img, int th, int tw) {
+  const unsigned cho = 4u * (unsigned)ch;
+  const float b = a.bias ? ld_su<float>(a.bias, cho) : 0.0f;
+  const float sc = a.bn_scale ? ld_su<float>(a.bn_scale, cho) : 1.0f, sh = a.bn_scale ? ld_su<float>(a.bn_shift, cho) : 0.0f;
+  const float floor_v = a.relu ? 0.0f : -3.402823466e38f;
+  const float sh2 = b * sc + sh;
+  float cm[4][3];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float t1 = s4[p][1] + s4[p][2], t2 = s4[p][1] - s4[p][2], t3 = s4[p][3] + s4[p][4], t4 = s4[p][3] - s4[p][4];
+    const float y0 = fmaxf((s4[p][0] + t1 + t3) * sc + sh2, floor_v), y1 = fmaxf((t2 + 2.0f * t4) * sc + sh2, floor_v);
+    const float y2 = fmaxf((t1 + 4.0f * t3) * sc + sh2, floor_v), y3 = fmaxf((t2 + 8.0f * t4 + s4[p][5]) * sc + sh2, floor_v);
+    cm[p][0] = y0;
+    cm[p][1] = fmaxf(fmaxf(y0, y1), y2);
+    cm[p][2] = fmaxf(y2, y3);
+  }
+  float* o = a.pool9 + (((long)img * a.cout + ch) * (3 * a.TH) + 3 * th) * (3 * a.TW) + 3 * tw;
+  const int pitch = 3 * a.TW;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    st(o + j, cm[0][j]);
+    st(o + pitch + j, fmaxf(fmaxf(cm[0][j], cm[1][j]), cm[2][j]));
+    st(o + 2 * pitch + j, fmaxf(cm[2][j], cm[3][j]));
+  }
+}
+
+// P9 -> the pooled blob y[n*c][2 TH][2 TW]: pooled row 2 t = block row 3 t + 1; pooled row 2 t + 1 = max(block row 3 t + 2, block
+// row 3 (t + 1)) (the tile below, if there is one: pooling_layer.cpp:131-147 clips the window at the bottom edge); columns alike.
+// One thread per tile column of a pooled row: six floats of P9 in, two out.
+__global__ __launch_bounds__(256) void pool9_finish_kernel(const float* p9, float* y, long planes, int TH, int TW) {
+  const long total = planes * 2 * TH * TW;
+  const int pitch = 3 * TW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int s = (int)(i % TW);
+    const long t1 = i / TW;
+    const int oh = (int)(t1 % (2 * TH));
+    const long pl = t1 / (2 * TH);
+    const int t = oh >> 1;
+    const float* r0 = p9 + (pl * 3 * TH + 3 * t + 1 + (oh & 1)) * pitch + 3 * s + 1;
+    const bool two_rows = (oh & 1) && t + 1 < TH, right = s + 1 < TW;
+    float o0 = ld(r0), o1 = fmaxf(ld(r0 + 1), right ? ld(r0 + 2) : -3.402823466e38f);
+    if (two_rows) {
+      const float* r1 = r0 + pitch;
+      o0 = fmaxf(o0, ld(r1));
+      o1 = fmaxf(o1, fmaxf(ld(r1 + 1), right ? ld(r1 + 2) : -3.402823466e38f));
+    }
+    st((float2*)(y + (pl * 2 * TH + oh) * (2 * TW) + 2 * s), make_float2(o0, o1));
   }
 }
 
@@ -559,7 +618,7 @@ struct WFusedArgs {
 #define ECO_WFUSED_R 3
 #define ECO_WFUSED_OCC 2
 #endif
-template <int KP, int VEC>
+template <int KP, int VEC, bool POOL = false>
 __global__ __launch_bounds__(256, ECO_WFUSED_OCC) void wfused_kernel(const WFusedArgs a) {
   ECO_CLOCK("wfused");
   const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -656,6 +715,10 @@ __global__ __launch_bounds__(256, ECO_WFUSED_OCC) void wfused_kernel(const WFuse
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int ch = mb * 32 + mrow0 + 8 * u;
+      if (POOL) {
+        if (ch < a.o.cout) wino_pool9_store(a.o, s4[u], ch, img, th, tw);
+        continue;
+      }
       if (ch < a.o.cout) wino_output_store<VEC>(a.o, s4[u], ch, o, 0, th, tw);
       o.res += 8 * a.o.residual.stride_c; o.raw += 8 * a.o.raw.stride_c;
       o.act += 8 * a.o.act.stride_c; o.act2 += 8 * a.o.act2.stride_c;
@@ -959,13 +1022,20 @@ extern "C" int eco_wfused_pack_weights(const eco_wgemm_plan* plan, const float* 
   return ECO_OK;
 }
 
-extern "C" int eco_wfused_forward(const eco_wgemm_plan* plan, const float* v, const float* up, int32_t h, int32_t w,
-                                  const eco_conv_epilogue* ep, void* stream) {
+static int wfused_launch(const eco_wgemm_plan* plan, const float* v, const float* up, int32_t h, int32_t w,
+                         const eco_conv_epilogue* ep, float* pool9, void* stream) {
   clear_error();
   if (int rc = wfused_check(plan)) return rc;
   ECO_REQUIRE(v && up && ep && h > 0 && w > 0, "wfused: bad argument");
   ECO_REQUIRE(plan->th == (h + 3) / 4 && plan->tw == (w + 3) / 4, "wfused: plan is for %dx%d tiles", plan->th, plan->tw);
-  ECO_REQUIRE(ep->raw.ptr || ep->act.ptr, "wfused: at least one of raw/act outputs is required");
+  if (pool9) {
+    ECO_REQUIRE(h % 4 == 0 && w % 4 == 0, "wfused + pooling: %dx%d planes do not tile by 4", h, w);
+    ECO_REQUIRE(!ep->raw.ptr && !ep->act.ptr && !ep->act2.ptr && !ep->residual.ptr,
+                "wfused + pooling: only the pooled activation exists (no raw / act / act2 / residual views)");
+    ECO_REQUIRE(((uintptr_t)pool9 & 3) == 0, "wfused + pooling: misaligned scratch");
+  } else {
+    ECO_REQUIRE(ep->raw.ptr || ep->act.ptr, "wfused: at least one of raw/act outputs is required");
+  }
   ECO_REQUIRE(!ep->bn_scale == !ep->bn_shift, "wfused: bn_scale and bn_shift must be given together");
   ECO_REQUIRE(!ep->act2.ptr || ep->act.ptr, "wfused: act2 needs act");
   ECO_REQUIRE(ep->nseg == 0, "wfused: segmented (sibling) launches exist for the direct kernels only");
@@ -979,6 +1049,7 @@ extern "C" int eco_wfused_forward(const eco_wgemm_plan* plan, const float* v, co
   a.o.n = plan->n; a.o.cout = plan->cout; a.o.D = 1; a.o.H = h; a.o.W = w; a.o.TH = plan->th; a.o.TW = plan->tw;
   a.o.NB = plan->n * plan->th * plan->tw;
   a.o.ntot = a.o.NB; a.o.ksplit = 1; a.o.m_pstride = 0;
+  a.o.pool9 = pool9;
   a.mblocks = plan->cout / 32;
   a.nblk = (int)ceil_div(a.o.NB, 32);
   a.Q = a.o.NB;
@@ -1002,9 +1073,15 @@ extern "C" int eco_wfused_forward(const eco_wgemm_plan* plan, const float* v, co
     hipLaunchKernelGGL((wfused_kernel<KP, VEC>), dim3((unsigned)grid), dim3(256), lds, s, a);                              \
   } while (0)
 #define ECO_WFUSED_RAISE(KP, VEC) ECO_RAISE_DYNAMIC_LDS((wfused_kernel<KP, VEC>), "wfused")
+#define ECO_WFUSED_POOL(KP)                                                                                                \
+  do {                                                                                                                     \
+    ECO_RAISE_DYNAMIC_LDS((wfused_kernel<KP, 1, true>), "wfused");                                                         \
+    hipLaunchKernelGGL((wfused_kernel<KP, 1, true>), dim3((unsigned)grid), dim3(256), lds, s, a);                          \
+  } while (0)
 #define ECO_WFUSED_KP(KP)                                                                                                  \
   case 2 * KP:                                                                                                             \
-    if (vec == 4) ECO_WFUSED_LAUNCH(KP, 4); else if (vec == 2) ECO_WFUSED_LAUNCH(KP, 2); else ECO_WFUSED_LAUNCH(KP, 1);    \
+    if (pool9) ECO_WFUSED_POOL(KP);                                                                                        \
+    else if (vec == 4) ECO_WFUSED_LAUNCH(KP, 4); else if (vec == 2) ECO_WFUSED_LAUNCH(KP, 2); else ECO_WFUSED_LAUNCH(KP, 1); \
     break
   switch (plan->cin) {
     ECO_WFUSED_KP(32); ECO_WFUSED_KP(48); ECO_WFUSED_KP(64); ECO_WFUSED_KP(80); ECO_WFUSED_KP(96); ECO_WFUSED_KP(112);
@@ -1012,6 +1089,28 @@ extern "C" int eco_wfused_forward(const eco_wgemm_plan* plan, const float* v, co
   }
 #undef ECO_WFUSED_KP
 #undef ECO_WFUSED_LAUNCH
+#undef ECO_WFUSED_POOL
 #undef ECO_WFUSED_RAISE
   return check_launch("eco_wfused_forward");
+}
+
+extern "C" int eco_wfused_forward(const eco_wgemm_plan* plan, const float* v, const float* up, int32_t h, int32_t w,
+                                  const eco_conv_epilogue* ep, void* stream) {
+  return wfused_launch(plan, v, up, h, w, ep, nullptr, stream);
+}
+
+extern "C" int64_t eco_wfused_pool_scratch_elems(const eco_wgemm_plan* plan) {
+  return plan ? (int64_t)plan->n * plan->cout * 9 * plan->th * plan->tw : 0;
+}
+
+extern "C" int eco_wfused_pool_forward(const eco_wgemm_plan* plan, const float* v, const float* up, int32_t h, int32_t w,
+                                       const eco_conv_epilogue* ep, float* scratch, float* y, void* stream) {
+  ECO_REQUIRE(scratch && y, "wfused + pooling: null scratch / output");
+  if (int rc = wfused_launch(plan, v, up, h, w, ep, scratch, stream)) return rc;
+  const long planes = (long)plan->n * plan->cout;
+  const long total = planes * 2 * plan->th * plan->tw;
+  ECO_REQUIRE(((uintptr_t)y & 7) == 0, "wfused + pooling: the pooled blob must be 8-byte aligned");
+  hipLaunchKernelGGL((pool9_finish_kernel), dim3(wg_grid(total)), dim3(256), 0, (hipStream_t)stream, scratch, y, planes, plan->th,
+                     plan->tw);
+  return check_launch("eco_wfused_pool_forward");
 }

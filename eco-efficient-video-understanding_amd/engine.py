@@ -147,6 +147,9 @@ class Engine:
         # wino3_min_positions tile positions (at one clip res4 / res5 have 32 / 4: they stay on the 2-D route)
         self.wino3 = True
         self.wino3_min_positions = 128
+        # conv2_3x3 -> pool2: the fused 2-D Winograd kernel writes partial window maxima instead of the conv output
+        # (csrc/eco_wgemm.hip, wino_pool9_store + pool9_finish_kernel)
+        self.wpool = True
         self.stem = True           # conv1 + BN + ReLU + pool1 as one launch (False: conv kernel + pooling kernel)
         self.siblings = True       # 1x1 convs reading the same bottom as one launch (fp32 path)
         # AVE pool 3x3/1/1 -> 1x1 conv (inception_3a/3b pool + pool_proj): both maps are linear, so the conv runs first
@@ -574,7 +577,8 @@ class Engine:
                                64 <= g["cin"] <= self.wfused_max_cin and g["cout"] % 32 == 0)
             elems = self.lib.wfused_weight_elems(plan) if wn["fused"] else plan.u_elems
             if wn["fused"]:
-                wn["m_elems"] = 0
+                # (no M in HBM; the pooling-fused form parks 9 floats per tile and channel in the same scratch buffer)
+                wn["m_elems"] = self.lib.wfused_pool_scratch_elems(plan) if (self.wpool and H % 4 == 0 and W % 4 == 0) else 0
             if old is not None and old.get("kind") == "wgemm" and old.get("fused") == wn["fused"] and \
                     old.get("up_elems") == elems:
                 wn["up"] = old["up"]
@@ -730,6 +734,49 @@ class Engine:
         self._add(i, f"{label}+{Lp.name}", lambda s: lib.stem_forward(x, wp, bias, sc, sh, relu, y, n, H, W, cout, s),
                   {"kernel": "eco::stem_kernel", "flops": 2 * n_conv * 147,
                    "bytes": 4 * (_prod(L.bottom_shapes[0]) + 147 * cout + _prod(Lp.top_shapes[0]))})
+        return True
+
+    def _try_fuse_wpool(self, i, L, ep, act_blob, label, layers, consumers, outputs, absorbed) -> bool:
+        """A stride-1 3x3 2-D conv on the fused Winograd kernel (+ BN + ReLU) whose activated blob feeds ONLY a MAX 3x3
+        stride-2 unpadded Pooling, on planes that tile by 4 -- conv2_3x3 -> pool2 (deploy.prototxt:103-128): the kernel
+        stores the nine partial window maxima of every 4x4 tile (9 floats instead of 16) and a small second launch folds
+        neighbouring tiles into the pooled blob; the 1.2 GB conv output (32 clips) is never written or read back."""
+        st = self._param_dev[L.name]
+        wn = st.get("wino")
+        if not self.wpool or act_blob is None or act_blob in outputs or ep.raw.ptr or ep.residual.ptr or self.dt or \
+                wn is None or wn.get("kind") != "wgemm" or not wn.get("fused"):
+            return False
+        cs = [c for c in consumers.get(act_blob, []) if absorbed.get(c) != L.name]
+        if len(cs) != 1 or layers[cs[0]].type != "Pooling":
+            return False
+        Lp = layers[cs[0]]
+        gp = Lp.geom
+        n, cin, H, W = L.bottom_shapes[0]
+        if gp["method"] != "MAX" or list(gp["kernel"]) != [3, 3] or list(gp["stride"]) != [2, 2] or any(gp["pad"]) or \
+                H % 4 or W % 4 or list(Lp.top_shapes[0][2:]) != [H // 2, W // 2]:
+            return False
+        cout = L.geom["cout"]
+        plan, up = wn["plan"], self.alloc.ptr(wn["up"])
+        lib = self.lib
+        self._materialize(Lp.tops[0], Lp.top_shapes[0])
+        absorbed[cs[0]] = L.name
+        self.fused_away[act_blob] = f"only exists inside the fused launch pair {L.name}+{Lp.name}"
+        x, y = self._ptr(L.bottoms[0]), self._ptr(Lp.tops[0])
+        v = self.alloc.ptr(self._wino_buf_v_elems)
+        scratch = self.alloc.ptr(self._wino_buf_m_elems)
+        self._keep.append((plan, ep))
+        tiles = n * wn["TH"] * wn["TW"]
+        v_bytes = 4 * 36 * cin * tiles
+        p9_bytes = 4 * 9 * cout * tiles
+        self._add(i, f"{label} [winograd F(4x4,3x3) input transform]", lambda s: lib.wino_input_q4_forward(plan, x, v, H, W, s),
+                  {"kernel": "eco::wino_input_q4_kernel", "flops": 0, "bytes": 4 * n * cin * H * W + v_bytes})
+        self._add(i, f"{label}+{Lp.name} [36 transformed-domain GEMMs, K = {cin}, + winograd F(4x4,3x3) output transform "
+                     f"+ partial window maxima]",
+                  lambda s: lib.wfused_pool_forward(plan, v, up, H, W, ep, scratch, y, s),
+                  {"kernel": "eco::wfused_kernel", "flops": 2 * 36 * tiles * cout * cin,
+                   "useful_flops": 2 * 36 * (n * H * W / 16.0) * cout * cin,
+                   # (the launch pair: V and the weights in, the pooled blob out; the partial maxima's round trip is extra)
+                   "bytes": v_bytes + 4 * 36 * cout * cin + 4 * _prod(Lp.top_shapes[0]), "scratch_bytes": 2 * p9_bytes})
         return True
 
     # -- blocked bf16-MFMA path (csrc/eco_blocked.hip) --------------------------------
@@ -1019,6 +1066,9 @@ class Engine:
             self.fused_away[value] = f"only exists inside the fused epilogue of {L.name}"
         # 3b. the stem: conv1 + BN + ReLU + pool1 as one launch
         if self._try_fuse_stem(i, L, ep, act_blob, label, layers, consumers, outputs, absorbed):
+            return None, label
+        # 3c. conv2_3x3 + BN + ReLU + pool2: the fused 2-D Winograd kernel leaves partial window maxima instead of its output
+        if self._try_fuse_wpool(i, L, ep, act_blob, label, layers, consumers, outputs, absorbed):
             return None, label
         # 4. activated output and its destination
         if act_blob is not None:

@@ -238,6 +238,9 @@ _SIGNATURES = {
                                           C.c_void_p]),
     "eco_wino3_output_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                            C.POINTER(ConvEpilogue), C.c_void_p]),
+    "eco_wfused_pool_scratch_elems": (C.c_int64, [C.POINTER(WGemmPlan)]),
+    "eco_wfused_pool_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                          C.POINTER(ConvEpilogue), C.c_void_p, C.c_void_p, C.c_void_p]),
     "eco_convb_plan_create": (C.c_int, [C.POINTER(ConvGeom), C.c_int32, C.c_int32, C.POINTER(ConvBPlan)]),
     "eco_convb_pack_weights": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvBPlan), C.c_void_p, C.c_void_p]),
     "eco_convb_forward": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvBPlan), C.c_void_p, C.c_void_p,
@@ -377,6 +380,14 @@ class EcoLib:
 
     def wfused_forward(self, plan: "WGemmPlan", v: int, up: int, h: int, w: int, ep: "ConvEpilogue", stream=None) -> None:
         self._check(self._dll.eco_wfused_forward(C.byref(plan), v, up, h, w, C.byref(ep), stream))
+
+    def wfused_pool_scratch_elems(self, plan: "WGemmPlan") -> int:
+        return int(self._dll.eco_wfused_pool_scratch_elems(C.byref(plan)))
+
+    def wfused_pool_forward(self, plan: "WGemmPlan", v: int, up: int, h: int, w: int, ep: "ConvEpilogue", scratch: int, y: int,
+                            stream=None) -> None:
+        """eco_wfused_forward + the MAX 3x3 / 2 pooling that follows it (conv2_3x3 -> pool2): pooled blob only."""
+        self._check(self._dll.eco_wfused_pool_forward(C.byref(plan), v, up, h, w, C.byref(ep), scratch, y, stream))
 
     # -- Winograd F(4x4,3x3) on the dedicated transformed-domain GEMM (csrc/eco_wgemm.hip) --
     def wgemm_plan(self, n, cin, cout, d, th, tw, kd, num_cu: Optional[int] = None, points: int = 36) -> "WGemmPlan":

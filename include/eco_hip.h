@@ -402,6 +402,14 @@ int64_t eco_wfused_weight_elems(const eco_wgemm_plan* plan);
 int eco_wfused_pack_weights(const eco_wgemm_plan* plan, const float* u, float* up); /* HOST */
 int eco_wfused_forward(const eco_wgemm_plan* plan, const float* v, const float* up, int32_t h, int32_t w,
                        const eco_conv_epilogue* ep, void* stream);
+/* The same with the MAX 3x3 stride-2 unpadded Pooling that consumes the activated output folded in (conv2_3x3 + BN + ReLU ->
+ * pool2, models_ECO_Lite/kinetics/deploy.prototxt:103-128; pooling_layer.cpp:131-147,199-225): every 4x4 output tile leaves
+ * as the 3x3 partial maxima it contributes (scratch: eco_wfused_pool_scratch_elems floats, [n][cout][3 th][3 tw]) and a
+ * second, small launch folds neighbouring tiles into y[n][cout][2 th][2 tw]; the convolution's own output is never written.
+ * h and w must be multiples of 4; `ep` supplies bias / folded BN / relu only (every view must be null).  (v18) */
+int64_t eco_wfused_pool_scratch_elems(const eco_wgemm_plan* plan);
+int eco_wfused_pool_forward(const eco_wgemm_plan* plan, const float* v, const float* up, int32_t h, int32_t w,
+                            const eco_conv_epilogue* ep, float* scratch, float* y, void* stream);
 
 /* ---- Winograd F(4x4x4,3x3x3) for the 3-D trunk (csrc/eco_wino3.hip, ABI v18) ---------------------------------
  *

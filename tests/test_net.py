@@ -179,6 +179,43 @@ layer { name: "cat" type: "Concat" bottom: "c1_bn" bottom: "c2" top: "cat" }
     assert relerr(net.forward()["cat"], ref2["cat"]) < 2e-4
 
 
+def test_fused_winograd_conv_absorbs_the_max_pooling_behind_it(backend):
+    """conv2_3x3 -> BN -> ReLU -> pool2 (MAX 3x3 / 2, unpadded) on planes that tile by 4: the fused Winograd kernel stores
+    partial window maxima and a second launch finishes the pooling -- two launches behind the input transform, the conv's
+    own blob is gone; planes that do NOT tile by 4, a second consumer of the conv blob, or wpool=False keep the pooling
+    layer as its own launch.  All against the oracle."""
+    def proto_for(H, W, extra=""):
+        return f"""name: "convpool"
+input: "data" input_dim: 2 input_dim: 64 input_dim: {H} input_dim: {W}
+layer {{ name: "c1" type: "Convolution" bottom: "data" top: "c1" convolution_param {{ num_output: 96 kernel_size: 3 pad: 1 }} }}
+layer {{ name: "c1_bn" type: "BN" bottom: "c1" top: "c1_bn" bn_param {{ frozen: true }} }}
+layer {{ name: "c1_relu" type: "ReLU" bottom: "c1_bn" top: "c1_bn" }}
+layer {{ name: "p1" type: "Pooling" bottom: "c1_bn" top: "p1" pooling_param {{ pool: MAX kernel_size: 3 stride: 2 }} }}
+{extra}"""
+    rng = np.random.default_rng(3)
+    for H, W, extra, fused in ((12, 16, "", True), (10, 14, "", False),
+                               (12, 16, 'layer { name: "r" type: "ReLU" bottom: "c1_bn" top: "r" }', False)):
+        proto = proto_for(H, W, extra)
+        spec = NetSpec.from_prototxt(proto)
+        params = fillers.synthetic_params(spec, seed=5)
+        x = rng.standard_normal((2, 64, H, W)).astype(np.float32)
+        ref = orc.forward(spec, params, {"data": x}, keep="all", fast_pool=False)
+        net = make_net(backend, proto, params, True, winograd=4)
+        labels = net.op_labels()
+        assert any("partial window maxima" in l for l in labels) == fused, labels
+        assert len(labels) == (2 if fused else 3 + bool(extra)), labels
+        net.blobs["data"].data[...] = x
+        out = net.forward()
+        assert relerr(out["p1"], ref["p1"]) < 2e-4
+        if fused:
+            assert "c1_bn" in net._engine.fused_away and "c1_bn" not in net._engine.tensors
+            net._engine.wpool = False
+            net._engine.build()
+            assert len(net.op_labels()) == 3 and not any("partial window maxima" in l for l in net.op_labels())
+            net.blobs["data"].data[...] = x
+            assert relerr(net.forward()["p1"], ref["p1"]) < 2e-4
+
+
 def test_trunk_takes_the_3d_winograd_route_where_depth_tiles_by_four(backend):
     """num_segments = 16: the res5 stage has 4 planes -> F(4x4x4,3x3x3) (csrc/eco_wino3.hip) on its three stride-1 convs
     (the only stage wide enough in this reduced net), residual + BN + ReLU + raw epilogue included; wino3 = False and

@@ -264,3 +264,60 @@ def test_wino3_rejects_wrong_plans(backend):
     with pytest.raises(hip.EcoError, match="kd"):
         lib.wgemm_plan(1, 32, 32, 1, 2, 2, 3, None, points=216)
     assert lib.wino3_lds_bytes(32, 7, 7) == 6 * 2 * 1 * 30 * 36 * 4
+
+
+# ---- fused 2-D Winograd conv + the MAX 3x3 / 2 pooling that follows it (conv2_3x3 -> pool2) --------------------------------
+@pytest.mark.parametrize("n,cin,cout,H,W,relu", [
+    (2, 64, 64, 8, 8, True),         # 2 x 2 tiles per image: every pooled cell kind (alone / two tiles / four tiles / at an edge)
+    (3, 64, 96, 12, 16, True),       # 3 x 4 tiles, 36 tile columns: two column blocks, the second ragged
+    (1, 96, 32, 16, 12, False),      # no ReLU: negative maxima survive (nothing assumes values >= 0)
+    (2, 64, 192, 56, 56, True),      # conv2_3x3 itself (two frames)
+])
+def test_wfused_conv_with_pooling(backend, n, cin, cout, H, W, relu):
+    if backend.kind == "emu" and H >= 56:
+        pytest.skip("full-size planes: GPU only")
+    lib = backend.lib
+    rng = np.random.default_rng(n + cin + cout + H)
+    x = rng.standard_normal((n, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    conv = orc.convolution(x, w, b, (3, 3), (1, 1), (1, 1)) * sc.reshape(1, -1, 1, 1) + sh.reshape(1, -1, 1, 1)
+    if relu:
+        conv = np.maximum(conv, 0)
+    ref = orc.pooling(conv.astype(np.float32), "MAX", (3, 3), (2, 2), (0, 0))
+    assert ref.shape == (n, cout, H // 2, W // 2)
+    TH, TW = H // 4, W // 4
+    plan = lib.wgemm_plan(n, cin, cout, 1, TH, TW, 1, None)
+    u = np.empty((36, cout, cin, 1), np.float32)
+    lib.wino_weight_transform(w.ctypes.data, cout, cin, 1, 4, u.ctypes.data)
+    up = np.zeros(lib.wfused_weight_elems(plan), np.float32)
+    lib.wfused_pack_weights(plan, u.ctypes.data, up.ctypes.data)
+    v = backend.dev(np.full(plan.v_elems, np.nan, np.float32))
+    lib.wino_input_q4_forward(plan, backend.ptr(backend.dev(x)), backend.ptr(v), H, W)
+    ep = hip.ConvEpilogue()
+    ep.bias = backend.ptr(backend.dev(b))
+    ep.residual, ep.raw, ep.act, ep.act2 = hip.null_view(), hip.null_view(), hip.null_view(), hip.null_view()
+    ep.bn_scale, ep.bn_shift, ep.relu = backend.ptr(backend.dev(sc)), backend.ptr(backend.dev(sh)), int(relu)
+    assert lib.wfused_pool_scratch_elems(plan) == n * cout * 9 * TH * TW
+    scratch = backend.empty((lib.wfused_pool_scratch_elems(plan),))
+    y = backend.empty(ref.shape)
+    lib.wfused_pool_forward(plan, backend.ptr(v), backend.ptr(backend.dev(up)), H, W, ep, backend.ptr(scratch), backend.ptr(y))
+    got = backend.host(y, ref.shape)
+    assert np.isfinite(got).all() and relerr(got, ref) < WTOL
+    if not relu:
+        assert (ref < 0).any()
+
+
+def test_wfused_pooling_rejects_ragged_planes_and_views(backend):
+    lib = backend.lib
+    plan = lib.wgemm_plan(1, 64, 32, 1, 3, 3, 1, None)        # 10 x 10 planes: 3 x 3 tiles, the last ones ragged
+    ep = hip.ConvEpilogue()
+    ep.residual, ep.raw, ep.act, ep.act2 = hip.null_view(), hip.null_view(), hip.null_view(), hip.null_view()
+    with pytest.raises(hip.EcoError, match="tile by 4"):
+        lib.wfused_pool_forward(plan, 16, 16, 10, 10, ep, 16, 16)
+    plan = lib.wgemm_plan(1, 64, 32, 1, 2, 2, 1, None)
+    ep.act = hip.plain_view(64, 32, 64)
+    with pytest.raises(hip.EcoError, match="only the pooled activation"):
+        lib.wfused_pool_forward(plan, 16, 16, 8, 8, ep, 16, 16)
