@@ -1358,7 +1358,9 @@ extern "C" int eco_conv_plan_create_batched(const eco_conv_geom* g, int32_t num_
     bool point = plan->mode == ECO_CONV_MODE_CTAP && batch == 1;
     for (int i = 0; i < 3; ++i) point = point && g->kernel[i] == 1 && g->stride[i] == 1 && g->pad[i] == 0;
     const long s_out_ = (long)g->out[0] * g->out[1] * g->out[2];
-    point = point && s_out_ % 4 == 0 && (long)g->n * s_out_ >= 4L * num_cu * 256;
+    // (one 256-wide tile per CU is enough: round 5 measured ECO-Full's 14 x 14 sibling groups -- 100 352 positions, until then
+    // on the gather kernel behind a 4-tiles-per-CU rule -- 2.5 % faster here, inception_4e_3x3_reduce 0.395 -> 0.345 ms)
+    point = point && s_out_ % 4 == 0 && (long)g->n * s_out_ >= 1L * num_cu * 256;
     if (point) { plan->mode = ECO_CONV_MODE_POINT; plan->bn = 256; }
   }
   plan->k = g->cin * g->kernel[0] * g->kernel[1] * g->kernel[2];

@@ -28,6 +28,8 @@ struct PoolArgs {
   int Di, Hi, Wi, Do, Ho, Wo;
   int kd, kh, kw, sd, sh, sw, pd, ph, pw;
   int method;
+  int c;           // channels per image
+  long y_extra;    // floats between the images of y beyond c * Do*Ho*Wo (0: dense; > 0: y is a channel slice of a Concat top)
 };
 
 __global__ __launch_bounds__(256) void pool_kernel(const PoolArgs a) {
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void pool_kernel(const PoolArgs a) {
           for (int w = ws; w < we; ++w) r += ld(xp + ((long)d * a.Hi + h) * a.Wi + w);
       r /= size;
     }
-    st(a.y + i, r);
+    st(a.y + i + (a.y_extra ? (nc / a.c) * a.y_extra : 0l), r);
   }
 }
 
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void pool2d_k3_kernel(const PoolArgs a) {
       const int he = min(hs + 3, a.Hi + a.ph), we = min(ws + 3, a.Wi + a.pw);
       r /= (float)((he - hs) * (we - ws));
     }
-    st(a.y + i, r);
+    st(a.y + i + (a.y_extra ? (nc / a.c) * a.y_extra : 0l), r);
   }
 }
 
@@ -129,7 +131,7 @@ __device__ __forceinline__ void st_vec(float* p, const float (&v)[VEC]) {
 // last column and the 3rd row simply do not exist at the right / bottom edge.
 template <int VEC>
 __global__ __launch_bounds__(256) void maxpool2d_k3s2_kernel(const float* x, float* y, long planes, int Hi, int Wi,
-                                                             int Ho, int Wo) {
+                                                             int Ho, int Wo, int c, long y_extra) {
   const int wq = Wo / VEC;
   const long total = planes * Ho * wq;
   for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void maxpool2d_k3s2_kernel(const float* x, flo
 #pragma unroll
       for (int e = 0; e < VEC; ++e) m[e] = fmaxf(m[e], fmaxf(fmaxf(in[2 * e], in[2 * e + 1]), in[2 * e + 2]));
     }
-    st_vec<VEC>(y + (pl * Ho + oh) * Wo + VEC * q, m);
+    st_vec<VEC>(y + (pl * Ho + oh) * Wo + VEC * q + (y_extra ? (pl / c) * y_extra : 0l), m);   // (y_extra: a Concat slice)
   }
 }
 
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const float* x, const
 
 using namespace eco;
 
-extern "C" int eco_pool_forward(const eco_pool_geom* g, const float* x, float* y, void* stream) {
+extern "C" int eco_pool_forward_strided(const eco_pool_geom* g, const float* x, float* y, int64_t y_image_stride, void* stream) {
   clear_error();
   ECO_REQUIRE(g && x && y, "pool: null argument");
   ECO_REQUIRE(g->n > 0 && g->c > 0, "pool: n and c must be positive");
@@ -587,12 +589,18 @@ extern "C" int eco_pool_forward(const eco_pool_geom* g, const float* x, float* y
   hipStream_t s = (hipStream_t)stream;
   const long rows = (long)g->n * g->c;
   const long s_in = (long)g->in[0] * g->in[1] * g->in[2];
-  if (global && g->method == ECO_POOL_AVE && s_in >= 32 && s_in < 2147483647l) {
+  // y as a channel slice of a wider tensor (a Concat top: concat_layer.cpp:60-81 copies the bottoms there; here the pooling
+  // writes its slice itself): images y_image_stride floats apart, the c channels of an image contiguous
+  const long s_out = (long)g->out[0] * g->out[1] * g->out[2];
+  ECO_REQUIRE(y_image_stride == 0 || y_image_stride >= (int64_t)g->c * s_out, "pool: y_image_stride %ld is smaller than an image (%ld)",
+              (long)y_image_stride, (long)g->c * s_out);
+  const long y_extra = y_image_stride ? (long)y_image_stride - (long)g->c * s_out : 0l;
+  if (y_extra == 0 && global && g->method == ECO_POOL_AVE && s_in >= 32 && s_in < 2147483647l) {
     hipLaunchKernelGGL((global_avg_kernel), dim3(grid_for(rows, 4)), dim3(kThreads), 0, s, x, y, rows, (int)s_in);
     return check_launch("eco_pool_forward(global)");
   }
   const bool two_d = g->in[0] == 1 && g->kernel[0] == 1 && g->stride[0] == 1 && g->pad[0] == 0;
-  const bool aligned = (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+  const bool aligned = (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && y_extra % 4 == 0;
   if (two_d && aligned && g->method == ECO_POOL_MAX && g->kernel[1] == 3 && g->kernel[2] == 3 && g->stride[1] == 2 &&
       g->stride[2] == 2 && g->pad[1] == 0 && g->pad[2] == 0 && g->in[2] % 4 == 0 && g->out[2] % 2 == 0 &&
       2 * (g->out[2] - 1) + 2 <= g->in[2]) {
@@ -600,15 +608,15 @@ extern "C" int eco_pool_forward(const eco_pool_geom* g, const float* x, float* y
     if (g->out[2] % 4 == 0) {
       const long total = rows * g->out[1] * (g->out[2] / 4);
       hipLaunchKernelGGL((maxpool2d_k3s2_kernel<4>), dim3(grid_for(total)), dim3(kThreads), 0, s, x, y, rows, g->in[1],
-                         g->in[2], g->out[1], g->out[2]);
+                         g->in[2], g->out[1], g->out[2], g->c, y_extra);
     } else {
       const long total = rows * g->out[1] * (g->out[2] / 2);
       hipLaunchKernelGGL((maxpool2d_k3s2_kernel<2>), dim3(grid_for(total)), dim3(kThreads), 0, s, x, y, rows, g->in[1],
-                         g->in[2], g->out[1], g->out[2]);
+                         g->in[2], g->out[1], g->out[2], g->c, y_extra);
     }
     return check_launch("eco_pool_forward(max 3x3 s2)");
   }
-  if (two_d && aligned && g->method == ECO_POOL_AVE && g->kernel[1] == 3 && g->kernel[2] == 3 && g->stride[1] == 1 &&
+  if (y_extra == 0 && two_d && aligned && g->method == ECO_POOL_AVE && g->kernel[1] == 3 && g->kernel[2] == 3 && g->stride[1] == 1 &&
       g->stride[2] == 1 && g->pad[1] == 1 && g->pad[2] == 1 && g->in[2] % 2 == 0 && g->in[1] >= 2 && g->in[2] >= 4) {
     const long hq = (g->in[1] + kAvgRows - 1) / kAvgRows;
     if (g->in[2] % 4 == 0) {
@@ -630,6 +638,7 @@ extern "C" int eco_pool_forward(const eco_pool_geom* g, const float* x, float* y
   a.sd = g->stride[0]; a.sh = g->stride[1]; a.sw = g->stride[2];
   a.pd = g->pad[0]; a.ph = g->pad[1]; a.pw = g->pad[2];
   a.method = g->method;
+  a.c = g->c; a.y_extra = y_extra;
   a.total = rows * a.Do * a.Ho * a.Wo;
   if (two_d && a.kh == 3 && a.kw == 3) {
     if (a.method == ECO_POOL_MAX) hipLaunchKernelGGL((pool2d_k3_kernel<ECO_POOL_MAX>), dim3(grid_for(a.total)), dim3(kThreads), 0, s, a);
@@ -638,6 +647,10 @@ extern "C" int eco_pool_forward(const eco_pool_geom* g, const float* x, float* y
   }
   hipLaunchKernelGGL((pool_kernel), dim3(grid_for(a.total)), dim3(kThreads), 0, s, a);
   return check_launch("eco_pool_forward");
+}
+
+extern "C" int eco_pool_forward(const eco_pool_geom* g, const float* x, float* y, void* stream) {
+  return eco_pool_forward_strided(g, x, y, 0, stream);
 }
 
 extern "C" int eco_avgpool_affine_forward(const float* x, const float* bias, const float* bn_scale, const float* bn_shift,

@@ -150,6 +150,7 @@ class Engine:
         # conv2_3x3 -> pool2: the fused 2-D Winograd kernel writes partial window maxima instead of the conv output
         # (csrc/eco_wgemm.hip, wino_pool9_store + pool9_finish_kernel)
         self.wpool = True
+        self.pool_into_concat = True   # a pooling feeding only a channel Concat writes its slice itself (ECO-Full 3c / 4e)
         self.stem = True           # conv1 + BN + ReLU + pool1 as one launch (False: conv kernel + pooling kernel)
         self.siblings = True       # 1x1 convs reading the same bottom as one launch (fp32 path)
         # AVE pool 3x3/1/1 -> 1x1 conv (inception_3a/3b pool + pool_proj): both maps are linear, so the conv runs first
@@ -880,6 +881,37 @@ class Engine:
                   {"kernel": hip.pool_kernel_name(pg), "flops": 0,
                    "bytes": 4 * (_prod(b) + _prod(L.top_shapes[0]))})
 
+    def _try_pool_into_concat(self, i, L, layers, consumers, outputs, absorbed, concat_skip) -> bool:
+        """A pooling whose top feeds only a channel Concat (inception_3c_pool / inception_4e_pool of ECO-Full: the MAX pool
+        branch of a stride-2 block, deploy.prototxt:1960-1990) writes its channels of the Concat top itself
+        (eco_pool_forward_strided): no pooled blob, no concat_copy launch."""
+        top = L.tops[0]
+        if self.dt or not self.pool_into_concat or top in outputs or len(L.bottom_shapes[0]) < 4:
+            return False
+        cs = [c for c in consumers.get(top, []) if c not in absorbed]
+        if len(cs) != 1 or layers[cs[0]].type != "Concat" or layers[cs[0]].geom["axis"] != 1:
+            return False
+        Lc = layers[cs[0]]
+        names = [self._resolve(b) for b in Lc.bottoms]
+        if names.count(top) != 1 or self._resolve(L.bottoms[0]) not in self.tensors:
+            return False
+        k = names.index(top)
+        ctot = Lc.top_shapes[0][1]
+        c0 = sum(bs[1] for bs in Lc.bottom_shapes[:k])
+        S = _prod(L.top_shapes[0][2:])
+        if Lc.tops[0] not in self.tensors:
+            self._materialize(Lc.tops[0], Lc.top_shapes[0])
+        concat_skip.setdefault(cs[0], []).append(k)
+        self.fused_away[top] = f"written directly into channels [{c0},{c0 + L.top_shapes[0][1]}) of {Lc.tops[0]}"
+        g, b = L.geom, L.bottom_shapes[0]
+        pg = hip.pool_geom(b[0], b[1], b[2:], g["kernel"], g["stride"], g["pad"], L.top_shapes[0][2:], g["method"])
+        self._keep.append(pg)
+        x, y = self._ptr(L.bottoms[0]), self._ptr(Lc.tops[0], c0 * S)
+        lib = self.lib
+        self._add(i, f"{L.name} [into {Lc.tops[0]}]", lambda s: lib.pool_forward_strided(pg, x, y, ctot * S, s),
+                  {"kernel": hip.pool_kernel_name(pg), "flops": 0, "bytes": 4 * (_prod(b) + _prod(L.top_shapes[0]))})
+        return True
+
     def _emit_concat(self, i: int, L: LayerSpec, skip: Sequence[int]) -> None:
         ax = L.geom["axis"]
         tshape = L.top_shapes[0]
@@ -985,7 +1017,8 @@ class Engine:
                     self._fuse_conv(i, L, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed,
                                     concat_skip)
             elif L.type == "Pooling" and (self._try_fuse_tail(i, L, layers, sole_consumer, absorbed) or
-                                          self._try_fuse_two_stream_tail(i, L, layers, absorbed)):
+                                          self._try_fuse_two_stream_tail(i, L, layers, absorbed) or
+                                          self._try_pool_into_concat(i, L, layers, consumers, outputs, absorbed, concat_skip)):
                 pass
             elif L.type == "Concat":
                 if L.tops[0] not in self.tensors:

@@ -188,6 +188,7 @@ _SIGNATURES = {
     "eco_wino_output_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.POINTER(ConvEpilogue), C.c_void_p]),
     "eco_pool_forward": (C.c_int, [C.POINTER(PoolGeom), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eco_pool_forward_strided": (C.c_int, [C.POINTER(PoolGeom), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "eco_bn_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                  C.c_int, C.c_void_p]),
     "eco_relu_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
@@ -459,6 +460,10 @@ class EcoLib:
     def pool_forward(self, g: PoolGeom, x: int, y: int, stream=None) -> None:
         self._check(self._dll.eco_pool_forward(C.byref(g), x, y, stream))
 
+
+    def pool_forward_strided(self, g: "PoolGeom", x: int, y: int, y_image_stride: int, stream=None) -> None:
+        """eco_pool_forward into a channel slice of a wider tensor (a Concat top): images y_image_stride floats apart."""
+        self._check(self._dll.eco_pool_forward_strided(C.byref(g), x, y, y_image_stride, stream))
     def bn_forward(self, x, y, scale, shift, n, c, inner, relu, stream=None) -> None:
         self._check(self._dll.eco_bn_forward(x, y, scale, shift, n, c, inner, int(relu), stream))
 

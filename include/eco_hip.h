@@ -257,6 +257,11 @@ typedef struct eco_pool_geom {
   int32_t method; /* ECO_POOL_MAX | ECO_POOL_AVE */
 } eco_pool_geom;
 int eco_pool_forward(const eco_pool_geom* g, const float* x, float* y, void* stream);
+/* The same with y as a channel slice of a wider tensor -- a Concat top (concat_layer.cpp:60-81 would copy the pooled blob
+ * there; inception_3c_pool / inception_4e_pool of ECO-Full, models_ECO_Full/kinetics/deploy.prototxt:1960-1990,3200-3230):
+ * y points at the slice's first channel of image 0, images are y_image_stride floats apart (0 = dense, as
+ * eco_pool_forward), the c channels of an image contiguous.  (v18) */
+int eco_pool_forward_strided(const eco_pool_geom* g, const float* x, float* y, int64_t y_image_stride, void* stream);
 
 /* AVE pooling 3x3 / stride 1 / pad 1 (divisor 9 everywhere: pooling_layer.cpp:247-262) of x[n,c,h,w], followed by
  * y = relu ? max(a, 0) : a with a = (avg + bias[c]) * bn_scale[c] + bn_shift[c], written through the strided view

@@ -273,6 +273,31 @@ def test_pool(backend, method, nc, insp, k, s, p):
     assert relerr(backend.host(y, ref.shape), ref) < TOL
 
 
+@pytest.mark.parametrize("method,nc,insp,k,s,p", [
+    ("MAX", (3, 8), (28, 28), (3, 3), (2, 2), (0, 0)),      # inception_3c_pool: the 8-byte vector kernel
+    ("MAX", (2, 5), (14, 14), (3, 3), (2, 2), (0, 0)),      # inception_4e_pool: 14 -> 7, the 3x3 kernel
+    ("MAX", (2, 4), (16, 16), (3, 3), (2, 2), (0, 0)),      # 16-byte vector kernel (8 outputs per row)
+    ("AVE", (2, 3), (6, 8), (3, 3), (1, 1), (1, 1)),        # the AVE fast path is dense-only: falls to the 3x3 kernel
+    ("AVE", (2, 2), (4, 5, 5), (2, 3, 3), (2, 2, 2), (0, 1, 1)),   # generic N-D kernel
+])
+def test_pool_into_a_concat_slice(backend, method, nc, insp, k, s, p):
+    """eco_pool_forward_strided: the pooled blob lands in channels [c0, c0 + c) of a wider tensor, the rest untouched."""
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(nc + tuple(insp)).astype(np.float32)
+    ref = orc.pooling(x, method, k, s, p)
+    n, c = nc
+    S = int(np.prod(ref.shape[2:]))
+    c0, ctot = 4, c + 8
+    g = hip.pool_geom(n, c, insp, k, s, p, ref.shape[2:], method)
+    big = backend.dev(np.full((n, ctot) + ref.shape[2:], 7.0, np.float32))
+    backend.lib.pool_forward_strided(g, backend.ptr(backend.dev(x)), backend.ptr(big, c0 * S), ctot * S)
+    got = backend.host(big, (n, ctot) + ref.shape[2:])
+    assert relerr(got[:, c0:c0 + c], ref) < TOL
+    assert (got[:, :c0] == 7.0).all() and (got[:, c0 + c:] == 7.0).all()
+    with pytest.raises(hip.EcoError, match="smaller than an image"):
+        backend.lib.pool_forward_strided(g, 16, 16, c * S - 1)
+
+
 def test_pool_rejects_wrong_output_shape(backend):
     g = hip.pool_geom(1, 1, (7, 7), (3, 3), (2, 2), (0, 0), (3, 3), "MAX")  # caffe ceil rule gives 4x4
     with pytest.raises(hip.EcoError):

@@ -328,3 +328,28 @@ def test_filler_init_and_bad_params(backend):
     bad["fc8"] = [p["fc8"][0][:, :5], p["fc8"][1]]
     with pytest.raises(ValueError, match="does not match"):
         make_net(backend, proto, bad, True)
+
+
+def test_eco_full_plan_has_no_concat_copies(backend):
+    """ECO-Full's stride-2 blocks (inception_3c / 4e) concatenate two strided convs and a MAX pool: the convs write their
+    Concat slices from their epilogues, and -- round 5 -- the pool writes its slice itself (eco_pool_forward_strided), so the
+    fused plan has no concat_copy launch left; pool_into_concat=False brings the two copies back.  Both match the oracle
+    (test_mini_eco_matches_oracle runs the default plan blob by blob)."""
+    proto = mini("full")
+    spec = NetSpec.from_prototxt(proto)
+    params = fillers.synthetic_params(spec, seed=7)
+    x = fillers.synthetic_frames(8, 32, 32, seed=3)
+    ref = orc.forward(spec, params, {"data": x}, fast_pool=False)["fc8"]
+    net = make_net(backend, proto, params, True)
+    labels = net.op_labels()
+    assert not any(l.startswith("inception_3c_output[") or l.startswith("inception_4e_output[") for l in labels), labels
+    assert "inception_3c_pool [into inception_3c_output]" in labels and "inception_4e_pool [into inception_4e_output]" in labels
+    assert "inception_3c_pool" in net._engine.fused_away
+    net.blobs["data"].data[...] = x
+    assert relerr(net.forward()["fc8"], ref) < TOL
+    net._engine.pool_into_concat = False
+    net._engine.build()
+    labels = net.op_labels()
+    assert sum(l.startswith("inception_3c_output[") or l.startswith("inception_4e_output[") for l in labels) == 2
+    net.blobs["data"].data[...] = x
+    assert relerr(net.forward()["fc8"], ref) < TOL
