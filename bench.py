@@ -563,7 +563,7 @@ def cpu_baseline(args, gen, N, frames, params, logits):
         return done, t_cpu, np.concatenate(refs, 0)
 
     variants = {}
-    max_clips = args.cpu_clips or 8
+    max_clips = min(args.cpu_clips or 8, len(frames) // N)     # (never more clips than the batch holds: --clips-per-gpu 2)
     blas_threads = min(cores, 64)   # SciPy's OpenBLAS is built for at most 64 threads
     if have_ref:
         eco_ref.set_blas_threads(blas_threads)

@@ -280,3 +280,24 @@ def test_eco_lite_c2_f32x3():
           f"{relerr(native[:1], ref):.3e}; f32x3 vs fp32-MFMA over 32 clips {np.abs(out - native).max() / scale:.3e}")
     assert relerr(out[:1], ref) < TOL and out[0].argmax() == ref.argmax()
     assert np.abs(out - native).max() < 1e-4 * scale
+
+
+@pytest.mark.gpu
+def test_bench_line_says_what_is_useful_and_what_moves():
+    """bench.py's JSON line (round-4 verdict item 7): `useful_frac` beside `frac` for the dominant kernel, `step_useful_frac`,
+    one `per_kernel` entry per family with its algorithmic bytes / PMC traffic / ratio fields (the PMC figures themselves are null
+    unless profiles/hbm_traffic_latest.json belongs to the running sources), and the strict top-1 at the top level."""
+    import json, subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-extra-configs",
+                          "--clips-per-gpu", "2"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    r = line["roofline"]
+    assert 0 < r["useful_frac"] <= r["frac"] + 1e-9 and 0 < r["step_useful_frac"] <= r["step_frac"] + 1e-9
+    fams = r["per_kernel"]
+    assert "eco::wgemm_kernel" in fams and "eco::wino3_input_kernel" in fams and "eco::wino3_output_kernel" in fams
+    for k, v in fams.items():
+        assert {"useful_frac_of_own_floor", "algorithmic_gb_per_launch", "traffic_gb_per_launch", "traffic_ratio"} <= set(v), k
+    assert line["top1_equal"] is True and line["max_rel_err_vs_cpu_ref"] < 1e-3
+    assert line["parity"]["top1_equal_per_clip"] == [True, True] and line["cpu_baseline"]["kind"] == "reference"

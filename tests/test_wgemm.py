@@ -321,3 +321,54 @@ def test_wfused_pooling_rejects_ragged_planes_and_views(backend):
     ep.act = hip.plain_view(64, 32, 64)
     with pytest.raises(hip.EcoError, match="only the pooled activation"):
         lib.wfused_pool_forward(plan, 16, 16, 8, 8, ep, 16, 16)
+
+
+# ---- the trunk's layers at their real sizes on the F(4x4x4,3x3x3) route (GPU only) -------------------------------------------
+ECO_TRUNK = [  # id, n, cin, cout, (D,H,W): models_ECO_Lite/kinetics/deploy.prototxt:1162-1660 at num_segments 16 / 32
+    ("res3a_2n", 2, 96, 128, (16, 28, 28)),
+    ("res3b", 2, 128, 128, (16, 28, 28)),
+    ("res4b", 3, 256, 256, (8, 14, 14)),        # two images per workgroup, the last group ragged
+    ("res5b", 9, 512, 512, (4, 7, 7)),          # eight images per workgroup, 7 x 7 planes: scalar accesses
+    ("res3_n32", 1, 128, 128, (32, 28, 28)),    # configs[4]'s depth: eight depth tiles
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n,cin,cout,dims", ECO_TRUNK, ids=[c[0] for c in ECO_TRUNK])
+def test_wino3_eco_trunk_layers(hip_backend, name, n, cin, cout, dims):
+    """Input transform -> 216 GEMMs -> output transform with the res*b_2 epilogue (Eltwise residual, raw sum, BN + ReLU) against the
+    oracle's direct convolution.  Tolerance 1e-4 of the largest output (measured 1-2e-5: three nested F(4,3) transforms)."""
+    be = hip_backend
+    D, H, W = dims
+    rng = np.random.default_rng(len(name) + cin)
+    x = np.maximum(rng.normal(size=(n, cin, D, H, W)), 0).astype(np.float32)     # a ReLU'd activation, as in the net
+    w = (rng.normal(size=(cout, cin, 3, 3, 3)) / np.sqrt(cin * 27)).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(n, cout, D, H, W)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
+    v = orc.convolution(x, w, b, (3, 3, 3), (1, 1, 1), (1, 1, 1)) + res
+    act = np.maximum(v * sc.reshape(1, -1, 1, 1, 1) + sh.reshape(1, -1, 1, 1, 1), 0)
+    lib = be.lib
+    TD, TH, TW = -(-D // 4), -(-H // 4), -(-W // 4)
+    plan = lib.wgemm_plan(n, cin, cout, TD, TH, TW, 1, None, points=216)
+    u = np.empty((216, cout, cin, 1), np.float32)
+    lib.wino3_weight_transform(w.ctypes.data, cout, cin, u.ctypes.data)
+    up = np.empty(plan.u_elems, np.float32)
+    lib.wgemm_pack_weights(plan, u.ctypes.data, up.ctypes.data)
+    vbuf, mbuf = be.empty((plan.v_elems,)), be.empty((plan.m_elems,))
+    S = D * H * W
+    y_raw, y_act = be.empty(v.shape), be.empty(v.shape)
+    ep = hip.ConvEpilogue()
+    ep.bias = be.ptr(be.dev(b))
+    ep.residual = hip.plain_view(be.ptr(be.dev(res)), cout, S)
+    ep.raw = hip.plain_view(be.ptr(y_raw), cout, S)
+    ep.act = hip.plain_view(be.ptr(y_act), cout, S)
+    ep.act2 = hip.null_view()
+    ep.bn_scale, ep.bn_shift, ep.relu = be.ptr(be.dev(sc)), be.ptr(be.dev(sh)), 1
+    lib.wino3_input_forward(plan, be.ptr(be.dev(x)), be.ptr(vbuf), D, H, W)
+    lib.wgemm_forward(plan, be.ptr(vbuf), be.ptr(be.dev(up)), be.ptr(mbuf))
+    lib.wino3_output_forward(plan, be.ptr(mbuf), D, H, W, ep)
+    tol = 1e-4 * np.abs(v).max()
+    e_raw, e_act = np.abs(be.host(y_raw, v.shape) - v).max(), np.abs(be.host(y_act, v.shape) - act).max()
+    print(f"{name}: raw {e_raw / np.abs(v).max():.2e}, act {e_act / np.abs(v).max():.2e} of the largest output")
+    assert e_raw <= tol and e_act <= tol
