@@ -43,6 +43,14 @@ namespace eco {
 constexpr int kSbPH = 8, kSbPW = 14;                       // pooled patch per workgroup
 constexpr int kSbCR = 2 * kSbPH + 1, kSbCQ = 2 * kSbPW + 1;   // conv patch: 17 x 29
 constexpr int kSbNPos = kSbCR * kSbCQ;                     // 493 conv positions, padded to 512 columns
+// Pitch of a conv row in the pooling stage (dwords).  29 would do; 39 makes 2 * pitch = 14 (mod 32): the pooling threads of a
+// 32-lane group -- 14 per pooled row, rows 2 * pitch apart -- then read 32 different banks (with 29, rows ph and ph + 1
+// shared eight of them: 482 M bank-conflict cycles per six launches, round-4 PMC).  The stage grows from 31 to 42 KB; two
+// workgroups still fit a CU (2 x 80.6 KB).
+#ifndef ECO_STEMB_PITCH
+#define ECO_STEMB_PITCH 39
+#endif
+constexpr int kSbSP = ECO_STEMB_PITCH;
 constexpr int kSbIR = 2 * (kSbCR - 1) + 7;                 // 39 input rows per channel
 constexpr int kSbIQ = 64;                                  // stored columns per row: 63 + the zero-weight tap's column
 constexpr int kSbRows = 3 * kSbIR;                         // 117 patch rows
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
   constexpr int COUT = 32 * TMC;
   constexpr int XS_BYTES = kSbRows * kSbRowBytes;          // 14976
   constexpr int W_VECS = kSbSteps * 2 * COUT;              // 16-byte vectors of packed weights
-  constexpr int STAGE_LD = kSbNPos + 3;                    // 496: staging row of one channel
+  constexpr int STAGE_LD = kSbCR * kSbSP + 3;              // staging row of one channel pair
   constexpr int XU4 = (kSbRows + 15) / 16, WU = (W_VECS + 255) / 256;
   ECO_DYNAMIC_LDS(lds);
   unsigned char* const Xs = (unsigned char*)lds;           // bf16 [3][39][64]
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
     pbase[j] = 2 * r * kSbRowBytes + 4 * q;
     // the pooling stage keeps a conv row's 29 columns parity split (15 even, then 14 odd): the 3x3 stride-2 windows of
     // consecutive pooled columns read consecutive words
-    soff[j] = r * kSbCQ + (q & 1) * ((kSbCQ + 1) / 2) + (q >> 1);
+    soff[j] = r * kSbSP + (q & 1) * ((kSbSP + 1) / 2) + (q >> 1);
   }
   const bool last_col_ok = wave * 128 + 96 + l31 < kSbNPos;   // only wave 3's j = 3 has padding columns
   const uint4* const wl = Ws + half * COUT + l31;          // A[m = l31 (+32 i)][k = 16 s + 8 half + e]
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
   // pooling threads: 14 x 8 pooled positions x 2 = 224 of the 256; thread (pos, clo) takes the 8-channel blocks clo, clo + 2
   const int pw = tid % kSbPW, ph = (tid / kSbPW) % kSbPH, clo = tid / (kSbPW * kSbPH);
   unsigned* const Su = (unsigned*)Ss;
-  const unsigned* const sp0 = Su + 4 * clo * STAGE_LD + 2 * ph * kSbCQ + pw;
+  const unsigned* const sp0 = Su + 4 * clo * STAGE_LD + 2 * ph * kSbSP + pw;
   unsigned* const sw0 = Su + 2 * half * STAGE_LD;
   const float relu_floor = a.relu ? 0.0f : -FLT_MAX;
   const float stage_floor = a.relu ? 0.0f : -__builtin_inff();      // ReLU ahead of the stage (see the pooling loop)
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void stemb_kernel(const StemBArgs a) {
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx)
         woff[dy * 3 + dx] = (r0 + 2 * ph + dy < a.Ho && q0 + 2 * pw + dx < a.Wo)
-                                ? dy * kSbCQ + (dx & 1) * ((kSbCQ + 1) / 2) + (dx >> 1) : 0;
+                                ? dy * kSbSP + (dx & 1) * ((kSbSP + 1) / 2) + (dx >> 1) : 0;
     uint4* const yp0 = a.y + (((long)f * cblocks + clo) * a.PHo + gph) * a.PWo + gpw;   // block clo of m-tile 0
     const long yblk = (long)a.PHo * a.PWo;
     ECO_SBTS(4);
@@ -484,7 +492,7 @@ extern "C" int eco_stemb_forward(const float* x, const void* wp, const float* bi
   const long grid = total < cap ? total : cap;
   static const int dyn = [] { const char* e = getenv("ECO_STEMB_DYNAMIC"); return (e && e[0] == '0') ? 0 : 1; }();
   a.ctr = (dyn && total > 2 * grid) ? stemb_counter_slot(stream) : nullptr;   // (worth a draw per patch only with several patches per workgroup)
-  const size_t lds = (size_t)kSbRows * kSbRowBytes + (size_t)kSbSteps * 2 * cout * 16 + sizeof(float) * (size_t)(2 * cout + 16 * (kSbNPos + 3));
+  const size_t lds = (size_t)kSbRows * kSbRowBytes + (size_t)kSbSteps * 2 * cout * 16 + sizeof(float) * (size_t)(2 * cout + 16 * (kSbCR * kSbSP + 3));
   hipStream_t s = (hipStream_t)stream;
   if (cout == 64) ECO_RAISE_DYNAMIC_LDS(stemb_kernel<2>, "stemb");
   else ECO_RAISE_DYNAMIC_LDS(stemb_kernel<1>, "stemb");
