@@ -68,7 +68,9 @@ __device__ __forceinline__ f4 lds_ld16(const float* p) {
   return *(const f4*)p;
 #else
   f4 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)p));
+  // ("memory": the compiler must not move this read ahead of the LDS stores / the barrier in front of it -- it does not
+  // know the instruction reads LDS)
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)p) : "memory");
   return v;
 #endif
 }

@@ -491,3 +491,18 @@ def test_convb_eco_permuted_volume_at_full_size(hip_backend):
     ref = np.maximum(ref * sc.reshape(1, -1, 1, 1) + sh.reshape(1, -1, 1, 1), 0)
     got = host_blocked(be, vol, (B, cout, T, H, H), dt)
     check(got, ref.reshape(B, T, cout, H, H).transpose(0, 2, 1, 3, 4), dt, "permuted volume")
+
+
+def test_counters_reset_and_streams(backend):
+    """eco_counters_reset clears the work counters of the dynamic-share launches (include/eco_hip.h, "Process-level state");
+    dynamic launches issued under different stream handles take different counter slots and all match the oracle (the emulator
+    ignores the stream for execution -- the slot bookkeeping is what runs here; on the GPU the handles are real streams)."""
+    lib = backend.lib
+    lib.counters_reset(None)
+    case = (4, 64, 32, (4, 16, 16), 1)       # 16 tiles on 8 workgroups, 6 groups of 9 taps: dynamic shares
+    n, cin, cout, in_sp, num_cu = case
+    for seed in (1, 2, 3):
+        plan = run_convb(backend, BF16, n, cin, cout, in_sp, (3, 3, 3), (1, 1, 1), (1, 1, 1), num_cu=num_cu, seed=seed, raw=False)
+        assert plan.pgrid == 8
+    lib.counters_reset(None)
+    run_convb(backend, BF16, n, cin, cout, in_sp, (3, 3, 3), (1, 1, 1), (1, 1, 1), num_cu=num_cu, seed=4, raw=False)
