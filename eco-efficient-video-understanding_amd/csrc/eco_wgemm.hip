@@ -31,6 +31,7 @@ namespace eco {
 
 constexpr int kWgP = 36;   // F(4x4,3x3): 6x6 transform points
 constexpr int kWgP3 = 216; // F(4x4x4,3x3x3): 6x6x6 transform points (the GEMM only sees more, shorter problems)
+constexpr int kWgPS2 = 320; // stride-2 3x3x3 as eight polyphase F(4,2) x F(7,2) x F(7,2) problems: 5x8x8 points (eco_wino_s2.hip)
 constexpr int kWgKp = 8;             // k-pairs (16 reduction elements) per stage
 
 struct WGemmArgs {
@@ -738,8 +739,9 @@ using namespace eco;
 
 static int wgemm_check_plan(const eco_wgemm_plan* p) {
   ECO_REQUIRE(p != nullptr, "wgemm: null plan");
-  ECO_REQUIRE(p->points == kWgP || (p->points == kWgP3 && p->kd == 1),
-              "wgemm: F(4x4,3x3) (36 transform points) or, with kd = 1, F(4x4x4,3x3x3) (216) is supported, got %d", p->points);
+  ECO_REQUIRE(p->points == kWgP || ((p->points == kWgP3 || p->points == kWgPS2) && p->kd == 1),
+              "wgemm: F(4x4,3x3) (36 transform points) or, with kd = 1, F(4x4x4,3x3x3) (216) / the stride-2 polyphase form (320) is "
+              "supported, got %d", p->points);
   ECO_REQUIRE(p->n > 0 && p->cin > 0 && p->cin % 16 == 0 && p->cout > 0 && p->d > 0 && p->th > 0 && p->tw > 0 &&
                   (p->kd == 1 || p->kd == 3),
               "wgemm: bad problem (n=%d cin=%d cout=%d d=%d tiles %dx%d kd=%d; cin must be a multiple of 16)", p->n, p->cin,

@@ -147,6 +147,14 @@ class Engine:
         # wino3_min_positions tile positions (at one clip res4 / res5 have 32 / 4: they stay on the 2-D route)
         self.wino3 = True
         self.wino3_min_positions = 128
+        # STRIDE-2 3x3x3 layers (res4a_1 / res4a_down) as eight polyphase F(4,2) x F(7,2) x F(7,2) problems on the same GEMM
+        # (csrc/eco_wino_s2.hip): 13.1 multiplies per output and input channel instead of 27, where the output volume tiles
+        # by 4 x 7 x 7, the input is exactly twice as large and a transform point still has wino_s2_min_positions tile
+        # positions (res5a at 32 clips has 32 and would stream 1.3 GB of transformed weights: it stays direct).  Convs of
+        # one geometry on the same bottom share the input transform and the GEMM.
+        self.wino_s2 = True
+        self.wino_s2_min_positions = 128
+        self._ws2_groups: Dict[str, dict] = {}
         # conv2_3x3 -> pool2: the fused 2-D Winograd kernel writes partial window maxima instead of the conv output
         # (csrc/eco_wgemm.hip, wino_pool9_store + pool9_finish_kernel)
         self.wpool = True
@@ -211,6 +219,7 @@ class Engine:
             return
         self.generation += 1
         self._sync_groups(set(self._dirty_params))
+        self._sync_ws2(set(self._dirty_params))
         for name in list(self._dirty_params):
             L = self.spec.layer(name)
             st = self._param_dev.setdefault(name, {})
@@ -227,6 +236,10 @@ class Engine:
                     swp = np.empty(self.lib.stemb_weight_elems(L.geom["cout"]), np.uint16)
                     self.lib.stemb_pack_weights(w.ctypes.data, L.geom["cout"], swp.ctypes.data)
                     self.alloc.upload(st["stemb_wp"], swp)
+            elif L.type == "Convolution" and "ws2" in st:
+                # (weights live in the group's transformed-domain image, _sync_ws2; the direct kernel's are not needed)
+                if L.geom["bias_term"]:
+                    self.alloc.upload(st["bias"], blobs[1])
             elif L.type == "Convolution":
                 g: hip.ConvGeom = st["geom"]
                 plan: hip.ConvPlan = st["plan"]
@@ -297,6 +310,12 @@ class Engine:
         self._groups = {}
         self._dirty_groups = set()
         self.generation += 1
+        # Split tops are names for their bottom (the fused plan's dataflow and the stride-2 Winograd groups work on real blobs)
+        self._alias_src: Dict[str, str] = {}
+        for L in spec.layers:
+            if L.type == "Split":
+                for t in L.tops:
+                    self._alias_src[t] = self._resolve(L.bottoms[0])
         # device-side parameter storage (sizes depend on geometry)
         for L in spec.layers:
             st = self._param_dev.setdefault(L.name, {})
@@ -339,6 +358,7 @@ class Engine:
                     st["bias"] = self.alloc.empty(L.geom["num_output"], np.float32)
                 st["size"] = (L.geom["num_output"], L.geom["K"])
                 self._dirty_params.add(L.name)
+        self._plan_ws2_groups()
         # one scratch buffer serves every split-K convolution (launches are serial on one stream); the same
         # goes for the Winograd path's transformed input / output volumes
         ws_bytes = max([st["plan"].ws_bytes for st in self._param_dev.values() if "plan" in st] +
@@ -346,7 +366,8 @@ class Engine:
                        [st["wino"]["points"] * st["wino"]["plan"].ws_bytes for st in self._param_dev.values()
                         if "wino" in st and st["wino"]["kind"] == "gather"] + [0])
         for key in ("v_elems", "m_elems"):
-            need = max([st["wino"][key] for st in self._param_dev.values() if "wino" in st] + [0])
+            need = max([st["wino"][key] for st in self._param_dev.values() if "wino" in st] +
+                       [getattr(grp["plan"], key) for grp in self._ws2_groups.values()] + [0])
             if need > getattr(self, "_wino_" + key, 0):
                 setattr(self, "_wino_buf_" + key, self.alloc.empty(need, np.float32))
                 setattr(self, "_wino_" + key, need)
@@ -685,6 +706,139 @@ class Engine:
                   {"kernel": f"eco::wino_output_kernel<{M}>", "flops": 0,
                    "bytes": 4 * P * tout + nbytes - 4 * (n * cin * D * H * W + 9 * kd * cin * cout)})
 
+    # -- stride-2 3x3x3 convolutions on the polyphase Winograd route (csrc/eco_wino_s2.hip) ----------------------------
+    def _ws2_eligible(self, L: LayerSpec) -> bool:
+        """3x3x3, stride 2, pad 1 on an input exactly twice the output volume, the output volume tiling by 4 x 7 x 7
+        (res4a_1 / res4a_down at num_segments 16 / 32: 8 x 14 x 14, models_ECO_Lite/kinetics/deploy.prototxt:1262-1330)."""
+        g = L.geom
+        if self.dt or not self.winograd or not self.wino_s2 or not self.wgemm or L.type != "Convolution":
+            return False
+        if len(L.bottom_shapes[0]) != 5 or tuple(g["kernel"]) != (3, 3, 3) or tuple(g["stride"]) != (2, 2, 2) or \
+                tuple(g["pad"]) != (1, 1, 1) or g.get("group", 1) != 1:
+            return False
+        n, cin, D, H, W = L.bottom_shapes[0]
+        Do, Ho, Wo = L.top_shapes[0][2:]
+        if (D, H, W) != (2 * Do, 2 * Ho, 2 * Wo) or Do % 4 or Ho % 7 or Wo % 7 or cin % 2 or cin < 16:
+            return False
+        TD, TH, TW = Do // 4, Ho // 7, Wo // 7
+        if self.winograd is True and n * TD * TH * TW < self.wino_s2_min_positions:   # an explicit winograd=4 overrides
+            return False
+        return self.lib.wino_s2_lds_bytes(n, TD, TH, TW) <= 152 * 1024
+
+    def _plan_ws2_groups(self) -> None:
+        """Group the eligible convs by (bottom blob, geometry) -- in the fused plan a residual block's first conv and its
+        projection shortcut become ONE transformed-domain problem of cout_1 + cout_2 rows -- and plan each group's GEMM."""
+        layers = self.spec.layers
+        old = self._ws2_groups
+        self._ws2_groups = {}
+        for L in layers:
+            self._param_dev.get(L.name, {}).pop("ws2", None)
+        found: Dict[tuple, List[int]] = {}
+        for i, L in enumerate(layers):
+            if L.type == "Convolution" and "wino" not in self._param_dev[L.name] and self._ws2_eligible(L):
+                k = (self._resolve(L.bottoms[0]), tuple(L.bottom_shapes[0]), tuple(L.top_shapes[0][2:]))
+                k = k if self.fuse else k + (i,)
+                # a layer that rewrites the shared bottom in place between two members splits the group
+                if k in found and any(layers[j].inplace and self._resolve(layers[j].bottoms[0]) == k[0]
+                                      for j in range(found[k][0], i)):
+                    k = k + (i,)
+                found.setdefault(k, []).append(i)
+        for k, idxs in found.items():
+            Ls = [layers[j] for j in idxs]
+            key = "|".join(Lc.name for Lc in Ls)
+            n, cin, D, H, W = Ls[0].bottom_shapes[0]
+            Do, Ho, Wo = Ls[0].top_shapes[0][2:]
+            couts = [Lc.geom["cout"] for Lc in Ls]
+            plan = self.lib.wgemm_plan(n, 8 * cin, sum(couts), Do // 4, Ho // 7, Wo // 7, 1, self.num_cu, points=320)
+            grp = dict(plan=plan, convs=[Lc.name for Lc in Ls], idxs=idxs, couts=couts, cin=cin)
+            o = old.get(key)
+            grp["up"] = o["up"] if o is not None and o["plan"].u_elems == plan.u_elems else self.alloc.empty(plan.u_elems, np.float32)
+            self._ws2_groups[key] = grp
+            for Lc in Ls:
+                self._param_dev[Lc.name]["ws2"] = key
+                self._dirty_params.add(Lc.name)
+
+    def _sync_ws2(self, dirty) -> None:
+        """(Re)build the transformed-domain weight image of the groups with a changed member: the members' weights
+        concatenated along cout -> u[320][ctot][8 cin] -> the GEMM kernel's packed layout."""
+        for key, grp in self._ws2_groups.items():
+            if not (dirty & set(grp["convs"])) or any(n not in self.params for n in grp["convs"]):
+                continue
+            plan, cin = grp["plan"], grp["cin"]
+            ctot = sum(grp["couts"])
+            w = np.ascontiguousarray(np.concatenate(
+                [np.asarray(self.params[n][0], np.float32).reshape(c, -1) for n, c in zip(grp["convs"], grp["couts"])], 0))
+            u = np.empty(320 * ctot * 8 * cin, np.float32)
+            self.lib.wino_s2_weight_transform(w.ctypes.data, ctot, cin, u.ctypes.data)
+            up = np.empty(plan.u_elems, np.float32)
+            self.lib.wgemm_pack_weights(plan, u.ctypes.data, up.ctypes.data)
+            del u
+            self.alloc.upload(grp["up"], up)
+
+    def _try_fuse_ws2(self, i, L, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed, concat_skip) -> bool:
+        """The first member of a stride-2 Winograd group emits the whole group here (every member's only input is the shared
+        bottom): one input transform, one GEMM, one output transform per member with the member's own epilogue.  A
+        projection shortcut emitted ahead of the block's second conv keeps its raw value; its Eltwise then rides on that
+        conv (the later producer), exactly as for the sibling launches of the direct kernels."""
+        key = self._param_dev[L.name].get("ws2")
+        if key is None:
+            return False
+        grp = self._ws2_groups[key]
+        if grp["idxs"][0] != i:
+            return False
+        if any(j in absorbed for j in grp["idxs"]):   # a member already runs inside another group: everyone back to the direct kernel
+            for name in grp["convs"]:
+                self._param_dev[name].pop("ws2", None)
+                self._dirty_params.add(name)
+            del self._ws2_groups[key]
+            return False
+        members = []
+        for j in grp["idxs"]:
+            Lj = layers[j]
+            self._emit_pos = i
+            try:
+                ep, label = self._conv_epilogue(j, Lj, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed,
+                                                concat_skip)
+            finally:
+                self._emit_pos = None
+            if j != i:
+                absorbed[j] = L.name
+            members.append((Lj, ep, label))
+        self._emit_ws2(i, key, members)
+        return True
+
+    def _emit_ws2(self, i: int, key: str, members) -> None:
+        grp = self._ws2_groups[key]
+        plan, up = grp["plan"], self.alloc.ptr(grp["up"])
+        lib = self.lib
+        L0 = members[0][0]
+        n, cin, D, H, W = L0.bottom_shapes[0]
+        Do, Ho, Wo = L0.top_shapes[0][2:]
+        ctot = sum(grp["couts"])
+        x = self._ptr(L0.bottoms[0])
+        v = self.alloc.ptr(self._wino_buf_v_elems)
+        m = self.alloc.ptr(self._wino_buf_m_elems)
+        pos = n * plan.d * plan.th * plan.tw                       # positions per transform point
+        S = Do * Ho * Wo
+        v_bytes, m_bytes = 4 * 320 * 8 * cin * pos, 4 * 320 * plan.ksplit * ctot * pos
+        x_bytes = 4 * n * cin * D * H * W
+        tag = "stride-2 winograd F(4,2)xF(7,2)xF(7,2)"
+        names = " | ".join(lb for _, _, lb in members)
+        self._keep.append(plan)
+        self._add(i, f"{names} [{tag} input transform]", lambda s: lib.wino_s2_input_forward(plan, x, v, D, H, W, s),
+                  {"kernel": "eco::wino_s2_input_kernel", "flops": 0, "bytes": x_bytes + v_bytes})
+        self._add(i, f"{names} [320 transformed-domain GEMMs, K = {8 * cin}]", lambda s: lib.wgemm_forward(plan, v, up, m, s),
+                  {"kernel": hip.wgemm_kernel_name(plan), "flops": 2 * 320 * pos * ctot * 8 * cin,
+                   "bytes": v_bytes + 4 * 320 * ctot * 8 * cin + m_bytes, "siblings": len(members)})
+        for (Lj, ep, label), c0 in zip(members, np.cumsum([0] + grp["couts"][:-1])):
+            cout = Lj.geom["cout"]
+            self._keep.append(ep)
+            touched = bool(ep.raw.ptr) + bool(ep.act.ptr) + bool(ep.residual.ptr) + bool(ep.act2.ptr)
+            self._add(i, f"{label} [{tag} output transform]",
+                      lambda s, c0=int(c0), cout=cout, ep=ep: lib.wino_s2_output_forward(plan, m, c0, cout, Do, Ho, Wo, ep, s),
+                      {"kernel": "eco::wino_s2_output_kernel", "flops": 0,
+                       "bytes": m_bytes * cout // ctot + 4 * n * cout * S * touched})
+
     # -- the stem: conv1_7x7_s2 + BN + ReLU + pool1_3x3_s2 as one launch (csrc/eco_stem.hip) --
     def _stem_geometry(self, L: LayerSpec) -> bool:
         g = L.geom
@@ -859,6 +1013,9 @@ class Engine:
         if "wino" in st:
             self._emit_wino_conv(i, L, ep, label, nbytes)
             return
+        if "ws2" in st and src is None and len(self._ws2_groups[st["ws2"]]["convs"]) == 1:
+            self._emit_ws2(i, st["ws2"], [(L, ep, label)])
+            return
         meta = {"kernel": hip.conv_kernel_name(plan), "flops": 2 * n_out * k, "bytes": nbytes}
         self._add(i, label, lambda s, g=g, plan=plan, x=x, wp=wp, kt=kt, ep=ep, ws=ws:
                   lib.conv_forward(g, plan, x, wp, kt, ep, ws, s), meta)
@@ -937,12 +1094,7 @@ class Engine:
     def _build_fused(self) -> None:
         spec = self.spec
         layers = spec.layers
-        # --- dataflow over "real" blobs: Split tops are names for their bottom -------------
-        self._alias_src: Dict[str, str] = {}
-        for L in layers:
-            if L.type == "Split":
-                for t in L.tops:
-                    self._alias_src[t] = self._resolve(L.bottoms[0])
+        # --- dataflow over "real" blobs: Split tops are names for their bottom (self._alias_src, build()) -------------
         consumers: Dict[str, List[int]] = {}
         for i, L in enumerate(layers):
             if L.type == "Split":
@@ -1012,8 +1164,10 @@ class Engine:
             if L.type == "Pooling" and i in self._commute_pools:
                 continue                     # runs behind its 1x1 conv (emitted with the conv, below)
             if L.type == "Convolution":
-                if not self._try_fuse_siblings(i, L, layers, consumers, outputs, sole_consumer, bn_relu_after,
-                                               absorbed, concat_skip):
+                if self._try_fuse_ws2(i, L, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed, concat_skip):
+                    pass
+                elif not self._try_fuse_siblings(i, L, layers, consumers, outputs, sole_consumer, bn_relu_after,
+                                                 absorbed, concat_skip):
                     self._fuse_conv(i, L, layers, consumers, outputs, sole_consumer, bn_relu_after, absorbed,
                                     concat_skip)
             elif L.type == "Pooling" and (self._try_fuse_tail(i, L, layers, sole_consumer, absorbed) or

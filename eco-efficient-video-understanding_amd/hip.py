@@ -21,7 +21,7 @@ ECO_ERR_INVALID = -1
 ECO_ERR_RUNTIME = -2
 POOL_MAX = 0
 POOL_AVE = 1
-ABI_VERSION = 18
+ABI_VERSION = 19
 MAX_SEG = 3   # ECO_MAX_SEG: extra output segments of a sibling launch
 DT_BF16 = 1
 DT_F32X3 = 3
@@ -239,6 +239,12 @@ _SIGNATURES = {
                                           C.c_void_p]),
     "eco_wino3_output_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                            C.POINTER(ConvEpilogue), C.c_void_p]),
+    "eco_wino_s2_weight_transform": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "eco_wino_s2_lds_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "eco_wino_s2_input_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                            C.c_void_p]),
+    "eco_wino_s2_output_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                             C.c_int32, C.POINTER(ConvEpilogue), C.c_void_p]),
     "eco_wfused_pool_scratch_elems": (C.c_int64, [C.POINTER(WGemmPlan)]),
     "eco_wfused_pool_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                           C.POINTER(ConvEpilogue), C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -415,6 +421,23 @@ class EcoLib:
 
     def wino3_output_forward(self, p: "WGemmPlan", m: int, d: int, h: int, w: int, ep: ConvEpilogue, stream=None) -> None:
         self._check(self._dll.eco_wino3_output_forward(C.byref(p), m, d, h, w, C.byref(ep), stream))
+
+    # -- stride-2 3x3x3 convolutions as polyphase F(4,2) x F(7,2) x F(7,2) problems on the same GEMM (csrc/eco_wino_s2.hip) --
+    def wino_s2_weight_transform(self, w_host: int, cout: int, cin: int, u_host: int) -> None:
+        """u[320][cout][8 cin] from w[cout][cin][3][3][3] (host)."""
+        self._check(self._dll.eco_wino_s2_weight_transform(w_host, cout, cin, u_host))
+
+    def wino_s2_lds_bytes(self, n: int, td: int, th: int, tw: int) -> int:
+        return int(self._dll.eco_wino_s2_lds_bytes(n, td, th, tw))
+
+    def wino_s2_input_forward(self, p: "WGemmPlan", x: int, v: int, d: int, h: int, w: int, stream=None) -> None:
+        """(d, h, w): the INPUT volume; the plan is wgemm_plan(n, 8 * cin, ctot, d/8, h/14, w/14, 1, points=320)."""
+        self._check(self._dll.eco_wino_s2_input_forward(C.byref(p), x, v, d, h, w, stream))
+
+    def wino_s2_output_forward(self, p: "WGemmPlan", m: int, c0: int, cout: int, od: int, oh: int, ow: int, ep: ConvEpilogue,
+                               stream=None) -> None:
+        """Channels [c0, c0 + cout) of the GEMM's rows -> the (od, oh, ow) OUTPUT volume with the member's epilogue."""
+        self._check(self._dll.eco_wino_s2_output_forward(C.byref(p), m, c0, cout, od, oh, ow, C.byref(ep), stream))
 
     def wgemm_pack_weights(self, p: "WGemmPlan", u_host: int, up_host: int) -> None:
         self._check(self._dll.eco_wgemm_pack_weights(C.byref(p), u_host, up_host))

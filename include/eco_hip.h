@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ECO_ABI_VERSION 18
+#define ECO_ABI_VERSION 19
 
 #define ECO_OK 0
 #define ECO_ERR_INVALID (-1) /* bad argument / geometry not supported on this path */
@@ -377,7 +377,7 @@ int eco_stemb_forward(const float* x, const void* wp, const float* bias, const f
 typedef struct eco_wgemm_plan {
   int32_t n, cin, cout, d, th, tw; /* clips/images, channels, depth, tiles per plane (ceil(H/4), ceil(W/4))   */
   int32_t kd;                      /* 1 (2-D 3x3) or 3 (3x3x3, depth taps direct)                             */
-  int32_t points;                  /* 36; 216 = F(4x4x4,3x3x3) below (kd = 1, d = depth TILES)                */
+  int32_t points;                  /* 36; 216 = F(4x4x4,3x3x3), 320 = the stride-2 form below (kd = 1, d = depth TILES) */
   int32_t bm, bn;                  /* block tile: output channels x positions                                 */
   int32_t nstages;                 /* (cin/16) * kd stages of 16 reduction elements                           */
   int32_t ksplit;                  /* split-K slices (rows of m)                                              */
@@ -435,6 +435,33 @@ int eco_wino3_input_forward(const eco_wgemm_plan* plan, const float* x, float* v
                             void* stream);
 int eco_wino3_output_forward(const eco_wgemm_plan* plan, const float* m, int32_t d, int32_t h, int32_t w,
                              const eco_conv_epilogue* ep, void* stream);
+
+/* ---- STRIDE-2 3x3x3 convolutions as polyphase minimal-filtering problems (csrc/eco_wino_s2.hip, ABI v19) ------
+ *
+ * res4a_1 / res4a_down (stride 2, pad 1, 3x3x3; models_ECO_Lite/kinetics/deploy.prototxt:1262-1330).  Per axis
+ * out[o] = (w0, w2) * x_odd[o-1 .. o] + (0, w1) * x_even[o-1 .. o]: eight stride-1 two-tap problems on the even / odd
+ * sub-lattices of the input, F(4,2) over depth and F(7,2) over rows and columns, all on the same 5 x 8 x 8 = 320
+ * transform points, so that the phases accumulate in the transformed domain like input channels (K = 8 cin):
+ * 13.1 multiplies per output and input channel instead of 27, no tile overhang where the OUTPUT volume tiles by
+ * 4 x 7 x 7 (8 x 14 x 14 at num_segments 16) and the input volume is exactly twice the output volume.
+ *   plan = eco_wgemm_plan_create(n, 8 * cin, ctot, Do/4, Ho/7, Wo/7, kd = 1, points = 320, ...)
+ *   v[p][k/2][r][2], m[p][slice][ctot][r]    p = (az*8 + ay)*8 + ax, k = ((c*2 + fz)*2 + fy)*2 + fx (f = 1: odd phase),
+ *                                            r = ((b*td + tz)*th + ty)*tw + tx
+ *   up = eco_wgemm_pack_weights(u), u = eco_wino_s2_weight_transform(w)      u[320][ctot][8 cin]
+ *   eco_wino_s2_input_forward(x -> v); eco_wgemm_forward(v, up -> m); eco_wino_s2_output_forward(m -> y, epilogue)
+ * Convolutions of one geometry that read the same blob (a residual block's first conv and its projection shortcut)
+ * concatenate their weights along cout (ctot rows), share v and the GEMM, and take one output-transform launch each:
+ * channels [c0, c0 + cout) of m with the member's own epilogue.  eco_wino_s2_lds_bytes(n, td, th, tw) must not exceed
+ * 152 KB (input planes up to ~56 x 56).  Results equal eco_conv_forward's up to fp32 rounding, ~1e-4 of the largest
+ * output per layer (cudnn_conv_layer.cu:15-65 leaves the algorithm to cuDNN). */
+int eco_wino_s2_weight_transform(const float* w, int32_t cout, int32_t cin, float* u); /* HOST */
+int64_t eco_wino_s2_lds_bytes(int32_t n, int32_t td, int32_t th, int32_t tw);
+/* (d, h, w): the INPUT volume (= twice the output volume) */
+int eco_wino_s2_input_forward(const eco_wgemm_plan* plan, const float* x, float* v, int32_t d, int32_t h, int32_t w,
+                              void* stream);
+/* (od, oh, ow): the OUTPUT volume; ep->nseg must be 0 */
+int eco_wino_s2_output_forward(const eco_wgemm_plan* plan, const float* m, int32_t c0, int32_t cout, int32_t od, int32_t oh,
+                               int32_t ow, const eco_conv_epilogue* ep, void* stream);
 
 /* ---- channel-blocked ("NC8") path on the bf16 matrix cores (csrc/eco_blocked.hip) -------------------------
  *

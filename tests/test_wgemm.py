@@ -372,3 +372,153 @@ def test_wino3_eco_trunk_layers(hip_backend, name, n, cin, cout, dims):
     e_raw, e_act = np.abs(be.host(y_raw, v.shape) - v).max(), np.abs(be.host(y_act, v.shape) - act).max()
     print(f"{name}: raw {e_raw / np.abs(v).max():.2e}, act {e_act / np.abs(v).max():.2e} of the largest output")
     assert e_raw <= tol and e_act <= tol
+
+
+# ---- stride-2 3x3x3 convolutions as polyphase F(4,2) x F(7,2) x F(7,2) problems (csrc/eco_wino_s2.hip) ------------------------
+S2_CASES = [  # n, cin, couts (members sharing v and the GEMM), OUTPUT volume (Do, Ho, Wo), num_cu
+    (1, 2, (32,), (4, 7, 7), None),          # one tile per image, K = 16: one stage, one depth tile per workgroup
+    (2, 4, (32, 64), (8, 7, 14), None),      # two members (first conv + projection shortcut), two depth tiles, two column tiles
+    (3, 2, (96,), (12, 14, 7), 1),           # three depth tiles (groups of two: the second ragged), bm = 96, tiny "device"
+]
+
+
+def run_wino_s2(backend, n, cin, couts, odims, num_cu, mode, relu_x=False, tol=5e-4):
+    Do, Ho, Wo = odims
+    D, H, W = 2 * Do, 2 * Ho, 2 * Wo
+    rng = np.random.default_rng(cin + sum(couts) + Ho + Do)
+    x = rng.normal(size=(n, cin, D, H, W)).astype(np.float32)
+    if relu_x:
+        x = np.maximum(x, 0)
+    ctot = sum(couts)
+    w = (rng.normal(size=(ctot, cin, 3, 3, 3)) / np.sqrt(cin * 27)).astype(np.float32)
+    b = rng.normal(size=ctot).astype(np.float32)
+    ref = orc.convolution(x, w, b, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    assert ref.shape == (n, ctot, Do, Ho, Wo)
+    lib = backend.lib
+    TD, TH, TW = Do // 4, Ho // 7, Wo // 7
+    plan = lib.wgemm_plan(n, 8 * cin, ctot, TD, TH, TW, 1, num_cu, points=320)
+    assert plan.points == 320 and plan.q == n * TD * TH * TW and plan.nstages == cin // 2
+    u = np.empty((320, ctot, 8 * cin, 1), np.float32)
+    lib.wino_s2_weight_transform(w.ctypes.data, ctot, cin, u.ctypes.data)
+    up = np.empty(plan.u_elems, np.float32)
+    lib.wgemm_pack_weights(plan, u.ctypes.data, up.ctypes.data)
+    vbuf = backend.dev(np.full(plan.v_elems, np.nan, np.float32))
+    mbuf = backend.empty((plan.m_elems,))
+    lib.wino_s2_input_forward(plan, backend.ptr(backend.dev(x)), backend.ptr(vbuf), D, H, W)
+    lib.wgemm_forward(plan, backend.ptr(vbuf), backend.ptr(backend.dev(up)), backend.ptr(mbuf))
+    S = Do * Ho * Wo
+    shp = (1, -1, 1, 1, 1)
+    worst = 0.0
+    c0 = 0
+    for k, cout in enumerate(couts):
+        v = ref[:, c0:c0 + cout]
+        scale = np.abs(v).max()
+        ep = hip.ConvEpilogue()
+        ep.bias = backend.ptr(backend.dev(b[c0:c0 + cout]))
+        ep.residual, ep.raw, ep.act, ep.act2 = hip.null_view(), hip.null_view(), hip.null_view(), hip.null_view()
+        ep.bn_scale = ep.bn_shift = None
+        ep.relu = 0
+        if mode == "plain" or (mode == "fused" and k % 2 == 1):     # (a shortcut keeps its raw value)
+            y_raw = backend.empty(v.shape)
+            ep.raw = hip.plain_view(backend.ptr(y_raw), cout, S)
+            lib.wino_s2_output_forward(plan, backend.ptr(mbuf), c0, cout, Do, Ho, Wo, ep)
+            worst = max(worst, np.abs(backend.host(y_raw, v.shape) - v).max() / scale)
+        else:
+            res = rng.normal(size=v.shape).astype(np.float32)
+            sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
+            ep.residual = hip.plain_view(backend.ptr(backend.dev(res)), cout, S)
+            ep.bn_scale, ep.bn_shift = backend.ptr(backend.dev(sc)), backend.ptr(backend.dev(sh))
+            ref_raw = v + res
+            if mode == "fused":        # bias + Eltwise residual + raw store + BN + ReLU
+                y_raw, y_act = backend.empty(v.shape), backend.empty(v.shape)
+                ep.relu = 1
+                ep.raw = hip.plain_view(backend.ptr(y_raw), cout, S)
+                ep.act = hip.plain_view(backend.ptr(y_act), cout, S)
+                lib.wino_s2_output_forward(plan, backend.ptr(mbuf), c0, cout, Do, Ho, Wo, ep)
+                worst = max(worst, np.abs(backend.host(y_raw, v.shape) - ref_raw).max() / scale,
+                            np.abs(backend.host(y_act, v.shape) - np.maximum(ref_raw * sc.reshape(shp) + sh.reshape(shp), 0)).max() / scale)
+            else:                      # views: no ReLU, the activated output into channel slices of two wider tensors, no raw output
+                o0, wide = 3, cout + 5
+                big = backend.dev(np.full((n, wide, Do, Ho, Wo), 7.0, np.float32))
+                big2 = backend.dev(np.full((n, wide, Do, Ho, Wo), -3.0, np.float32))
+                ep.act = hip.View(backend.ptr(big, o0 * S), wide * S, 0, S, 1)
+                ep.act2 = hip.View(backend.ptr(big2, 1 * S), wide * S, 0, S, 1)
+                lib.wino_s2_output_forward(plan, backend.ptr(mbuf), c0, cout, Do, Ho, Wo, ep)
+                ref_act = ref_raw * sc.reshape(shp) + sh.reshape(shp)
+                assert (ref_act < 0).any()
+                got, got2 = backend.host(big, (n, wide, Do, Ho, Wo)), backend.host(big2, (n, wide, Do, Ho, Wo))
+                worst = max(worst, np.abs(got[:, o0:o0 + cout] - ref_act).max() / scale,
+                            np.abs(got2[:, 1:1 + cout] - ref_act).max() / scale)
+                assert (got[:, :o0] == 7.0).all() and (got[:, o0 + cout:] == 7.0).all()
+                assert (got2[:, :1] == -3.0).all() and (got2[:, 1 + cout:] == -3.0).all()
+        c0 += cout
+    assert worst <= tol, worst
+    return worst
+
+
+@pytest.mark.parametrize("n,cin,couts,odims,num_cu", S2_CASES, ids=[f"s2_{i}" for i in range(len(S2_CASES))])
+@pytest.mark.parametrize("mode", ["plain", "fused", "views"])
+def test_wino_s2_route_matches_direct_conv(backend, n, cin, couts, odims, num_cu, mode):
+    """Input transform -> 320 GEMMs (K = 8 cin) -> one output transform per member against the oracle's direct stride-2
+    convolution.  Tolerance 5e-4 of the largest output (measured ~1e-4 at K = 1024: two nested eight-point transforms)."""
+    run_wino_s2(backend, n, cin, couts, odims, num_cu, mode)
+
+
+def test_wino_s2_weight_transform_is_the_polyphase_kronecker_product(backend):
+    """u[(az, ay, ax)][co][((ci*2 + fz)*2 + fy)*2 + fx] = sum G5[az][tz] G8[ay][ty] G8[ax][tx] g_f[tz][ty][tx] with, per axis,
+    g_1 = (w0, w2) (odd phase) and g_0 = (0, w1) (even phase); G = Cook-Toom evaluation rows over the row scales of B^T."""
+    G5 = np.array([[1, 0], [1 / 2, 1 / 2], [1 / 6, -1 / 6], [8 / 3, 4 / 3], [0, 1 / 2]])
+    G8 = np.array([[1, 0], [-2 / 9, -2 / 9], [-2 / 9, 2 / 9], [1 / 90, 2 / 90], [1 / 90, -2 / 90], [32 / 45, 16 / 45],
+                   [32 / 45, -16 / 45], [0, 1]])
+    rng = np.random.default_rng(7)
+    w = rng.normal(size=(3, 2, 3, 3, 3)).astype(np.float32)
+    u = np.empty((320, 3, 16), np.float32)
+    backend.lib.wino_s2_weight_transform(w.ctypes.data, 3, 2, u.ctypes.data)
+    sel = {1: [0, 2], 0: [1, 1]}
+    ref = np.empty((5, 8, 8, 3, 2, 2, 2, 2))
+    for fz in (0, 1):
+        for fy in (0, 1):
+            for fx in (0, 1):
+                g = w.astype(np.float64)[:, :, sel[fz]][:, :, :, sel[fy]][:, :, :, :, sel[fx]].copy()
+                if not fz:
+                    g[:, :, 0] = 0
+                if not fy:
+                    g[:, :, :, 0] = 0
+                if not fx:
+                    g[:, :, :, :, 0] = 0
+                ref[:, :, :, :, :, fz, fy, fx] = np.einsum("az,by,cx,oizyx->abcoi", G5, G8, G8, g)
+    assert np.abs(u - ref.reshape(320, 3, 16)).max() < 1e-6
+
+
+def test_wino_s2_rejects_wrong_plans_and_volumes(backend):
+    lib = backend.lib
+    p216 = lib.wgemm_plan(1, 32, 32, 1, 2, 2, 1, None, points=216)
+    with pytest.raises(hip.EcoError, match="320"):
+        lib.wino_s2_input_forward(p216, 0, 0, 8, 14, 14)
+    p = lib.wgemm_plan(1, 32, 32, 1, 1, 1, 1, None, points=320)
+    with pytest.raises(hip.EcoError, match="even"):
+        lib.wino_s2_input_forward(p, 0, 0, 7, 14, 14)
+    with pytest.raises(hip.EcoError, match="4x7x7"):
+        lib.wino_s2_input_forward(p, 0, 0, 8, 16, 14)
+    with pytest.raises(hip.EcoError, match="tiles"):
+        lib.wino_s2_input_forward(p, 0, 0, 16, 14, 14)    # two depth tiles, plan has one
+    ep = hip.ConvEpilogue()
+    ep.residual, ep.raw, ep.act, ep.act2 = hip.null_view(), hip.plain_view(64, 8, 196), hip.null_view(), hip.null_view()
+    with pytest.raises(hip.EcoError, match="channels"):
+        lib.wino_s2_output_forward(p, 64, 28, 8, 4, 7, 7, ep)
+    assert lib.wino_s2_lds_bytes(32, 2, 2, 2) == 2 * 10 * 30 * 32 * 4 and lib.wino_s2_lds_bytes(1, 1, 1, 1) == 10 * 16 * 20 * 4
+
+
+S2_ECO = [  # id, n, cin, couts, OUTPUT volume: models_ECO_Lite/kinetics/deploy.prototxt:1262-1330 at num_segments 16 / 32
+    ("res4a", 2, 128, (256, 256), (8, 14, 14)),
+    ("res4a_n32", 1, 128, (256,), (16, 14, 14)),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n,cin,couts,odims", S2_ECO, ids=[c[0] for c in S2_ECO])
+def test_wino_s2_eco_trunk_layers(hip_backend, name, n, cin, couts, odims):
+    """res4a_1 | res4a_down at their real size (K = 1024, 512 GEMM rows) on a ReLU'd input, the first member with the
+    Eltwise residual + raw + BN + ReLU epilogue, against the oracle's direct convolution."""
+    worst = run_wino_s2(hip_backend, n, cin, couts, odims, None, "fused", relu_x=True)
+    print(f"{name}: {worst:.2e} of the largest output")
