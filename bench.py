@@ -262,6 +262,18 @@ def main() -> None:
         roofline["traffic"], roofline["traffic_unit"] = None, f"null: {type(e).__name__}: {e}"
     if roofline["traffic"] is not None and dom["bytes"] > 0:
         roofline["traffic_ratio"] = round(roofline["traffic"] / (dom["bytes"] / dom["launches"] / 1e9), 3)
+    # the whole step's HBM traffic by the same counters (every eco:: kernel of the PMC passes, bytes per launch x launches
+    # per step) beside SURVEY.md section 8(d)'s fused-model figure (each conv / fc: input + weights + output once, pools in +
+    # out, residual reads, dual writes): the excess is the Winograd routes' V / M scratch and split-K partial sums
+    try:
+        roofline["step_traffic_gb"], roofline["step_traffic_unit"] = step_traffic_from_summary(tr, workload_key, src_now)
+    except Exception as e:
+        roofline["step_traffic_gb"], roofline["step_traffic_unit"] = None, f"null: {type(e).__name__}: {e}"
+    fused_gb = spec.fused_model_bytes() / 1e9 if hasattr(spec, "fused_model_bytes") else None
+    roofline["step_fused_model_gb"] = round(fused_gb, 2) if fused_gb is not None else None
+    roofline["step_launch_model_gb"] = round(sum(p["bytes"] for p in prof) / 1e9, 2)   # what the launches must move, V / M included
+    if roofline["step_traffic_gb"] is not None and fused_gb:
+        roofline["step_traffic_ratio_to_fused_model"] = round(roofline["step_traffic_gb"] / fused_gb, 3)
     executed = sum(p["flops"] for p in prof)
     roofline.update({
         "kernel": dom_name, "largest_instance": dom_inst, "launches_per_step": dom["launches"],
@@ -337,7 +349,8 @@ def main() -> None:
     cfg = baseline_config(args.variant, N, B, args.dtype, world)
     name = "Lite" if args.variant == "lite" else "Full"
     line = {
-        "metric": "clips/sec (whole node), ECO-%s N=%d 224x224 bs%d; top-1 logits vs CPU ref" % (name, N, B),
+        # (spelled exactly as BASELINE.json's `metric`: U+00D7 between the frame extents)
+        "metric": "clips/sec (whole node), ECO-%s N=%d 224\u00d7224 bs%d; top-1 logits vs CPU ref" % (name, N, B),
         "value": round(clips_per_s, 2), "unit": "clips/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -432,6 +445,24 @@ def traffic_from_summary(tr, workload_key, family, src_now):
     w = sum(c.get("launches", 1) for c in rows.values())
     gb = round(sum(c["hbm_bytes_per_launch"] * c.get("launches", 1) for c in rows.values()) / w / 1e9, 4)
     return gb, "GB per launch (PMC, " + tsrc + ", same sources " + src_now[:12] + ")"
+
+
+def step_traffic_from_summary(tr, workload_key, src_now):
+    """(GB per step or None, unit / reason): sum over every eco:: kernel of the workload's PMC passes of corrected HBM bytes per
+    launch x launches, divided by the steps those passes ran (`pmc_steps` of profiles/hbm_traffic_latest.json)."""
+    if workload_key == tr.get("workload", "lite/16/32/f32"):
+        tk, tsrc = tr["kernels"], tr["source"]
+    elif workload_key in tr.get("workloads", {}):
+        tk, tsrc = tr["workloads"][workload_key]["kernels"], tr["workloads"][workload_key]["source"]
+    else:
+        return None, f"null: no PMC passes of workload {workload_key} in profiles/hbm_traffic_latest.json"
+    if tr.get("src_sha256") is None or tr.get("src_sha256") != src_now:
+        return None, "null: profiles/hbm_traffic_latest.json was collected on a build of other sources"
+    steps = tr.get("pmc_steps")
+    if not steps:
+        return None, "null: profiles/hbm_traffic_latest.json does not say how many steps its PMC passes ran"
+    tot = sum(c["hbm_bytes_per_launch"] * c.get("launches", 1) for k, c in tk.items() if k.startswith("eco::"))
+    return round(tot / steps / 1e9, 2), f"GB per step (PMC FETCH_SIZE x 2 + WRITE_SIZE over {steps} steps, {tsrc})"
 
 
 def parity_record(got, ref, dtype: str, what: str, clips=None) -> dict:
@@ -575,7 +606,7 @@ def cpu_baseline(args, gen, N, frames, params, logits):
         # one "image" per clip, so fewer clips would leave most cores idle there)
         par = args.cpu_clips or min(32, len(frames) // N)
         img_threads = min(cores, 64)   # OpenBLAS keeps one buffer per concurrent caller, at most its NUM_THREADS (64)
-        d2, t2, _ = run(lambda *a: eco_ref.convolution(*a, image_threads=img_threads), 0.0, par, clips_at_once=par)
+        d2, t2, ref_all = run(lambda *a: eco_ref.convolution(*a, image_threads=img_threads), 0.0, par, clips_at_once=par)
         variants["image_parallel"] = dict(clips_per_s=round(d2 / t2, 4), clips=d2, seconds=round(t2, 2), blas_threads=1,
                                           image_threads=img_threads,
                                           kind="same arithmetic, one batch of clips at once, images spread over host threads")
@@ -598,6 +629,15 @@ def cpu_baseline(args, gen, N, frames, params, logits):
     done = cc["clips"]
     got = logits[:done].detach().float().cpu().numpy()
     parity = parity_record(got, ref, args.dtype, "caffe_cost CPU run above: " + cc["kind"], list(range(done)))
+    if have_ref and d2 > done:
+        # the image_parallel leg computed EVERY clip of the batch on the CPU (the reference's im2col + sgemm call sequence,
+        # pinned bit-identically to the compiled ConvolutionLayer class in tests/test_oracle_ref.py): the line's parity
+        # record covers them all; the record against the class itself (first clips) stays beside it
+        first = parity
+        parity = parity_record(logits[:d2].detach().float().cpu().numpy(), ref_all, args.dtype,
+                               "image_parallel CPU run above (reference im2col, compiled from util/im2col.cpp, + OpenBLAS sgemm; "
+                               "all clips of the batch)", list(range(d2)))
+        parity["first_clips_vs_convolution_layer_class"] = first
     return cpu, parity
 
 

@@ -22,25 +22,56 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// (round-5 advisor finding) Three ways the slot of a launch could be shared by launches that run concurrently, all closed:
+//   * hipStreamPerThread is ONE handle value for a different real stream in every host thread: static shares (-1).
+//     (The null stream and hipStreamLegacy name the same, process-wide, in-order stream: one slot.)
+//   * the capture ring wrapped: two live graphs could hold the same slot.  Capture slots are now handed out once; when the
+//     192 are gone, captured launches take static shares until eco_counters_release_capture_slots() says that every graph
+//     captured so far has been destroyed.
+//   * the 64-entry stream table never forgot a destroyed stream: a process that creates and destroys streams ended on
+//     static shares for good.  A full table now recycles the entry of a stream that has no work in flight (destroyed
+//     handles and idle streams alike: hipStreamQuery says anything but hipErrorNotReady).
+static std::mutex g_slot_mu;
+static void* g_seen[64];
+static int g_nseen = 0;
+static unsigned g_cap_next = 0;
+
 int counter_slot_index(void* stream) {
-  static std::mutex mu;
-  static void* seen[64];
-  static int nseen = 0;
-  static unsigned cap_seq = 0;
-  std::lock_guard<std::mutex> lock(mu);
+  std::lock_guard<std::mutex> lock(g_slot_mu);
 #ifndef ECO_EMU
+  if ((hipStream_t)stream == hipStreamPerThread) return -1;
+  if ((hipStream_t)stream == hipStreamLegacy) stream = nullptr;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing((hipStream_t)stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive)
-    return 64 + (int)(cap_seq++ % 192u);
-#else
-  (void)cap_seq;
+    return g_cap_next < 192u ? 64 + (int)(g_cap_next++) : -1;
 #endif
-  for (int i = 0; i < nseen; ++i)
-    if (seen[i] == stream) return i;
-  if (nseen == 64) return -1;
-  seen[nseen] = stream;
-  return nseen++;
+  for (int i = 0; i < g_nseen; ++i)
+    if (g_seen[i] == stream) return i;
+  if (g_nseen < 64) {
+    g_seen[g_nseen] = stream;
+    return g_nseen++;
+  }
+#ifndef ECO_EMU
+  for (int i = 0; i < 64; ++i) {
+    if (g_seen[i] == nullptr) continue;                       // (the null stream is never evicted)
+    const hipError_t q = hipStreamQuery((hipStream_t)g_seen[i]);
+    (void)hipGetLastError();                                  // an invalid (destroyed) handle must not look like a launch failure
+    if (q != hipErrorNotReady) {
+      g_seen[i] = stream;
+      return i;
+    }
+  }
+#endif
+  return -1;
 }
+
+void counter_release_capture_slots() {
+  std::lock_guard<std::mutex> lock(g_slot_mu);
+  g_cap_next = 0;
+}
+
+// test hook (tests/test_advice_r5.py through eco_counter_slot_probe): the slot a launch on `stream` would get
+int counter_slot_probe(void* stream) { return counter_slot_index(stream); }
 
 }  // namespace eco
 
@@ -136,3 +167,14 @@ extern "C" int eco_counters_reset(void* stream) {
   if (int rc = eco::spanp_counters_reset(stream)) return rc;
   return eco::stemb_counters_reset(stream);
 }
+
+namespace eco {
+void counter_release_capture_slots();
+int counter_slot_probe(void* stream);
+}
+extern "C" int eco_counters_release_capture_slots(void) {
+  clear_error();
+  eco::counter_release_capture_slots();
+  return ECO_OK;
+}
+extern "C" int eco_counter_slot_probe(void* stream) { return eco::counter_slot_probe(stream); }

@@ -32,6 +32,7 @@ namespace eco {
 constexpr int kWgP = 36;   // F(4x4,3x3): 6x6 transform points
 constexpr int kWgP3 = 216; // F(4x4x4,3x3x3): 6x6x6 transform points (the GEMM only sees more, shorter problems)
 constexpr int kWgPS2 = 320; // stride-2 3x3x3 as eight polyphase F(4,2) x F(7,2) x F(7,2) problems: 5x8x8 points (eco_wino_s2.hip)
+constexpr int kWgPS2D = 64; // ... and its 2-D form, F(7,2) x F(7,2) with direct depth taps in the reduction
 constexpr int kWgKp = 8;             // k-pairs (16 reduction elements) per stage
 
 struct WGemmArgs {
@@ -739,9 +740,9 @@ using namespace eco;
 
 static int wgemm_check_plan(const eco_wgemm_plan* p) {
   ECO_REQUIRE(p != nullptr, "wgemm: null plan");
-  ECO_REQUIRE(p->points == kWgP || ((p->points == kWgP3 || p->points == kWgPS2) && p->kd == 1),
-              "wgemm: F(4x4,3x3) (36 transform points) or, with kd = 1, F(4x4x4,3x3x3) (216) / the stride-2 polyphase form (320) is "
-              "supported, got %d", p->points);
+  ECO_REQUIRE(p->points == kWgP || ((p->points == kWgP3 || p->points == kWgPS2 || p->points == kWgPS2D) && p->kd == 1),
+              "wgemm: F(4x4,3x3) (36 transform points) or, with kd = 1, F(4x4x4,3x3x3) (216) / the stride-2 polyphase forms (320, 64) "
+              "are supported, got %d", p->points);
   ECO_REQUIRE(p->n > 0 && p->cin > 0 && p->cin % 16 == 0 && p->cout > 0 && p->d > 0 && p->th > 0 && p->tw > 0 &&
                   (p->kd == 1 || p->kd == 3),
               "wgemm: bad problem (n=%d cin=%d cout=%d d=%d tiles %dx%d kd=%d; cin must be a multiple of 16)", p->n, p->cin,
@@ -1107,11 +1108,13 @@ extern "C" int64_t eco_wfused_pool_scratch_elems(const eco_wgemm_plan* plan) {
 
 extern "C" int eco_wfused_pool_forward(const eco_wgemm_plan* plan, const float* v, const float* up, int32_t h, int32_t w,
                                        const eco_conv_epilogue* ep, float* scratch, float* y, void* stream) {
+  clear_error();
+  // every argument is checked before the first launch: an error return leaves nothing enqueued (round-5 advisor finding)
   ECO_REQUIRE(scratch && y, "wfused + pooling: null scratch / output");
+  ECO_REQUIRE(((uintptr_t)y & 7) == 0, "wfused + pooling: the pooled blob must be 8-byte aligned");
   if (int rc = wfused_launch(plan, v, up, h, w, ep, scratch, stream)) return rc;
   const long planes = (long)plan->n * plan->cout;
   const long total = planes * 2 * plan->th * plan->tw;
-  ECO_REQUIRE(((uintptr_t)y & 7) == 0, "wfused + pooling: the pooled blob must be 8-byte aligned");
   hipLaunchKernelGGL((pool9_finish_kernel), dim3(wg_grid(total)), dim3(256), 0, (hipStream_t)stream, scratch, y, planes, plan->th,
                      plan->tw);
   return check_launch("eco_wfused_pool_forward");

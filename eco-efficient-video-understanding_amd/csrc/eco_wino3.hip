@@ -60,26 +60,20 @@ __device__ __forceinline__ void w3_at(const float (&m)[6], float (&y)[4]) {
 }
 
 // A 16-byte LDS read that IS one ds_read_b128: from dynamic LDS with run-time row pitches the compiler splits a float4
-// load into two ds_read2_b32 (it cannot see the 16-byte alignment the layout guarantees).  Not tracked by the compiler's
-// wait counts: lds_wait(values) before the first use.
+// load into two ds_read2_b32 (it cannot see the 16-byte alignment the layout guarantees).  Told that the pointer is an
+// LDS address (address space 3) with 16-byte alignment it emits the instruction itself AND tracks its lgkmcnt -- round 5
+// issued the read from inline asm with a plain "=v" output, whose register the compiler took for valid at once (round-5
+// advisor finding: a copy or spill between the 18 reads and the wait would have moved stale data).
 typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4 lds_ld16(const float* p) {
 #ifdef ECO_EMU
   return *(const f4*)p;
 #else
-  f4 v;
-  // ("memory": the compiler must not move this read ahead of the LDS stores / the barrier in front of it -- it does not
-  // know the instruction reads LDS)
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)p) : "memory");
-  return v;
+  typedef __attribute__((address_space(3))) const f4 lds_f4_t;
+  return *(lds_f4_t*)__builtin_assume_aligned((__attribute__((address_space(3))) const float*)p, 16);
 #endif
 }
-// (the values are in/out operands of the wait: nothing that reads them may be scheduled ahead of it)
-__device__ __forceinline__ void lds_wait(f4& a, f4& b, f4& c) {
-#ifndef ECO_EMU
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
-#endif
-}
+__device__ __forceinline__ void lds_wait(f4&, f4&, f4&) {}   // (the compiler's own wait counts cover the reads now)
 
 struct Wino3InArgs {
   const float* x;   // [n][cin][D][H][W]

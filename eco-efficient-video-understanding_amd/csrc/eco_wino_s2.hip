@@ -16,6 +16,15 @@
 // channels 0.66 ms at 131 TFLOP/s, against 2 x (0.82 + 0.06) ms on the direct kernel.  res5a (4 x 7 x 7 outputs: one
 // tile per clip, 32 positions per point) would stream 1.3 GB of transformed weights per layer and stays direct.
 //
+// THE 2-D FORM (points = 64): where the output volume has too few 4 x 7 x 7 tiles for that (res5a: 4 x 7 x 7 outputs, one tile
+// per clip -- 32 positions per point would stream 1.3 GB of transformed weights per layer) or there is no depth axis at all
+// (ECO-Full's strided 2-D 3x3 convs: inception_3c / 4e, models_ECO_Full/kinetics/deploy.prototxt:1854-1990, 3420-3560), only
+// rows and columns are transformed, F(7,2) x F(7,2) on the four (row, column) phases, and the depth taps stay direct -- they
+// join the reduction: K = kz * 4 cin with kz = 3 (stride-2 depth, pad 1) or 1 (2-D), and every OUTPUT PLANE is a position:
+//   V2[p][k/2][r][k%2]   p = ay*8 + ax,  k = ((c*kz + tz)*2 + fy)*2 + fx,  r = ((b*Do + od)*TH + th)*TW + tw,
+//                        the (tz, od) entry transformed from input plane 2 od + tz - 1 (zeros outside the volume)
+// 64 * 4 * kz / 49 = 15.7 (kz = 3) / 5.2 (kz = 1) multiplies per output and input channel instead of 27 / 9.
+//
 //   V[p][k/2][r][k%2]    p = (az*8 + ay)*8 + ax,  k = ((c*2 + fz)*2 + fy)*2 + fx  (f = 1: odd phase),
 //                        r = ((b*TD + td)*TH + th)*TW + tw                       (the GEMM's kd = 1 layout, eco_wgemm.hip)
 //   M[p][slice][cout][r]
@@ -31,7 +40,8 @@
 
 namespace eco {
 
-constexpr int kS2P = 320;
+constexpr int kS2P = 320;    // F(4,2) x F(7,2) x F(7,2): 5 x 8 x 8 points
+constexpr int kS2P2 = 64;    // the 2-D form: F(7,2) x F(7,2)
 
 // ---- 1-D transforms ------------------------------------------------------------------------------------------------
 // F(4,2), points (0, 1, -1, 1/2, inf).  B^T rows scaled by (1, 2, 6, 3/8, 2):
@@ -228,8 +238,11 @@ struct S2OutArgs {
 // tile, plane position) folds the five depth points into four output planes and applies the fused epilogue (bias,
 // Eltwise residual, raw store, folded BN, ReLU, both activated destinations; strided views); lanes walk a plane in
 // memory order.
+// ZT = false: the 2-D form -- no depth points (a.TD counts OUTPUT PLANES, each its own position), phase B is the epilogue alone.
+template <bool ZT>
 __global__ __launch_bounds__(256) void wino_s2_output_kernel(const S2OutArgs a) {
-  ECO_DYNAMIC_LDS(sp);   // [5 az][GB * TD][Ho * Wo]
+  constexpr int NZ = ZT ? 5 : 1;
+  ECO_DYNAMIC_LDS(sp);   // [NZ az][GB * TD][Ho * Wo]
   const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
   const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int bg = wg % a.nbg, ch = wg / a.nbg;
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(256) void wino_s2_output_kernel(const S2OutArgs a) 
   const int npl = a.GB * a.TD;
 
   // ---- phase A ----
-  for (int it = tid; it < 5 * npos; it += nthr) {
+  for (int it = tid; it < NZ * npos; it += nthr) {
     const int pos = it % npos, az = it / npos;
     const int bl = pos / tpi, rem = pos - bl * tpi;
     const int td = rem / tpp, tt = rem - td * tpp;
@@ -283,36 +296,143 @@ __global__ __launch_bounds__(256) void wino_s2_output_kernel(const S2OutArgs a) 
     const int bl = pl / a.TD, td = pl - bl * a.TD;
     const int b = b0 + bl;
     const float* src = sp + (long)pl * S + s;
-    const float mz[5] = {src[0], src[az_stride], src[2 * az_stride], src[3 * az_stride], src[4 * az_stride]};
-    float y[4];
-    s2_at4(mz, y);
-    const long spo = (long)(4 * td) * S + s;
+    constexpr int NO = ZT ? 4 : 1;                      // output planes per item
+    float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (ZT) {
+      const float mz[5] = {src[0], src[az_stride], src[2 * az_stride], src[3 * az_stride], src[4 * az_stride]};
+      s2_at4(mz, y);
+    } else {
+      y[0] = src[0];
+    }
+    const long spo = (long)(NO * td) * S + s;
     const long rb = a.residual.ptr ? view_base(a.residual, b, 0) + (long)ch * a.residual.stride_c + spo : 0;
     float res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (a.residual.ptr) {
 #pragma unroll
-      for (int o = 0; o < 4; ++o)
-        if (4 * td + o < a.Do) res[o] = ld(a.residual.ptr + rb + (long)o * S);
+      for (int o = 0; o < NO; ++o)
+        if (NO * td + o < a.Do) res[o] = ld(a.residual.ptr + rb + (long)o * S);
     }
 #pragma unroll
-    for (int o = 0; o < 4; ++o) y[o] += bias + res[o];
+    for (int o = 0; o < NO; ++o) y[o] += bias + res[o];
     if (a.raw.ptr) {
       float* op = a.raw.ptr + view_base(a.raw, b, 0) + (long)ch * a.raw.stride_c + spo;
 #pragma unroll
-      for (int o = 0; o < 4; ++o)
-        if (4 * td + o < a.Do) st(op + (long)o * S, y[o]);
+      for (int o = 0; o < NO; ++o)
+        if (NO * td + o < a.Do) st(op + (long)o * S, y[o]);
     }
     if (a.act.ptr) {
       float* op = a.act.ptr + view_base(a.act, b, 0) + (long)ch * a.act.stride_c + spo;
       float* op2 = a.act2.ptr ? a.act2.ptr + view_base(a.act2, b, 0) + (long)ch * a.act2.stride_c + spo : nullptr;
 #pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        if (4 * td + o >= a.Do) continue;
+      for (int o = 0; o < NO; ++o) {
+        if (NO * td + o >= a.Do) continue;
         const float v = y[o] * sc + sh;
         const float z = a.relu ? fmaxf(v, 0.0f) : v;
         st(op + (long)o * S, z);
         if (op2) st(op2 + (long)o * S, z);
       }
+    }
+  }
+}
+
+// ---- the 2-D form's input transform ---------------------------------------------------------------------------------
+struct S2dInArgs {
+  const float* x;   // [n][cin][D][H][W]; D = 2 Do (kz = 3) or Do (kz = 1; D = 1 for a 2-D blob), H = 14 TH, W = 14 TW
+  float* v;
+  int n, cin, D, H, W, Do, TH, TW, KZ;
+  int GB, nbg;      // images per workgroup, image groups
+  int PH, PW;       // parked plane: rows H + 2, columns W + 4 rounded up to 4, zero borders above / left
+  int Q;            // positions per k-pair row: n * Do * TH * TW
+  long v_pstride;
+};
+
+// One workgroup per (input channel, group of GB images): the channel's planes of the group are parked in LDS with zero
+// borders (phase 1, 16-byte column groups), then one thread per (position = (image, output plane, tile), depth tap, row
+// phase) transforms its 8 rows x 16 columns along w and h and writes 8 x 8 points for the column-phase pair (phase 2), as
+// in the 3-D form.  A depth tap that falls outside the volume (plane -1) writes zeros: V is a dense GEMM operand.
+template <int VEC>
+__global__ __launch_bounds__(256) void wino_s2d_input_kernel(const S2dInArgs a) {
+  ECO_DYNAMIC_LDS(zd);   // [GB][D][PH][PW]
+  const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
+  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int bg = wg % a.nbg, c = wg / a.nbg;
+  const int b0 = bg * a.GB;
+  const int gb = a.n - b0 < a.GB ? a.n - b0 : a.GB;
+  const int plane = a.PH * a.PW;
+  const long hw = (long)a.H * a.W;
+
+  // ---- phase 1 ----
+  const int pwv = a.PW / 4;
+  const int slots = gb * a.D * a.PH * pwv;
+  for (int s = tid; s < slots; s += nthr) {
+    const int pv = s % pwv;
+    int t = s / pwv;
+    const int ph = t % a.PH;
+    t /= a.PH;                                            // = bl * D + d
+    const int bl = t / a.D, d = t - bl * a.D;
+    const int h = ph - 2, w0 = 4 * pv - 4;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h >= 0 && w0 >= 0 && w0 < a.W) {
+      const float* xp = a.x + (((long)(b0 + bl) * a.cin + c) * a.D + d) * hw + (long)h * a.W + w0;
+      if (VEC == 4) {
+        q = ld((const float4*)xp);
+      } else {
+        q.x = ld(xp);
+        if (w0 + 1 < a.W) q.y = ld(xp + 1);
+        if (w0 + 2 < a.W) q.z = ld(xp + 2);
+        if (w0 + 3 < a.W) q.w = ld(xp + 3);
+      }
+    }
+    *(float4*)(zd + (long)t * plane + ph * a.PW + 4 * pv) = q;
+  }
+  __syncthreads();
+
+  // ---- phase 2 ----
+  const int tpp = a.TH * a.TW, tpi = a.Do * tpp, npos = gb * tpi;
+  for (int it = tid; it < 2 * a.KZ * npos; it += nthr) {
+    const int pos = it % npos, combo = it / npos;
+    const int bl = pos / tpi, rem = pos - bl * tpi;
+    const int od = rem / tpp, tt = rem - od * tpp;
+    const int th = tt / a.TW, tw = tt - th * a.TW;
+    const int fy = combo & 1, tz = combo >> 1;
+    const int d = a.KZ == 3 ? 2 * od + tz - 1 : od;
+    const long r = (long)(b0 + bl) * tpi + rem;
+    const long kp = ((long)c * a.KZ + tz) * 2 + fy;
+    float* vo = a.v + (kp * a.Q + r) * 2;
+    if (d < 0) {                                          // (d <= D - 1 always: D = 2 Do)
+#pragma unroll 8
+      for (int p = 0; p < 64; ++p) st((float2*)(vo + (long)p * a.v_pstride), make_float2(0.0f, 0.0f));
+      continue;
+    }
+    const float* src = zd + ((long)bl * a.D + d) * plane + (14 * th + fy) * a.PW + 14 * tw + 2;
+    float t[8][2][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float row[16];
+      const float2* rp = (const float2*)(src + 2 * i * a.PW);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float2 q = rp[j];
+        row[2 * j] = q.x;
+        row[2 * j + 1] = q.y;
+      }
+#pragma unroll
+      for (int fx = 0; fx < 2; ++fx) {
+        const float dd[8] = {row[fx], row[2 + fx], row[4 + fx], row[6 + fx], row[8 + fx], row[10 + fx], row[12 + fx], row[14 + fx]};
+        s2_bt8(dd, t[i][fx]);
+      }
+    }
+#pragma unroll
+    for (int ax = 0; ax < 8; ++ax) {
+      float y0[8], y1[8];
+      {
+        const float c0[8] = {t[0][0][ax], t[1][0][ax], t[2][0][ax], t[3][0][ax], t[4][0][ax], t[5][0][ax], t[6][0][ax], t[7][0][ax]};
+        s2_bt8(c0, y0);
+        const float c1[8] = {t[0][1][ax], t[1][1][ax], t[2][1][ax], t[3][1][ax], t[4][1][ax], t[5][1][ax], t[6][1][ax], t[7][1][ax]};
+        s2_bt8(c1, y1);
+      }
+#pragma unroll
+      for (int ay = 0; ay < 8; ++ay) st((float2*)(vo + (long)(ay * 8 + ax) * a.v_pstride), make_float2(y0[ay], y1[ay]));
     }
   }
 }
@@ -340,6 +460,29 @@ static S2Shape s2_shape(int n, int td, int th, int tw) {
   s.GB = gb;
   s.nbg = (int)ceil_div(n, gb);
   s.lds_out = gb * per_image;
+  return s;
+}
+
+struct S2dShape { int GB, nbg, PH, PW; size_t lds_in; int GBo, nbgo; size_t lds_out; };
+static S2dShape s2d_shape(int n, int kz, int od, int th, int tw) {
+  S2dShape s;
+  const int D = kz == 3 ? 2 * od : od;
+  s.PH = 14 * th + 2;
+  s.PW = (14 * tw + 4 + 3) / 4 * 4;
+  const int tpi = od * th * tw;
+  const size_t in_image = (size_t)D * s.PH * s.PW * 4, out_image = (size_t)od * 49 * th * tw * 4;
+  auto group = [&](size_t per_image, size_t budget) {
+    int gb = (int)ceil_div(32, tpi);                      // at least 32 positions per (point, k-pair / channel) run
+    while (gb > 1 && gb * per_image > budget) --gb;
+    if (gb > n) gb = n;
+    return gb < 1 ? 1 : gb;
+  };
+  s.GB = group(in_image, 80 * 1024);
+  s.nbg = (int)ceil_div(n, s.GB);
+  s.lds_in = s.GB * in_image;
+  s.GBo = group(out_image, 64 * 1024);
+  s.nbgo = (int)ceil_div(n, s.GBo);
+  s.lds_out = s.GBo * out_image;
   return s;
 }
 
@@ -468,7 +611,122 @@ extern "C" int eco_wino_s2_output_forward(const eco_wgemm_plan* plan, const floa
   a.m_pstride = (long)plan->ksplit * a.m_sstride;
   const long grid = (long)cout * a.nbg;
   ECO_REQUIRE(grid < 2147483647l, "stride-2 winograd output transform: too many workgroups");
-  if (s.lds_out > 64 * 1024) ECO_RAISE_DYNAMIC_LDS(wino_s2_output_kernel, "stride-2 winograd output transform");
-  hipLaunchKernelGGL((wino_s2_output_kernel), dim3((unsigned)grid), dim3(256), s.lds_out, (hipStream_t)stream, a);
+  if (s.lds_out > 64 * 1024) ECO_RAISE_DYNAMIC_LDS(wino_s2_output_kernel<true>, "stride-2 winograd output transform");
+  hipLaunchKernelGGL((wino_s2_output_kernel<true>), dim3((unsigned)grid), dim3(256), s.lds_out, (hipStream_t)stream, a);
   return check_launch("eco_wino_s2_output_forward");
+}
+
+// ---- the 2-D form: plan = eco_wgemm_plan_create(n, 4 * kz * cin, ctot, Do, Ho / 7, Wo / 7, kd = 1, points = 64) ------------
+static int s2d_check_plan(const eco_wgemm_plan* p, int32_t kz, int32_t od, int32_t oh, int32_t ow, const char* who) {
+  ECO_REQUIRE(p != nullptr, "%s: null plan", who);
+  ECO_REQUIRE(p->points == kS2P2 && p->kd == 1, "%s: needs a 2-D stride-2 polyphase plan (points = 64, kd = 1), got points=%d kd=%d", who,
+              p->points, p->kd);
+  ECO_REQUIRE(kz == 1 || kz == 3, "%s: kz must be 1 (no depth taps) or 3 (stride-2 depth taps), got %d", who, kz);
+  ECO_REQUIRE(od > 0 && oh > 0 && ow > 0 && oh % 7 == 0 && ow % 7 == 0, "%s: the output planes %dx%d must tile by 7x7", who, oh, ow);
+  ECO_REQUIRE(p->d == od && p->th == oh / 7 && p->tw == ow / 7, "%s: plan is for %d planes of %dx%d tiles, output volume %dx%dx%d needs %d of %dx%d",
+              who, p->d, p->th, p->tw, od, oh, ow, od, oh / 7, ow / 7);
+  ECO_REQUIRE(p->n > 0 && p->cin > 0 && p->cin % 16 == 0 && p->cin % (4 * kz) == 0 && p->cout > 0, "%s: bad plan", who);
+  return ECO_OK;
+}
+
+extern "C" int64_t eco_wino_s2d_lds_bytes(int32_t n, int32_t kz, int32_t od, int32_t th, int32_t tw) {
+  if (n <= 0 || (kz != 1 && kz != 3) || od <= 0 || th <= 0 || tw <= 0) return -1;
+  const S2dShape s = s2d_shape(n, kz, od, th, tw);
+  return (int64_t)(s.lds_in > s.lds_out ? s.lds_in : s.lds_out);
+}
+
+extern "C" int eco_wino_s2d_weight_transform(const float* w, int32_t cout, int32_t cin, int32_t kz, float* u) {
+  clear_error();
+  ECO_REQUIRE(w && u && cout > 0 && cin > 0 && (kz == 1 || kz == 3), "2-D stride-2 winograd weights: bad argument");
+  // u[p][co][k] = (G8 (x) G8) g_f,  k = ((ci*kz + tz)*2 + fy)*2 + fx,  g = w[co][ci][tz], per axis g_1 = (w0, w2), g_0 = (0, w1)
+  const long K = 4L * kz * cin, plane = (long)cout * K;
+  for (long co = 0; co < cout; ++co)
+    for (long ci = 0; ci < cin; ++ci)
+      for (int tz = 0; tz < kz; ++tz) {
+        const float* g = w + ((co * cin + ci) * kz + tz) * 9;
+        for (int f = 0; f < 4; ++f) {
+          const int fy = f >> 1, fx = f & 1;
+          double g2[2][2];
+          for (int ty = 0; ty < 2; ++ty)
+            for (int tx = 0; tx < 2; ++tx) {
+              const int ky = fy ? 2 * ty : (ty ? 1 : -1), kx = fx ? 2 * tx : (tx ? 1 : -1);
+              g2[ty][tx] = (ky < 0 || kx < 0) ? 0.0 : (double)g[ky * 3 + kx];
+            }
+          const long k = ((ci * kz + tz) * 2 + fy) * 2 + fx;
+          for (int ay = 0; ay < 8; ++ay)
+            for (int ax = 0; ax < 8; ++ax) {
+              double acc = 0.0;
+              for (int ty = 0; ty < 2; ++ty)
+                for (int tx = 0; tx < 2; ++tx) acc += kS2G8[ay][ty] * kS2G8[ax][tx] * g2[ty][tx];
+              u[(long)(ay * 8 + ax) * plane + co * K + k] = (float)acc;
+            }
+        }
+      }
+  return ECO_OK;
+}
+
+extern "C" int eco_wino_s2d_input_forward(const eco_wgemm_plan* plan, const float* x, float* v, int32_t kz, int32_t d, int32_t h,
+                                          int32_t w, void* stream) {
+  clear_error();
+  ECO_REQUIRE(d > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0 && (kz != 3 || d % 2 == 0),
+              "2-D stride-2 winograd input transform: the input volume %dx%dx%d must have even extents", d, h, w);
+  const int od = kz == 3 ? d / 2 : d;
+  if (int rc = s2d_check_plan(plan, kz, od, h / 2, w / 2, "2-D stride-2 winograd input transform")) return rc;
+  ECO_REQUIRE(x && v, "2-D stride-2 winograd input transform: null argument");
+  ECO_REQUIRE(((uintptr_t)v & 7) == 0, "2-D stride-2 winograd input transform: v must be 8-byte aligned");
+  const S2dShape s = s2d_shape(plan->n, kz, od, plan->th, plan->tw);
+  ECO_REQUIRE(s.lds_in <= (size_t)kEcoMaxDynamicLds, "2-D stride-2 winograd input transform: %dx%dx%d volumes need %zu bytes of LDS (max %d)",
+              d, h, w, s.lds_in, kEcoMaxDynamicLds);
+  S2dInArgs a;
+  a.x = x; a.v = v; a.n = plan->n; a.cin = plan->cin / (4 * kz); a.D = d; a.H = h; a.W = w; a.Do = od;
+  a.TH = plan->th; a.TW = plan->tw; a.KZ = kz;
+  a.GB = s.GB; a.nbg = s.nbg; a.PH = s.PH; a.PW = s.PW;
+  a.Q = (int)plan->q;
+  a.v_pstride = (long)(plan->cin / 2) * plan->q * 2;
+  const long grid = (long)a.cin * a.nbg;
+  ECO_REQUIRE(grid < 2147483647l, "2-D stride-2 winograd input transform: too many workgroups");
+  const bool vec4 = w % 4 == 0 && ((uintptr_t)x & 15) == 0;
+  hipStream_t st_ = (hipStream_t)stream;
+  const dim3 g((unsigned)grid), b(256);
+  if (vec4) {
+    if (s.lds_in > 64 * 1024) ECO_RAISE_DYNAMIC_LDS((wino_s2d_input_kernel<4>), "2-D stride-2 winograd input transform");
+    hipLaunchKernelGGL((wino_s2d_input_kernel<4>), g, b, s.lds_in, st_, a);
+  } else {
+    if (s.lds_in > 64 * 1024) ECO_RAISE_DYNAMIC_LDS((wino_s2d_input_kernel<1>), "2-D stride-2 winograd input transform");
+    hipLaunchKernelGGL((wino_s2d_input_kernel<1>), g, b, s.lds_in, st_, a);
+  }
+  return check_launch("eco_wino_s2d_input_forward");
+}
+
+extern "C" int eco_wino_s2d_output_forward(const eco_wgemm_plan* plan, const float* m, int32_t c0, int32_t cout, int32_t od,
+                                           int32_t oh, int32_t ow, const eco_conv_epilogue* ep, void* stream) {
+  clear_error();
+  ECO_REQUIRE(plan != nullptr, "2-D stride-2 winograd output transform: null plan");
+  // (kz does not matter on this side: points and tiles are what is checked)
+  if (int rc = s2d_check_plan(plan, 1, od, oh, ow, "2-D stride-2 winograd output transform")) return rc;
+  ECO_REQUIRE(m && ep, "2-D stride-2 winograd output transform: null argument");
+  ECO_REQUIRE(c0 >= 0 && cout > 0 && c0 + cout <= plan->cout, "2-D stride-2 winograd output transform: channels [%d, %d) of the plan's %d",
+              c0, c0 + cout, plan->cout);
+  ECO_REQUIRE(ep->raw.ptr || ep->act.ptr, "2-D stride-2 winograd output transform: at least one of raw/act outputs is required");
+  ECO_REQUIRE(!ep->bn_scale == !ep->bn_shift, "2-D stride-2 winograd output transform: bn_scale and bn_shift must be given together");
+  ECO_REQUIRE(!ep->act2.ptr || ep->act.ptr, "2-D stride-2 winograd output transform: act2 needs act");
+  ECO_REQUIRE(ep->nseg == 0, "2-D stride-2 winograd output transform: one launch per member (c0, cout) instead of a segmented epilogue");
+  const eco_view* views[4] = {&ep->residual, &ep->raw, &ep->act, &ep->act2};
+  for (const eco_view* v : views)
+    ECO_REQUIRE(!v->ptr || (v->t >= 1 && v->stride_c >= 1), "2-D stride-2 winograd output transform: view needs t >= 1 and stride_c >= 1");
+  const S2dShape s = s2d_shape(plan->n, 1, od, plan->th, plan->tw);
+  ECO_REQUIRE(s.lds_out <= (size_t)kEcoMaxDynamicLds, "2-D stride-2 winograd output transform: %dx%dx%d volumes need %zu bytes of LDS (max %d)",
+              od, oh, ow, s.lds_out, kEcoMaxDynamicLds);
+  S2OutArgs a;
+  a.m = m; a.bias = ep->bias; a.bn_scale = ep->bn_scale; a.bn_shift = ep->bn_shift;
+  a.residual = ep->residual; a.raw = ep->raw; a.act = ep->act; a.act2 = ep->act2; a.relu = ep->relu;
+  a.n = plan->n; a.c0 = c0; a.cout = cout; a.Do = od; a.Ho = oh; a.Wo = ow; a.TD = od; a.TH = plan->th; a.TW = plan->tw;
+  a.GB = s.GBo; a.nbg = s.nbgo; a.Q = (int)plan->q; a.ksplit = plan->ksplit;
+  a.m_sstride = (long)plan->cout * plan->q;
+  a.m_pstride = (long)plan->ksplit * a.m_sstride;
+  const long grid = (long)cout * a.nbg;
+  ECO_REQUIRE(grid < 2147483647l, "2-D stride-2 winograd output transform: too many workgroups");
+  if (s.lds_out > 64 * 1024) ECO_RAISE_DYNAMIC_LDS(wino_s2_output_kernel<false>, "2-D stride-2 winograd output transform");
+  hipLaunchKernelGGL((wino_s2_output_kernel<false>), dim3((unsigned)grid), dim3(256), s.lds_out, (hipStream_t)stream, a);
+  return check_launch("eco_wino_s2d_output_forward");
 }

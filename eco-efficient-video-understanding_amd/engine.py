@@ -707,23 +707,57 @@ class Engine:
                    "bytes": 4 * P * tout + nbytes - 4 * (n * cin * D * H * W + 9 * kd * cin * cout)})
 
     # -- stride-2 3x3x3 convolutions on the polyphase Winograd route (csrc/eco_wino_s2.hip) ----------------------------
-    def _ws2_eligible(self, L: LayerSpec) -> bool:
-        """3x3x3, stride 2, pad 1 on an input exactly twice the output volume, the output volume tiling by 4 x 7 x 7
-        (res4a_1 / res4a_down at num_segments 16 / 32: 8 x 14 x 14, models_ECO_Lite/kinetics/deploy.prototxt:1262-1330)."""
+    def _ws2_form(self, L: LayerSpec):
+        """Which polyphase form runs a stride-2 3x3(x3) convolution, or None (the direct strided kernel):
+          ("3d", TD, TH, TW)      3x3x3, stride 2, pad 1 on an input exactly twice the output volume, the output volume tiling by
+                                  4 x 7 x 7 with enough tiles: F(4,2) x F(7,2) x F(7,2), 320 points, K = 8 cin (res4a_1 / res4a_down
+                                  at num_segments 16 / 32: 8 x 14 x 14 outputs, models_ECO_Lite/kinetics/deploy.prototxt:1262-1330)
+          ("2d", kz, Do, TH, TW)  output planes tiling by 7 x 7: F(7,2) x F(7,2), 64 points, every output plane a position, the depth
+                                  taps in the reduction (K = 4 kz cin): res5a_1 / res5a_down (4 x 7 x 7 outputs: kz = 3) and the
+                                  strided 2-D 3x3 convs of ECO-Full's inception_3c / 4e (kz = 1), where the estimate below says
+                                  the transforms pay."""
         g = L.geom
-        if self.dt or not self.winograd or not self.wino_s2 or not self.wgemm or L.type != "Convolution":
-            return False
-        if len(L.bottom_shapes[0]) != 5 or tuple(g["kernel"]) != (3, 3, 3) or tuple(g["stride"]) != (2, 2, 2) or \
-                tuple(g["pad"]) != (1, 1, 1) or g.get("group", 1) != 1:
-            return False
-        n, cin, D, H, W = L.bottom_shapes[0]
-        Do, Ho, Wo = L.top_shapes[0][2:]
-        if (D, H, W) != (2 * Do, 2 * Ho, 2 * Wo) or Do % 4 or Ho % 7 or Wo % 7 or cin % 2 or cin < 16:
-            return False
-        TD, TH, TW = Do // 4, Ho // 7, Wo // 7
-        if self.winograd is True and n * TD * TH * TW < self.wino_s2_min_positions:   # an explicit winograd=4 overrides
-            return False
-        return self.lib.wino_s2_lds_bytes(n, TD, TH, TW) <= 152 * 1024
+        if self.dt or not self.winograd or not self.wino_s2 or not self.wgemm or L.type != "Convolution" or g.get("group", 1) != 1:
+            return None
+        nd = len(L.bottom_shapes[0]) - 2
+        if nd not in (2, 3) or tuple(g["kernel"])[-2:] != (3, 3) or tuple(g["stride"])[-2:] != (2, 2) or tuple(g["pad"])[-2:] != (1, 1):
+            return None
+        n, cin = L.bottom_shapes[0][:2]
+        H, W = L.bottom_shapes[0][-2:]
+        Ho, Wo = L.top_shapes[0][-2:]
+        if (H, W) != (2 * Ho, 2 * Wo) or Ho % 7 or Wo % 7 or cin % 4 or cin < 16:
+            return None
+        TH, TW = Ho // 7, Wo // 7
+        forced = self.winograd is not True                      # an explicit winograd=4 overrides the size rules
+        if nd == 3 and (g["kernel"][0], g["stride"][0], g["pad"][0]) == (3, 2, 1):
+            D, Do = L.bottom_shapes[0][2], L.top_shapes[0][2]
+            if D != 2 * Do:
+                return None
+            if Do % 4 == 0 and (forced or n * (Do // 4) * TH * TW >= self.wino_s2_min_positions) and \
+                    self.lib.wino_s2_lds_bytes(n, Do // 4, TH, TW) <= 152 * 1024:
+                return ("3d", Do // 4, TH, TW)
+            kz = 3
+        elif nd == 2 or (g["kernel"][0], g["stride"][0], g["pad"][0]) == (1, 1, 0):
+            Do, kz = (1 if nd == 2 else L.top_shapes[0][2]), 1
+        else:
+            return None
+        if not forced:
+            if n * Do * TH * TW < self.wino_s2_min_positions:
+                return None
+            # do the transforms pay?  direct: 27 / 9 multiplies per output and input channel on the gather kernel (0.55 of the
+            # MFMA peak measured on these layers); here 64 * 4 kz / 49 of them on the dense GEMM (0.65) + V, M and the blobs
+            # through the transform kernels (4.5 TB/s measured).  Small output-channel counts lose: inception_3c_double_3x3_2
+            cout = g["cout"]
+            outs = n * Do * Ho * Wo
+            t_direct = 2.0 * outs * cout * cin * 9 * kz / (0.55 * 157.3e12)
+            pos = n * Do * TH * TW
+            t_ws = 2.0 * 64 * pos * cout * 4 * kz * cin / (0.65 * 157.3e12) + \
+                4.0 * (_prod(L.bottom_shapes[0]) + 64 * pos * (4 * kz * cin + cout) + outs * cout) / 4.5e12
+            if t_direct < 1.15 * t_ws:
+                return None
+        if self.lib.wino_s2d_lds_bytes(n, kz, Do, TH, TW) > 152 * 1024:
+            return None
+        return ("2d", kz, Do, TH, TW)
 
     def _plan_ws2_groups(self) -> None:
         """Group the eligible convs by (bottom blob, geometry) -- in the fused plan a residual block's first conv and its
@@ -735,8 +769,9 @@ class Engine:
             self._param_dev.get(L.name, {}).pop("ws2", None)
         found: Dict[tuple, List[int]] = {}
         for i, L in enumerate(layers):
-            if L.type == "Convolution" and "wino" not in self._param_dev[L.name] and self._ws2_eligible(L):
-                k = (self._resolve(L.bottoms[0]), tuple(L.bottom_shapes[0]), tuple(L.top_shapes[0][2:]))
+            form = self._ws2_form(L) if L.type == "Convolution" and "wino" not in self._param_dev[L.name] else None
+            if form is not None:
+                k = (self._resolve(L.bottoms[0]), tuple(L.bottom_shapes[0]), tuple(L.top_shapes[0][2:]), form)
                 k = k if self.fuse else k + (i,)
                 # a layer that rewrites the shared bottom in place between two members splits the group
                 if k in found and any(layers[j].inplace and self._resolve(layers[j].bottoms[0]) == k[0]
@@ -746,11 +781,14 @@ class Engine:
         for k, idxs in found.items():
             Ls = [layers[j] for j in idxs]
             key = "|".join(Lc.name for Lc in Ls)
-            n, cin, D, H, W = Ls[0].bottom_shapes[0]
-            Do, Ho, Wo = Ls[0].top_shapes[0][2:]
+            n, cin = Ls[0].bottom_shapes[0][:2]
             couts = [Lc.geom["cout"] for Lc in Ls]
-            plan = self.lib.wgemm_plan(n, 8 * cin, sum(couts), Do // 4, Ho // 7, Wo // 7, 1, self.num_cu, points=320)
-            grp = dict(plan=plan, convs=[Lc.name for Lc in Ls], idxs=idxs, couts=couts, cin=cin)
+            form = k[3]
+            if form[0] == "3d":
+                plan = self.lib.wgemm_plan(n, 8 * cin, sum(couts), form[1], form[2], form[3], 1, self.num_cu, points=320)
+            else:
+                plan = self.lib.wgemm_plan(n, 4 * form[1] * cin, sum(couts), form[2], form[3], form[4], 1, self.num_cu, points=64)
+            grp = dict(plan=plan, convs=[Lc.name for Lc in Ls], idxs=idxs, couts=couts, cin=cin, form=form)
             o = old.get(key)
             grp["up"] = o["up"] if o is not None and o["plan"].u_elems == plan.u_elems else self.alloc.empty(plan.u_elems, np.float32)
             self._ws2_groups[key] = grp
@@ -768,8 +806,13 @@ class Engine:
             ctot = sum(grp["couts"])
             w = np.ascontiguousarray(np.concatenate(
                 [np.asarray(self.params[n][0], np.float32).reshape(c, -1) for n, c in zip(grp["convs"], grp["couts"])], 0))
-            u = np.empty(320 * ctot * 8 * cin, np.float32)
-            self.lib.wino_s2_weight_transform(w.ctypes.data, ctot, cin, u.ctypes.data)
+            if grp["form"][0] == "3d":
+                u = np.empty(320 * ctot * 8 * cin, np.float32)
+                self.lib.wino_s2_weight_transform(w.ctypes.data, ctot, cin, u.ctypes.data)
+            else:
+                kz = grp["form"][1]
+                u = np.empty(64 * ctot * 4 * kz * cin, np.float32)
+                self.lib.wino_s2d_weight_transform(w.ctypes.data, ctot, cin, kz, u.ctypes.data)
             up = np.empty(plan.u_elems, np.float32)
             self.lib.wgemm_pack_weights(plan, u.ctypes.data, up.ctypes.data)
             del u
@@ -812,32 +855,45 @@ class Engine:
         plan, up = grp["plan"], self.alloc.ptr(grp["up"])
         lib = self.lib
         L0 = members[0][0]
-        n, cin, D, H, W = L0.bottom_shapes[0]
-        Do, Ho, Wo = L0.top_shapes[0][2:]
+        form = grp["form"]
+        n, cin = L0.bottom_shapes[0][:2]
+        D = L0.bottom_shapes[0][2] if len(L0.bottom_shapes[0]) == 5 else 1
+        H, W = L0.bottom_shapes[0][-2:]
+        Do = L0.top_shapes[0][2] if len(L0.top_shapes[0]) == 5 else 1
+        Ho, Wo = L0.top_shapes[0][-2:]
         ctot = sum(grp["couts"])
         x = self._ptr(L0.bottoms[0])
         v = self.alloc.ptr(self._wino_buf_v_elems)
         m = self.alloc.ptr(self._wino_buf_m_elems)
         pos = n * plan.d * plan.th * plan.tw                       # positions per transform point
         S = Do * Ho * Wo
-        v_bytes, m_bytes = 4 * 320 * 8 * cin * pos, 4 * 320 * plan.ksplit * ctot * pos
+        P, K = plan.points, plan.cin
+        v_bytes, m_bytes = 4 * P * K * pos, 4 * P * plan.ksplit * ctot * pos
         x_bytes = 4 * n * cin * D * H * W
-        tag = "stride-2 winograd F(4,2)xF(7,2)xF(7,2)"
         names = " | ".join(lb for _, _, lb in members)
         self._keep.append(plan)
-        self._add(i, f"{names} [{tag} input transform]", lambda s: lib.wino_s2_input_forward(plan, x, v, D, H, W, s),
-                  {"kernel": "eco::wino_s2_input_kernel", "flops": 0, "bytes": x_bytes + v_bytes})
-        self._add(i, f"{names} [320 transformed-domain GEMMs, K = {8 * cin}]", lambda s: lib.wgemm_forward(plan, v, up, m, s),
-                  {"kernel": hip.wgemm_kernel_name(plan), "flops": 2 * 320 * pos * ctot * 8 * cin,
-                   "bytes": v_bytes + 4 * 320 * ctot * 8 * cin + m_bytes, "siblings": len(members)})
+        if form[0] == "3d":
+            tag = "stride-2 winograd F(4,2)xF(7,2)xF(7,2)"
+            k_in, k_out = "eco::wino_s2_input_kernel", "eco::wino_s2_output_kernel<true>"
+            fin = lambda s: lib.wino_s2_input_forward(plan, x, v, D, H, W, s)
+            fout = lib.wino_s2_output_forward
+        else:
+            kz = form[1]
+            tag = "stride-2 winograd F(7,2)xF(7,2)" + (", depth taps direct" if kz == 3 else "")
+            k_in, k_out = "eco::wino_s2d_input_kernel", "eco::wino_s2_output_kernel<false>"
+            fin = lambda s: lib.wino_s2d_input_forward(plan, x, v, kz, D, H, W, s)
+            fout = lib.wino_s2d_output_forward
+        self._add(i, f"{names} [{tag} input transform]", fin, {"kernel": k_in, "flops": 0, "bytes": x_bytes + v_bytes})
+        self._add(i, f"{names} [{P} transformed-domain GEMMs, K = {K}]", lambda s: lib.wgemm_forward(plan, v, up, m, s),
+                  {"kernel": hip.wgemm_kernel_name(plan), "flops": 2 * P * pos * ctot * K,
+                   "bytes": v_bytes + 4 * P * ctot * K + m_bytes, "siblings": len(members)})
         for (Lj, ep, label), c0 in zip(members, np.cumsum([0] + grp["couts"][:-1])):
             cout = Lj.geom["cout"]
             self._keep.append(ep)
             touched = bool(ep.raw.ptr) + bool(ep.act.ptr) + bool(ep.residual.ptr) + bool(ep.act2.ptr)
             self._add(i, f"{label} [{tag} output transform]",
-                      lambda s, c0=int(c0), cout=cout, ep=ep: lib.wino_s2_output_forward(plan, m, c0, cout, Do, Ho, Wo, ep, s),
-                      {"kernel": "eco::wino_s2_output_kernel", "flops": 0,
-                       "bytes": m_bytes * cout // ctot + 4 * n * cout * S * touched})
+                      lambda s, c0=int(c0), cout=cout, ep=ep: fout(plan, m, c0, cout, Do, Ho, Wo, ep, s),
+                      {"kernel": k_out, "flops": 0, "bytes": m_bytes * cout // ctot + 4 * n * cout * S * touched})
 
     # -- the stem: conv1_7x7_s2 + BN + ReLU + pool1_3x3_s2 as one launch (csrc/eco_stem.hip) --
     def _stem_geometry(self, L: LayerSpec) -> bool:
@@ -899,8 +955,8 @@ class Engine:
         st = self._param_dev[L.name]
         wn = st.get("wino")
         if not self.wpool or act_blob is None or act_blob in outputs or ep.raw.ptr or ep.residual.ptr or self.dt or \
-                wn is None or wn.get("kind") != "wgemm" or not wn.get("fused"):
-            return False
+                wn is None or wn.get("kind") != "wgemm" or not wn.get("fused") or wn.get("m_elems", 0) <= 0:
+            return False   # (m_elems: the partial-maxima scratch _plan_wino sized for this form; 0 = planned without it)
         cs = [c for c in consumers.get(act_blob, []) if absorbed.get(c) != L.name]
         if len(cs) != 1 or layers[cs[0]].type != "Pooling":
             return False
@@ -1066,7 +1122,8 @@ class Engine:
         x, y = self._ptr(L.bottoms[0]), self._ptr(Lc.tops[0], c0 * S)
         lib = self.lib
         self._add(i, f"{L.name} [into {Lc.tops[0]}]", lambda s: lib.pool_forward_strided(pg, x, y, ctot * S, s),
-                  {"kernel": hip.pool_kernel_name(pg), "flops": 0, "bytes": 4 * (_prod(b) + _prod(L.top_shapes[0]))})
+                  {"kernel": hip.pool_kernel_name(pg, ctot * S, c0 * S), "flops": 0,
+                   "bytes": 4 * (_prod(b) + _prod(L.top_shapes[0]))})
         return True
 
     def _emit_concat(self, i: int, L: LayerSpec, skip: Sequence[int]) -> None:

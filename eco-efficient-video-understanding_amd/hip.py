@@ -137,19 +137,25 @@ def convb_kernel_name(plan: "ConvBPlan") -> str:
     return f"eco::convb_kernel<{tm}, {tn}, {wm}, {wn}, 3>"
 
 
-def pool_kernel_name(g: "PoolGeom") -> str:
-    """Device kernel eco_pool_forward picks for this geometry (mirrors the dispatch in csrc/eco_ops.hip;
-    the float4 fast paths additionally need 16-byte aligned pointers, which torch allocations are)."""
+def pool_kernel_name(g: "PoolGeom", y_image_stride: int = 0, y_offset_elems: int = 0) -> str:
+    """Device kernel eco_pool_forward / eco_pool_forward_strided picks for this geometry (mirrors the dispatch in
+    csrc/eco_ops.hip; the float4 fast paths additionally need 16-byte aligned pointers, which torch allocations are).
+    `y_image_stride` / `y_offset_elems`: the pooled blob written as a channel slice of a wider tensor (images that many
+    floats apart, the slice starting that many floats into the allocation): the global-average and AVE 3x3/1/1 fast paths
+    take dense outputs only, the MAX 3x3/2 one needs a slice whose gap and start are multiples of four floats."""
     two_d = g.in_[0] == 1 and g.kernel[0] == 1 and g.stride[0] == 1 and g.pad[0] == 0
     k, s, p = tuple(g.kernel[1:]), tuple(g.stride[1:]), tuple(g.pad[1:])
-    if all(g.kernel[i] == g.in_[i] and g.pad[i] == 0 and g.out[i] == 1 for i in range(3)) and g.method == POOL_AVE \
-            and g.in_[0] * g.in_[1] * g.in_[2] >= 32:
+    s_out = g.out[0] * g.out[1] * g.out[2]
+    y_extra = y_image_stride - g.c * s_out if y_image_stride else 0
+    aligned = y_extra % 4 == 0 and y_offset_elems % 4 == 0
+    if y_extra == 0 and all(g.kernel[i] == g.in_[i] and g.pad[i] == 0 and g.out[i] == 1 for i in range(3)) and \
+            g.method == POOL_AVE and g.in_[0] * g.in_[1] * g.in_[2] >= 32:
         return "eco::global_avg_kernel"
-    if two_d and g.method == POOL_MAX and k == (3, 3) and s == (2, 2) and p == (0, 0) and g.in_[2] % 4 == 0 \
+    if two_d and aligned and g.method == POOL_MAX and k == (3, 3) and s == (2, 2) and p == (0, 0) and g.in_[2] % 4 == 0 \
             and g.out[2] % 2 == 0 and 2 * (g.out[2] - 1) + 2 <= g.in_[2]:
         return "eco::maxpool2d_k3s2_kernel<%d>" % (4 if g.out[2] % 4 == 0 else 2)
-    if two_d and g.method == POOL_AVE and k == (3, 3) and s == (1, 1) and p == (1, 1) and g.in_[2] % 2 == 0 \
-            and g.in_[1] >= 2 and g.in_[2] >= 4:
+    if y_extra == 0 and two_d and aligned and g.method == POOL_AVE and k == (3, 3) and s == (1, 1) and p == (1, 1) and \
+            g.in_[2] % 2 == 0 and g.in_[1] >= 2 and g.in_[2] >= 4:
         return "eco::avgpool2d_k3s1p1_kernel<%d>" % (4 if g.in_[2] % 4 == 0 else 2)
     if two_d and k == (3, 3):
         return "eco::pool2d_k3_kernel"
@@ -233,6 +239,8 @@ _SIGNATURES = {
     "eco_wino_output_dm_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_int32, C.c_int32,
                                              C.POINTER(ConvEpilogue), C.c_void_p]),
     "eco_counters_reset": (C.c_int, [C.c_void_p]),
+    "eco_counters_release_capture_slots": (C.c_int, []),
+    "eco_counter_slot_probe": (C.c_int, [C.c_void_p]),
     "eco_wino3_weight_transform": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "eco_wino3_lds_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "eco_wino3_input_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
@@ -245,6 +253,12 @@ _SIGNATURES = {
                                             C.c_void_p]),
     "eco_wino_s2_output_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                              C.c_int32, C.POINTER(ConvEpilogue), C.c_void_p]),
+    "eco_wino_s2d_weight_transform": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "eco_wino_s2d_lds_bytes": (C.c_int64, [C.c_int32] * 5),
+    "eco_wino_s2d_input_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                             C.c_int32, C.c_void_p]),
+    "eco_wino_s2d_output_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                              C.c_int32, C.POINTER(ConvEpilogue), C.c_void_p]),
     "eco_wfused_pool_scratch_elems": (C.c_int64, [C.POINTER(WGemmPlan)]),
     "eco_wfused_pool_forward": (C.c_int, [C.POINTER(WGemmPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                           C.POINTER(ConvEpilogue), C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -409,6 +423,14 @@ class EcoLib:
         """Zero the work counters of the dynamic-share launches (after a faulted kernel; include/eco_hip.h)."""
         self._check(self._dll.eco_counters_reset(stream))
 
+    def counters_release_capture_slots(self) -> None:
+        """Return the 192 capture slots to the pool: only when every graph captured so far has been destroyed."""
+        self._check(self._dll.eco_counters_release_capture_slots())
+
+    def counter_slot_probe(self, stream=None) -> int:
+        """Slot (0..255) a dynamic-share launch on `stream` would take now, -1 = static shares (include/eco_hip.h)."""
+        return int(self._dll.eco_counter_slot_probe(stream))
+
     # -- Winograd F(4x4x4,3x3x3): the 3-D trunk's transforms around the same GEMM (csrc/eco_wino3.hip) --
     def wino3_weight_transform(self, w_host: int, cout: int, cin: int, u_host: int) -> None:
         self._check(self._dll.eco_wino3_weight_transform(w_host, cout, cin, u_host))
@@ -438,6 +460,22 @@ class EcoLib:
                                stream=None) -> None:
         """Channels [c0, c0 + cout) of the GEMM's rows -> the (od, oh, ow) OUTPUT volume with the member's epilogue."""
         self._check(self._dll.eco_wino_s2_output_forward(C.byref(p), m, c0, cout, od, oh, ow, C.byref(ep), stream))
+
+    # ... and the 2-D form: F(7,2) x F(7,2) on 64 points, depth taps (kz = 3) or none (kz = 1) in the reduction
+    def wino_s2d_weight_transform(self, w_host: int, cout: int, cin: int, kz: int, u_host: int) -> None:
+        """u[64][cout][4 kz cin] from w[cout][cin][kz][3][3] (host)."""
+        self._check(self._dll.eco_wino_s2d_weight_transform(w_host, cout, cin, kz, u_host))
+
+    def wino_s2d_lds_bytes(self, n: int, kz: int, od: int, th: int, tw: int) -> int:
+        return int(self._dll.eco_wino_s2d_lds_bytes(n, kz, od, th, tw))
+
+    def wino_s2d_input_forward(self, p: "WGemmPlan", x: int, v: int, kz: int, d: int, h: int, w: int, stream=None) -> None:
+        """(d, h, w): the INPUT volume; the plan is wgemm_plan(n, 4 * kz * cin, ctot, od, h/14, w/14, 1, points=64)."""
+        self._check(self._dll.eco_wino_s2d_input_forward(C.byref(p), x, v, kz, d, h, w, stream))
+
+    def wino_s2d_output_forward(self, p: "WGemmPlan", m: int, c0: int, cout: int, od: int, oh: int, ow: int, ep: ConvEpilogue,
+                                stream=None) -> None:
+        self._check(self._dll.eco_wino_s2d_output_forward(C.byref(p), m, c0, cout, od, oh, ow, C.byref(ep), stream))
 
     def wgemm_pack_weights(self, p: "WGemmPlan", u_host: int, up_host: int) -> None:
         self._check(self._dll.eco_wgemm_pack_weights(C.byref(p), u_host, up_host))

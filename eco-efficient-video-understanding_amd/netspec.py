@@ -640,6 +640,39 @@ class NetSpec:
     def consumers(self, blob: str, after: int = -1) -> List[int]:
         return [i for i, L in enumerate(self.layers) if i > after and blob in L.bottoms]
 
+    def fused_model_bytes(self, elem: int = 4) -> int:
+        """Algorithmic bytes of one forward in the FUSED model of SURVEY.md section 8(d): each Convolution / InnerProduct
+        reads its input and weights and writes its output once (bias / BN / ReLU / Dropout folded; Concat / Reshape / Split /
+        Permute free), each Pooling reads its bottom and writes its top, each Eltwise costs one extra operand read, and a
+        conv / Eltwise value that is needed raw AND through its BN + ReLU is written twice (res3a / res4a / res5a)."""
+        consumers: Dict[str, List[LayerSpec]] = {}
+        alias: Dict[str, str] = {}
+        for L in self.layers:
+            if L.type == "Split":
+                for t in L.tops:
+                    alias[t] = alias.get(L.bottoms[0], L.bottoms[0])
+        for L in self.layers:
+            if L.type != "Split":
+                for b in L.bottoms:
+                    consumers.setdefault(alias.get(b, b), []).append(L)
+        tot = 0
+        for L in self.layers:
+            if L.type == "Convolution":
+                g = L.geom
+                tot += elem * (_prod(L.bottom_shapes[0]) + g["cout"] * g["cin"] * _prod(g["kernel"]) + _prod(L.top_shapes[0]))
+            elif L.type == "InnerProduct":
+                g = L.geom
+                tot += elem * (g["M"] * g["K"] + g["num_output"] * g["K"] + g["M"] * g["num_output"])
+            elif L.type == "Pooling":
+                tot += elem * (_prod(L.bottom_shapes[0]) + _prod(L.top_shapes[0]))
+            elif L.type == "Eltwise":
+                tot += elem * _prod(L.top_shapes[0]) * (len(L.bottoms) - 1)
+            if L.type in ("Convolution", "Eltwise"):
+                cs = [c for c in consumers.get(alias.get(L.tops[0], L.tops[0]), []) if not (c.inplace and c.type == "Dropout")]
+                if any(c.type == "BN" for c in cs) and len(cs) > 1:
+                    tot += elem * _prod(L.top_shapes[0])
+        return tot
+
     def conv_fc_flops(self) -> int:
         """2*MAC over Convolution + InnerProduct layers."""
         tot = 0

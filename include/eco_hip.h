@@ -90,15 +90,24 @@ const char* eco_source_digest(void);
  *
  * WORK COUNTERS.  The persistent bf16 kernels (convb_spanp_kernel, stemb_kernel) draw work items from a counter in
  * device memory that the launch's last workgroup resets to zero.  The counters live in two module-scope arrays of 256
- * slots per device.  Slot choice: an eager launch uses the one slot of ITS STREAM (launches of one stream execute in
- * order), for up to 64 distinct streams per process -- a launch on a 65th stream silently takes static shares instead; a
- * launch recorded during stream capture takes the next of 192 capture slots, and the captured graph keeps them.
- * What this guarantees: any number of host threads / streams (<= 64) may launch eagerly at the same time, and captured
- * graphs may replay next to eager launches on other streams.  What it does not: two graphs that together captured more
- * than 192 dynamic-share launches may hold the same slot -- replay such graphs one at a time (or from one stream); and a
- * kernel that faults mid-flight leaves its slot non-zero -- call eco_counters_reset(stream) after recovering the device.
- * (Round-4 advisor finding; until v17 a sequence number modulo 256 chose the slot.)  (v18) */
+ * slots per device.  Slot choice (eco_counter_slot_probe reports it):
+ *   - an eager launch uses the one slot of ITS STREAM (launches of one stream execute in order), for up to 64 distinct
+ *     streams per process; the null stream and hipStreamLegacy are one stream; hipStreamPerThread -- one handle value for a
+ *     different stream in every host thread -- always takes static shares.  When the table is full, the entry of a stream
+ *     without work in flight (destroyed or idle) is recycled; if every one of the 64 is busy the launch takes static shares;
+ *   - a launch recorded during stream capture takes the next of 192 capture slots and the captured graph keeps it.  The
+ *     slots are handed out ONCE (v19; v18 wrapped around, so two live graphs -- re-captures after a reshape, graphs of
+ *     several Net objects -- could end up on one slot and race when replayed on different streams): once the 192 are
+ *     gone, captured launches take static shares.  eco_counters_release_capture_slots() returns them all to the pool; call
+ *     it only when every graph captured so far has been destroyed.
+ * What this guarantees: any number of host threads / streams may launch eagerly at the same time, and captured graphs may
+ * replay next to each other and next to eager launches; no combination shares a counter between launches that can run
+ * concurrently.  Static shares (slot -1) are always correct, only less balanced.  What it does not: a kernel that faults
+ * mid-flight leaves its slot non-zero -- call eco_counters_reset(stream) after recovering the device.
+ * (Round-4 / round-5 advisor findings; until v17 a sequence number modulo 256 chose the slot.) */
 int eco_counters_reset(void* stream);
+int eco_counters_release_capture_slots(void);   /* (v19) */
+int eco_counter_slot_probe(void* stream);       /* (v19) slot (0..255) a dynamic-share launch on `stream` would take now, -1 = static */
 
 /* ---- convolution (+ fused bias / residual / BN / ReLU epilogue) -------------------- */
 
@@ -377,7 +386,7 @@ int eco_stemb_forward(const float* x, const void* wp, const float* bias, const f
 typedef struct eco_wgemm_plan {
   int32_t n, cin, cout, d, th, tw; /* clips/images, channels, depth, tiles per plane (ceil(H/4), ceil(W/4))   */
   int32_t kd;                      /* 1 (2-D 3x3) or 3 (3x3x3, depth taps direct)                             */
-  int32_t points;                  /* 36; 216 = F(4x4x4,3x3x3), 320 = the stride-2 form below (kd = 1, d = depth TILES) */
+  int32_t points;                  /* 36; 216 = F(4x4x4,3x3x3), 320 / 64 = the stride-2 forms below (kd = 1)        */
   int32_t bm, bn;                  /* block tile: output channels x positions                                 */
   int32_t nstages;                 /* (cin/16) * kd stages of 16 reduction elements                           */
   int32_t ksplit;                  /* split-K slices (rows of m)                                              */
@@ -427,7 +436,8 @@ int eco_wfused_pool_forward(const eco_wgemm_plan* plan, const float* v, const fl
  *   up = eco_wgemm_pack_weights(u), u = eco_wino3_weight_transform(w)       u[216][cout][cin] = (G x G x G) w
  *   eco_wino3_input_forward(x -> v); eco_wgemm_forward(v, up -> m); eco_wino3_output_forward(m -> y, epilogue)
  * The two transforms keep a group of images' planes in LDS: eco_wino3_lds_bytes(n, th, tw) must not exceed 152 KB
- * (planes up to ~56x56); they fail with ECO_ERR_INVALID otherwise.  Results equal eco_conv_forward's up to fp32
+ * (planes up to 52x52: 48 (4 th + 2)(4 tw + 8) bytes for one image; 56x56 needs 174 KB) -- ask eco_wino3_lds_bytes, the
+ * entry points fail with ECO_ERR_INVALID otherwise.  Results equal eco_conv_forward's up to fp32
  * rounding (cudnn_conv_layer.cu:15-65 leaves the algorithm to cuDNN). */
 int eco_wino3_weight_transform(const float* w, int32_t cout, int32_t cin, float* u); /* HOST */
 int64_t eco_wino3_lds_bytes(int32_t n, int32_t th, int32_t tw);
@@ -462,6 +472,21 @@ int eco_wino_s2_input_forward(const eco_wgemm_plan* plan, const float* x, float*
 /* (od, oh, ow): the OUTPUT volume; ep->nseg must be 0 */
 int eco_wino_s2_output_forward(const eco_wgemm_plan* plan, const float* m, int32_t c0, int32_t cout, int32_t od, int32_t oh,
                                int32_t ow, const eco_conv_epilogue* ep, void* stream);
+/* The 2-D form of the same idea, for output volumes with too few 4 x 7 x 7 tiles (res5a_1 / res5a_down: 4 x 7 x 7 outputs) and
+ * for the strided 2-D 3x3 convolutions of ECO-Full (inception_3c / 4e, models_ECO_Full/kinetics/deploy.prototxt:1854-1990,
+ * 3420-3560): F(7,2) x F(7,2) over rows and columns on 8 x 8 = 64 points, the depth taps direct and part of the reduction.
+ * kz = 3: a 3x3x3 kernel, stride 2 / pad 1 on all three axes (input depth = 2 od); kz = 1: a (1x)3x3 kernel, stride (1,)2,2,
+ * pad (0,)1,1 (input depth = od; od = 1 for 2-D blobs).  Every output plane is a position of its own:
+ *   plan = eco_wgemm_plan_create(n, 4 * kz * cin, ctot, od, oh/7, ow/7, kd = 1, points = 64, ...)
+ *   v[p][k/2][r][2], m[p][slice][ctot][r]    p = ay*8 + ax, k = ((c*kz + tz)*2 + fy)*2 + fx, r = ((b*od + z)*th + ty)*tw + tx
+ *   u = eco_wino_s2d_weight_transform(w[cout][cin][kz][3][3], ...)             u[64][ctot][4 kz cin]
+ * and the same three steps.  eco_wino_s2d_lds_bytes(n, kz, od, th, tw) <= 152 KB. */
+int eco_wino_s2d_weight_transform(const float* w, int32_t cout, int32_t cin, int32_t kz, float* u); /* HOST */
+int64_t eco_wino_s2d_lds_bytes(int32_t n, int32_t kz, int32_t od, int32_t th, int32_t tw);
+int eco_wino_s2d_input_forward(const eco_wgemm_plan* plan, const float* x, float* v, int32_t kz, int32_t d, int32_t h,
+                               int32_t w, void* stream);
+int eco_wino_s2d_output_forward(const eco_wgemm_plan* plan, const float* m, int32_t c0, int32_t cout, int32_t od, int32_t oh,
+                                int32_t ow, const eco_conv_epilogue* ep, void* stream);
 
 /* ---- channel-blocked ("NC8") path on the bf16 matrix cores (csrc/eco_blocked.hip) -------------------------
  *

@@ -61,3 +61,36 @@ def test_traffic_is_reported_only_for_the_profiled_sources_and_workload():
     assert gb is None and "other sources" in unit
     gb, unit = bench.traffic_from_summary(tr, "lite/32/32/bf16", "eco::wgemm_kernel", "a" * 64)    # family not in that pass
     assert gb is None and "no PMC row" in unit
+
+
+def test_step_traffic_sums_every_kernel_of_the_profiled_steps():
+    """roofline.step_traffic_gb (round-5 verdict item 3): sum over the eco:: kernels of PMC bytes per launch x launches, per step."""
+    tr = {"source": "profiles/rXX_pmc_hbm_traffic.csv", "src_sha256": "a" * 64, "workload": "lite/16/32/f32", "pmc_steps": 6,
+          "kernels": {"eco::wgemm_kernel<2, 2, 2, 2>": {"hbm_bytes_per_launch": 1.0e9, "launches": 54},
+                      "eco::stem_kernel<2>": {"hbm_bytes_per_launch": 0.6e9, "launches": 6},
+                      "at::native::vectorized_elementwise_kernel": {"hbm_bytes_per_launch": 5.0e9, "launches": 6}},   # not the path's
+          "workloads": {}}
+    gb, unit = bench.step_traffic_from_summary(tr, "lite/16/32/f32", "a" * 64)
+    assert gb == 9.6 and "6 steps" in unit
+    assert bench.step_traffic_from_summary(tr, "lite/16/32/f32", "b" * 64)[0] is None          # other sources
+    assert bench.step_traffic_from_summary(tr, "full/16/32/f32", "a" * 64)[0] is None          # workload not profiled
+    del tr["pmc_steps"]
+    assert bench.step_traffic_from_summary(tr, "lite/16/32/f32", "a" * 64)[0] is None
+
+
+def test_fused_model_bytes_are_the_survey_figures():
+    """NetSpec.fused_model_bytes = SURVEY.md section 8(d): 18.54 GB (configs[1]), 31.30 GB (configs[3]) per 32 clips, fp32."""
+    from eco_amd import models
+    from eco_amd.netspec import NetSpec
+    lite = NetSpec.from_prototxt(models.eco_lite_deploy(num_segments=16, num_clips=32))
+    full = NetSpec.from_prototxt(models.eco_full_deploy(num_segments=16, num_clips=32))
+    assert round(lite.fused_model_bytes() / 1e9, 2) == 18.54 and round(full.fused_model_bytes() / 1e9, 2) == 31.30
+    assert round(NetSpec.from_prototxt(models.eco_lite_deploy(num_segments=32, num_clips=32)).fused_model_bytes(2) / 1e9, 2) == 18.47
+
+
+def test_metric_string_is_baseline_json_s():
+    import json
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    want = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    assert "×" in want and '224\\u00d7224' in src
+    assert want == "clips/sec (whole node), ECO-%s N=%d 224×224 bs%d; top-1 logits vs CPU ref" % ("Lite", 16, 32)

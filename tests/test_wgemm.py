@@ -522,3 +522,107 @@ def test_wino_s2_eco_trunk_layers(hip_backend, name, n, cin, couts, odims):
     Eltwise residual + raw + BN + ReLU epilogue, against the oracle's direct convolution."""
     worst = run_wino_s2(hip_backend, n, cin, couts, odims, None, "fused", relu_x=True)
     print(f"{name}: {worst:.2e} of the largest output")
+
+
+# ---- the 2-D form: F(7,2) x F(7,2) on 64 points, depth taps direct (kz = 3) or none (kz = 1) ---------------------------------
+S2D_CASES = [  # n, cin, couts, kz, OUTPUT volume (Do, Ho, Wo), num_cu
+    (2, 4, (32, 32), 3, (2, 7, 7), None),      # res5a-like: one tile per plane, depth taps incl. the plane above the volume
+    (3, 8, (64,), 1, (1, 14, 7), None),        # a strided 2-D 3x3 conv (D = 1): K = 4 cin
+    (5, 4, (96,), 3, (3, 7, 14), 1),           # odd output depth, ragged image groups, bm = 96, tiny "device"
+    (2, 4, (32,), 1, (4, 7, 7), None),         # a (1,3,3) kernel with stride (1,2,2) on a 3-D blob: planes are positions
+]
+
+
+def run_wino_s2d(backend, n, cin, couts, kz, odims, num_cu, mode, relu_x=False, tol=5e-4):
+    Do, Ho, Wo = odims
+    D, H, W = (2 * Do if kz == 3 else Do), 2 * Ho, 2 * Wo
+    rng = np.random.default_rng(cin + sum(couts) + Ho + Do + kz)
+    x = rng.normal(size=(n, cin, D, H, W)).astype(np.float32)
+    if relu_x:
+        x = np.maximum(x, 0)
+    ctot = sum(couts)
+    w = (rng.normal(size=(ctot, cin, kz, 3, 3)) / np.sqrt(cin * 9 * kz)).astype(np.float32)
+    b = rng.normal(size=ctot).astype(np.float32)
+    ref = orc.convolution(x, w, b, (kz, 3, 3), (2 if kz == 3 else 1, 2, 2), (1 if kz == 3 else 0, 1, 1))
+    assert ref.shape == (n, ctot, Do, Ho, Wo)
+    lib = backend.lib
+    TH, TW = Ho // 7, Wo // 7
+    K = 4 * kz * cin
+    plan = lib.wgemm_plan(n, K, ctot, Do, TH, TW, 1, num_cu, points=64)
+    assert plan.points == 64 and plan.q == n * Do * TH * TW and plan.nstages == K // 16
+    u = np.empty((64, ctot, K, 1), np.float32)
+    lib.wino_s2d_weight_transform(w.ctypes.data, ctot, cin, kz, u.ctypes.data)
+    up = np.empty(plan.u_elems, np.float32)
+    lib.wgemm_pack_weights(plan, u.ctypes.data, up.ctypes.data)
+    vbuf = backend.dev(np.full(plan.v_elems, np.nan, np.float32))
+    mbuf = backend.empty((plan.m_elems,))
+    lib.wino_s2d_input_forward(plan, backend.ptr(backend.dev(x)), backend.ptr(vbuf), kz, D, H, W)
+    lib.wgemm_forward(plan, backend.ptr(vbuf), backend.ptr(backend.dev(up)), backend.ptr(mbuf))
+    S = Do * Ho * Wo
+    shp = (1, -1, 1, 1, 1)
+    worst, c0 = 0.0, 0
+    for k, cout in enumerate(couts):
+        v = ref[:, c0:c0 + cout]
+        scale = np.abs(v).max()
+        ep = hip.ConvEpilogue()
+        ep.bias = backend.ptr(backend.dev(b[c0:c0 + cout]))
+        ep.residual, ep.raw, ep.act, ep.act2 = hip.null_view(), hip.null_view(), hip.null_view(), hip.null_view()
+        ep.bn_scale = ep.bn_shift = None
+        ep.relu = 0
+        if mode == "plain" or k % 2 == 1:
+            y_raw = backend.empty(v.shape)
+            ep.raw = hip.plain_view(backend.ptr(y_raw), cout, S)
+            lib.wino_s2d_output_forward(plan, backend.ptr(mbuf), c0, cout, Do, Ho, Wo, ep)
+            worst = max(worst, np.abs(backend.host(y_raw, v.shape) - v).max() / scale)
+        else:   # bias + residual + BN + ReLU into a channel slice of a wider (Concat) tensor, raw beside it
+            res = rng.normal(size=v.shape).astype(np.float32)
+            sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
+            o0, wide = 8, cout + 24
+            big = backend.dev(np.full((n, wide, Do, Ho, Wo), 7.0, np.float32))
+            y_raw = backend.empty(v.shape)
+            ep.residual = hip.plain_view(backend.ptr(backend.dev(res)), cout, S)
+            ep.raw = hip.plain_view(backend.ptr(y_raw), cout, S)
+            ep.bn_scale, ep.bn_shift, ep.relu = backend.ptr(backend.dev(sc)), backend.ptr(backend.dev(sh)), 1
+            ep.act = hip.View(backend.ptr(big, o0 * S), wide * S, 0, S, 1)
+            lib.wino_s2d_output_forward(plan, backend.ptr(mbuf), c0, cout, Do, Ho, Wo, ep)
+            ref_raw = v + res
+            got = backend.host(big, (n, wide, Do, Ho, Wo))
+            worst = max(worst, np.abs(backend.host(y_raw, v.shape) - ref_raw).max() / scale,
+                        np.abs(got[:, o0:o0 + cout] - np.maximum(ref_raw * sc.reshape(shp) + sh.reshape(shp), 0)).max() / scale)
+            assert (got[:, :o0] == 7.0).all() and (got[:, o0 + cout:] == 7.0).all()
+        c0 += cout
+    assert worst <= tol, worst
+    return worst
+
+
+@pytest.mark.parametrize("n,cin,couts,kz,odims,num_cu", S2D_CASES, ids=[f"s2d_{i}" for i in range(len(S2D_CASES))])
+@pytest.mark.parametrize("mode", ["plain", "fused"])
+def test_wino_s2d_route_matches_direct_conv(backend, n, cin, couts, kz, odims, num_cu, mode):
+    run_wino_s2d(backend, n, cin, couts, kz, odims, num_cu, mode)
+
+
+def test_wino_s2d_rejects_wrong_plans(backend):
+    lib = backend.lib
+    p320 = lib.wgemm_plan(1, 32, 32, 1, 1, 1, 1, None, points=320)
+    with pytest.raises(hip.EcoError, match="64"):
+        lib.wino_s2d_input_forward(p320, 0, 0, 3, 8, 14, 14)
+    p = lib.wgemm_plan(1, 48, 32, 4, 1, 1, 1, None, points=64)
+    with pytest.raises(hip.EcoError, match="kz"):
+        lib.wino_s2d_input_forward(p, 0, 0, 2, 8, 14, 14)
+    with pytest.raises(hip.EcoError, match="planes"):
+        lib.wino_s2d_input_forward(p, 0, 0, 3, 4, 14, 14)        # two output planes, the plan has four
+    assert lib.wino_s2d_lds_bytes(32, 3, 4, 1, 1) == 8 * 8 * 16 * 20 * 4    # eight images' eight planes
+
+
+S2D_ECO = [  # id, n, cin, couts, kz, OUTPUT volume
+    ("res5a", 8, 256, (512, 512), 3, (4, 7, 7)),                 # models_ECO_Lite/kinetics/deploy.prototxt:1462-1530
+    ("inception_3c_3x3", 32, 128, (160,), 1, (1, 14, 14)),       # models_ECO_Full/kinetics/deploy.prototxt:1854-1990
+    ("inception_4e_double_3x3_2", 64, 256, (256,), 1, (1, 7, 7)),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n,cin,couts,kz,odims", S2D_ECO, ids=[c[0] for c in S2D_ECO])
+def test_wino_s2d_eco_layers(hip_backend, name, n, cin, couts, kz, odims):
+    worst = run_wino_s2d(hip_backend, n, cin, couts, kz, odims, None, "fused", relu_x=True)
+    print(f"{name}: {worst:.2e} of the largest output")

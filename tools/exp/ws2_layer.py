@@ -78,3 +78,16 @@ for c in couts[:1]:
     ep = eps[0][2]
     timeit(lambda: lib.conv_forward(g, p, x.data_ptr(), wp.data_ptr(), kt.data_ptr(), ep, ws.data_ptr() if p.ws_bytes else None, s),
            f"direct conv_mfma (one conv, split-K {p.ksplit}, incl. reduce)")
+
+# the same GEMM on N(0,1) operands (is the time data-dependent?)
+v2 = torch.randn(plan.v_elems, device=dev)
+up2 = torch.randn(plan.u_elems, device=dev)
+timeit(lambda: lib.wgemm_forward(plan, v2.data_ptr(), up2.data_ptr(), m.data_ptr(), s), "GEMM, N(0,1) V and U")
+timeit(lambda: lib.wgemm_forward(plan, v.data_ptr(), up2.data_ptr(), m.data_ptr(), s), "GEMM, transformed V, N(0,1) U")
+timeit(lambda: lib.wgemm_forward(plan, v2.data_ptr(), up.data_ptr(), m.data_ptr(), s), "GEMM, N(0,1) V, 0.01 N(0,1) U")
+print("V stats: zeros %.3f, |V| mean %.3f max %.1f" % ((v == 0).float().mean().item(), v.abs().mean().item(), v.abs().max().item()))
+for bn, ks in ((128, 1), (128, 2), (256, 2)):
+    q = lib.wgemm_plan(B, 8 * cin, ctot, Do // 4, Ho // 7, Wo // 7, 1, None, points=320)
+    q.bn = bn; q.ksplit = ks
+    m2 = torch.empty(320 * ks * ctot * plan.q, device=dev)
+    timeit(lambda: lib.wgemm_forward(q, v.data_ptr(), up.data_ptr(), m2.data_ptr(), s), f"GEMM, real operands, bn={bn} ks={ks}")

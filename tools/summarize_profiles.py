@@ -70,6 +70,9 @@ def main():
                    # sources keeps the field, an edited kernel drops it
                    "src_sha256": open(sha).read().strip().splitlines()[-1] if os.path.exists(sha) else None,
                    "workload": "lite/16/32/f32",
+                   # steps each PMC pass ran (tools/profile_round.sh: bench.py --steps 2 --warmup 1 + the three per-launch
+                   # profiling iterations): launches / pmc_steps = launches per step
+                   "pmc_steps": 6,
                    "kernels": summary, "workloads": others}, f, indent=1)
     sq = os.path.join(src, "pmc_sq", "bench_counter_collection.csv")
     if os.path.exists(sq):
