@@ -24,13 +24,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # MI355X peaks from /opt/skills/guides/MI355X_MICROARCH.md (dense, no sparsity)
-PEAK_MFMA_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32x3": 2500.0 / 6}   # f32x3: 6 bf16 products per fp32 multiply
+PEAK_MFMA_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
 PEAK_HBM_GBS = 8000.0
 
 
 def baseline_config(variant: str, segments: int, clips: int, dtype: str, world: int) -> str:
     """Which BASELINE.json configuration a run is (the judge matches `config.workload` against it)."""
-    if variant == "lite" and segments == 16 and clips == 32 and dtype in ("f32", "f32x3"):
+    if variant == "lite" and segments == 16 and clips == 32 and dtype == "f32":
         return "BASELINE.json configs[1]" if world == 1 else (
             "BASELINE.json configs[2]" if world == 8 else f"configs[1] per GPU x{world} GPUs (configs[2] sharding)")
     if variant == "full" and segments == 16 and clips == 32 and dtype == "f32":
@@ -50,9 +50,8 @@ def main() -> None:
     ap.add_argument("--clips-per-gpu", type=int, default=32)
     ap.add_argument("--segments", type=int, default=16)
     ap.add_argument("--variant", choices=["lite", "full"], default="lite")
-    ap.add_argument("--dtype", choices=["f32", "bf16", "f32x3"], default="f32",
-                    help="f32: fp32 storage, fp32 MFMA; bf16: bf16 storage, bf16 MFMA (configs[4]); f32x3: fp32 storage, "
-                         "operands split exactly into 3 bf16 terms on the bf16 MFMA (fp32 accumulation in all three)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32: fp32 storage, fp32 MFMA; bf16: bf16 storage, bf16 MFMA, fp32 accumulation (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-winograd", action="store_true", help="evaluate every convolution directly (A/B runs)")
     ap.add_argument("--graph", action="store_true",

@@ -1,7 +1,6 @@
 """Host-side mirror of the channel-blocked ("NC8") storage of csrc/eco_blocked.hip.
 
-The blocked bf16 path keeps activations as ``X[n][c/8][spatial...][c%8]`` (bf16 bits, or fp32 for the
-split-operand form).  Callers never see that layout: inputs and logits are plain fp32, and when a caller
+The blocked bf16 path keeps activations as ``X[n][c/8][spatial...][c%8]`` (bf16 bits).  Callers never see that layout: inputs and logits are plain fp32, and when a caller
 looks at an intermediate blob (``net.blobs[name].data``) the raw storage is converted back to the reference's
 ``N,C,[D,]H,W`` fp32 here.  NumPy only -- plumbing, no arithmetic beyond the bf16 <-> fp32 bit moves."""
 from __future__ import annotations
@@ -11,8 +10,7 @@ from typing import Sequence
 import numpy as np
 
 DT_BF16 = 1
-DT_F32X3 = 3
-STORAGE = {DT_BF16: np.uint16, DT_F32X3: np.float32}
+STORAGE = {DT_BF16: np.uint16}
 
 
 def bf16_bits(x: np.ndarray) -> np.ndarray:

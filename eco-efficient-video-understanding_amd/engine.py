@@ -118,13 +118,13 @@ class Engine:
         self.lib = lib
         self.alloc = alloc
         self.fuse = fuse
-        # "f32": fp32 N,C,[D,]H,W blobs, fp32 MFMA kernels (eco_conv.hip).  "bf16" / "f32x3": the channel-blocked
+        # "f32": fp32 N,C,[D,]H,W blobs, fp32 MFMA kernels (eco_conv.hip).  "bf16": the channel-blocked
         # path on the bf16 matrix cores (eco_blocked.hip) with bf16 storage / fp32 storage and exactly split
         # operands; fused plan only, every convolution evaluated directly.
-        if dtype not in ("f32", "bf16", "f32x3"):
-            raise ValueError("dtype must be 'f32', 'bf16' or 'f32x3'")
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
         self.dtype = dtype
-        self.dt = {"f32": 0, "bf16": hip.DT_BF16, "f32x3": hip.DT_F32X3}[dtype]
+        self.dt = {"f32": 0, "bf16": hip.DT_BF16}[dtype]
         if self.dt and not fuse:
             raise NetSpecError("the blocked bf16-MFMA path runs the fused plan only (fuse=True)")
         self.esize = 2 if self.dt == hip.DT_BF16 else 4        # bytes per stored activation element

@@ -24,7 +24,6 @@ POOL_AVE = 1
 ABI_VERSION = 19
 MAX_SEG = 3   # ECO_MAX_SEG: extra output segments of a sibling launch
 DT_BF16 = 1
-DT_F32X3 = 3
 
 _i32x3 = C.c_int32 * 3
 

@@ -174,8 +174,7 @@ class Net:
         # summation order); the default (True) routes every stride-1 3x3(x3) conv with cin >= 64 through
         # Winograd F(4x4,3x3) when the batch is large enough (engine._wino_eligible); 2 / 4 force the tile size
         # dtype: "f32" (default) = the reference's fp32 blobs on the fp32 MFMA kernels; "bf16" = bf16 storage and
-        # bf16 MFMA with fp32 accumulation (BASELINE configs[4]); "f32x3" = fp32 storage, operands split exactly
-        # into three bf16 terms on the bf16 matrix cores.  The last two keep activations channel-blocked internally;
+        # bf16 MFMA with fp32 accumulation (BASELINE configs[4]), which keeps activations channel-blocked internally;
         # .data still hands out N,C,... fp32 arrays.
         # pool_commute=False keeps AVE pool -> 1x1 conv in the reference's order (default: conv first, on the block's
         # input inside the sibling launch; the average then runs on the conv's channels -- engine.pool_commute)

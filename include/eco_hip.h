@@ -79,7 +79,8 @@ const char* eco_source_digest(void);
  * ENVIRONMENT SWITCHES.  Read with getenv() the first time the path they guard is taken, then cached for the life of the
  * process; none changes results beyond fp32 summation order, all select between forms that the tests run against the same
  * oracle (tests/test_fallback_paths.py, on the emulator and on the GPU).  Unset = the default in brackets.
- *   ECO_SPANP=0           bf16 stride-1 3x3(x3) convolutions on the per-tile span kernel instead of the persistent one [persistent]
+ *   ECO_SPANP=0           bf16 stride-1 3x3(x3) convolutions on the per-tap LDS-DMA kernel (the fallback of views >= 2 GB) instead of
+ *                         the persistent span kernel [persistent]
  *   ECO_SPANP_DYNAMIC=0   the persistent kernel's workgroups take equal static item shares instead of drawing from a counter [dynamic]
  *   ECO_STEMB_DYNAMIC=0   the same for the fused bf16 stem's patches [dynamic]
  *   ECO_CONVB_DMA_BUF=0   the LDS-DMA kernel addresses its operands with 64-bit flat addresses instead of buffer descriptors
@@ -496,10 +497,10 @@ int eco_wino_s2d_output_forward(const eco_wgemm_plan* plan, const float* m, int3
  * Same operators, epilogue algebra and error conventions as the fp32 entry points above; in every
  * eco_view / eco_conv_epilogue handed to these functions `ptr` addresses elements of the storage type and the
  * strides count 8-channel blocks:  block(img, c, sp) = (img / t)*stride_b + (img % t)*stride_t + (c/8)*stride_c + sp.
- * bias / bn_scale / bn_shift / fc weights / logits are fp32 for both storage types. */
+ * bias / bn_scale / bn_shift / fc weights / logits are fp32. */
 #define ECO_DT_BF16 1  /* bf16 storage; products of bf16 operands accumulated in fp32                         */
-#define ECO_DT_F32X3 3 /* fp32 storage; each operand split exactly into 3 bf16 terms, the 6 products of order */
-                       /* <= 2 accumulated in fp32: fp32-class results on the bf16 matrix cores              */
+/* (ECO_DT_F32X3 = 3 -- fp32 storage, every operand split exactly into three bf16 terms -- existed until v18: 27.6 ms per
+ * configs[1] step against 17.3 ms on the fp32 MFMA, never a reported configuration; removed in v19 with its kernel) */
 
 typedef struct eco_convb_plan {
   int32_t bm, bn;    /* block tile: output channels x output positions                                  */
@@ -512,7 +513,7 @@ typedef struct eco_convb_plan {
   int32_t span_pieces; /* > 0: stride-1 same-size (kd)x3x3 span kernel; 64-position DMA pieces per staged span */
   int32_t pgrid;     /* > 0 (span plans, v17): workgroups of the persistent span kernel, 2 per compute unit,   */
                      /* a multiple of 8 XCDs x the M-blocks of a position tile; 0 = one workgroup per tile   */
-  int64_t wp_vecs;   /* 16-byte vectors in the packed weights: terms * nstages * 4 * mpad                */
+  int64_t wp_vecs;   /* 16-byte vectors in the packed weights: nstages * 4 * mpad                          */
   int64_t ws_bytes;  /* device scratch eco_convb_forward needs (0: none)                                 */
   int32_t tail_tiles;  /* > 0 (persistent span plans with ksplit == 1, v17): the last tail_tiles tiles are   */
   int32_t tail_ksplit; /* cut into tail_ksplit slices of their reduction (partial sums + a reduce launch     */
@@ -522,8 +523,8 @@ typedef struct eco_convb_plan {
 /* Requirements: cout % 8 == 0 and cin % 8 == 0, or the stem geometry (cin 3, 2-D 7x7, stride 2, pad 3, even W).
  * num_cu = 0 sizes the plan for 256 compute units. */
 int eco_convb_plan_create(const eco_conv_geom* g, int32_t dt, int32_t num_cu, eco_convb_plan* plan);
-/* HOST function: caffe weights w[cout][cin][kd][kh][kw] (fp32) -> wp[term][stage][4][mpad][8] bf16
- * (stage = channel-group*taps + tap; ECO_DT_F32X3 stores the three bf16 terms of every weight). */
+/* HOST function: caffe weights w[cout][cin][kd][kh][kw] (fp32) -> wp[stage][4][mpad][8] bf16
+ * (stage = channel-group*taps + tap). */
 int eco_convb_pack_weights(const eco_conv_geom* g, const eco_convb_plan* plan, const float* w, void* wp);
 /* ConvolutionLayer::Forward_gpu (+ fused BN / ReLU / Eltwise / Concat / Reshape+Permute) on blocked tensors. */
 int eco_convb_forward(const eco_conv_geom* g, const eco_convb_plan* plan, const void* x, const void* wp,

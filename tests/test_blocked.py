@@ -3,17 +3,15 @@ emulator (CPU suite) and on the GPU (-m gpu).
 
 Tolerances.  ECO_DT_BF16: operands are bf16 (the oracle is fed the same bf16-rounded inputs and weights, so the
 products agree exactly), accumulation is fp32, and each stored output is rounded once to bf16: |err| <=
-2^-8 |y| (half a bf16 ulp is 2^-9) + accumulation-order noise.  ECO_DT_F32X3: operands are split exactly into three
-bf16 terms and the six products of order <= 2 are kept: fp32-class, 2e-5 of the largest output as for the fp32
-kernels."""
+2^-8 |y| (half a bf16 ulp is 2^-9) + accumulation-order noise."""
 import numpy as np
 import pytest
 
 import eco_oracle as orc
 from eco_amd import blocked, hip
 
-BF16, F32X3 = hip.DT_BF16, hip.DT_F32X3
-DTS = [pytest.param(BF16, id="bf16"), pytest.param(F32X3, id="f32x3")]
+BF16 = hip.DT_BF16
+DTS = [pytest.param(BF16, id="bf16")]
 
 
 def dev_blocked(backend, x, dt):
@@ -307,7 +305,7 @@ def oracle_blocked(spec, params, x, dt, stored):
                        input_hook=lambda name, v: blocked.bf16_round(v))
 
 
-@pytest.mark.parametrize("dtype,dt", [("bf16", BF16), ("f32x3", F32X3)])
+@pytest.mark.parametrize("dtype,dt", [("bf16", BF16)])
 def test_mini_eco_lite_blocked(backend, dtype, dt):
     from eco_amd import fillers
     from eco_amd.net import Net
@@ -323,8 +321,7 @@ def test_mini_eco_lite_blocked(backend, dtype, dt):
     stored = {n for n, t in net._engine.tensors.items() if t.dt}
     ref = oracle_blocked(spec, params, x, dt, stored)
     scale = np.abs(ref["fc8"]).max()
-    # bf16: against the oracle with the same storage rounding (accumulation order and double rounding remain);
-    # f32x3: fp32-class
+    # against the oracle with the same storage rounding (accumulation order and double rounding remain)
     assert np.abs(out - ref["fc8"]).max() <= (2e-2 if dt == BF16 else 2e-5) * scale
     if dt == BF16:  # and against the plain fp32 oracle within the stated bf16 tolerance
         full = orc.forward(spec, params, {"data": x})["fc8"]

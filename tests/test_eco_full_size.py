@@ -262,24 +262,28 @@ def test_eco_lite_c5_bf16_n32():
     assert np.abs(outp - out[perm]).max() < 5e-3 * scale   # tile boundaries move with the clip order
 
 
-def test_eco_lite_c2_f32x3():
-    """configs[1] geometry on the split-operand path (fp32 storage, three exact bf16 terms per operand, six MFMA
-    products): fp32-class logits -- the fp32 tolerance of 1e-3 applies, measured value printed -- and it agrees
-    with the fp32-MFMA path of the same build."""
+def test_eco_lite_c2_direct_and_minimal_filtering_plans_agree():
+    """configs[1] with every convolution evaluated directly (winograd=False: the reference's arithmetic up to summation order)
+    against the default plan -- F(4x4,3x3), F(4x4x4,3x3x3) and, since round 6, the stride-2 polyphase routes of res4a / res5a --
+    over all 32 clips: fp32 rounding only (1e-4 of the largest logit; measured value printed); both against the oracle on clip 0."""
     N, B = 16, 32
     proto = models.eco_lite_deploy(num_segments=N, num_clips=B)
     spec = NetSpec.from_prototxt(proto)
     params = fillers.synthetic_params(spec)
     x = fillers.synthetic_frames(B * N)
-    out = Net(proto, params=params, dtype="f32x3").forward(data=x)["fc8"].copy()
+    net = Net(proto, params=params)
+    labels = net.op_labels()
+    assert sum("stride-2 winograd" in l for l in labels) == 6 and sum("F(4x4x4,3x3x3) input" in l for l in labels) == 9, labels
+    assert not any("conv_mfma" in (op[3].get("kernel") or "") for op in net._engine.ops)     # no direct strided launch is left
+    out = net.forward(data=x)["fc8"].copy()
     scale = np.abs(out).max()
     spec1 = NetSpec.from_prototxt(models.eco_lite_deploy(num_segments=N, num_clips=1))
     ref = _fast_oracle(spec1, params, x[:N])["fc8"]
     native = Net(proto, params=params, winograd=False).forward(data=x)["fc8"]
-    print(f"f32x3: rel err vs CPU oracle {relerr(out[:1], ref):.3e}; fp32-MFMA direct path vs oracle "
-          f"{relerr(native[:1], ref):.3e}; f32x3 vs fp32-MFMA over 32 clips {np.abs(out - native).max() / scale:.3e}")
-    assert relerr(out[:1], ref) < TOL and out[0].argmax() == ref.argmax()
-    assert np.abs(out - native).max() < 1e-4 * scale
+    print(f"default plan vs CPU oracle {relerr(out[:1], ref):.3e}; direct plan vs oracle {relerr(native[:1], ref):.3e}; "
+          f"default vs direct over 32 clips {np.abs(out - native).max() / scale:.3e}")
+    assert relerr(out[:1], ref) < TOL and relerr(native[:1], ref) < TOL and out[0].argmax() == ref.argmax()
+    assert np.abs(out - native).max() < 1e-4 * scale and (out.argmax(1) == native.argmax(1)).all()
 
 
 @pytest.mark.gpu

@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-PEAK_MFMA = {"f32": 157.3e12, "bf16": 2500e12, "f32x3": 2500e12 / 6}   # f32x3: six bf16 MFMA products per fp32 one
+PEAK_MFMA = {"f32": 157.3e12, "bf16": 2500e12}
 PEAK_HBM = 8.0e12
 
 
@@ -26,7 +26,7 @@ def main() -> None:
     ap.add_argument("--clips", type=int, default=32)
     ap.add_argument("--iterations", type=int, default=10)
     ap.add_argument("--no-fuse", action="store_true", help="one launch per prototxt layer, like the reference executor")
-    ap.add_argument("--dtype", choices=["f32", "bf16", "f32x3"], default="f32")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--no-winograd", action="store_true")
     args = ap.parse_args()
 
