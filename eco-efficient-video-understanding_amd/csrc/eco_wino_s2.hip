@@ -361,29 +361,42 @@ __global__ __launch_bounds__(256) void wino_s2d_input_kernel(const S2dInArgs a) 
   const int plane = a.PH * a.PW;
   const long hw = (long)a.H * a.W;
 
-  // ---- phase 1 ----
+  // ---- phase 1 ----  (eight slots per thread and pass: the loads of a pass are all in flight before the first LDS store -- one
+  // load per loop iteration left every iteration a memory round trip of its own: res5a 0.064 ms for 152 MB)
   const int pwv = a.PW / 4;
   const int slots = gb * a.D * a.PH * pwv;
-  for (int s = tid; s < slots; s += nthr) {
-    const int pv = s % pwv;
-    int t = s / pwv;
-    const int ph = t % a.PH;
-    t /= a.PH;                                            // = bl * D + d
-    const int bl = t / a.D, d = t - bl * a.D;
-    const int h = ph - 2, w0 = 4 * pv - 4;
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (h >= 0 && w0 >= 0 && w0 < a.W) {
-      const float* xp = a.x + (((long)(b0 + bl) * a.cin + c) * a.D + d) * hw + (long)h * a.W + w0;
-      if (VEC == 4) {
-        q = ld((const float4*)xp);
-      } else {
-        q.x = ld(xp);
-        if (w0 + 1 < a.W) q.y = ld(xp + 1);
-        if (w0 + 2 < a.W) q.z = ld(xp + 2);
-        if (w0 + 3 < a.W) q.w = ld(xp + 3);
+  constexpr int U = 8;
+  for (int s0 = tid; s0 < slots; s0 += nthr * U) {
+    float4 q[U];
+    int off[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s = s0 + u * nthr;
+      q[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      off[u] = -1;
+      if (s >= slots) continue;
+      const int pv = s % pwv;
+      int t = s / pwv;
+      const int ph = t % a.PH;
+      t /= a.PH;                                            // = bl * D + d
+      const int bl = t / a.D, d = t - bl * a.D;
+      const int h = ph - 2, w0 = 4 * pv - 4;
+      off[u] = t * plane + ph * a.PW + 4 * pv;
+      if (h >= 0 && w0 >= 0 && w0 < a.W) {
+        const float* xp = a.x + (((long)(b0 + bl) * a.cin + c) * a.D + d) * hw + (long)h * a.W + w0;
+        if (VEC == 4) {
+          q[u] = ld((const float4*)xp);
+        } else {
+          q[u].x = ld(xp);
+          if (w0 + 1 < a.W) q[u].y = ld(xp + 1);
+          if (w0 + 2 < a.W) q[u].z = ld(xp + 2);
+          if (w0 + 3 < a.W) q[u].w = ld(xp + 3);
+        }
       }
     }
-    *(float4*)(zd + (long)t * plane + ph * a.PW + 4 * pv) = q;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (off[u] >= 0) *(float4*)(zd + off[u]) = q[u];
   }
   __syncthreads();
 
