@@ -19,7 +19,7 @@ cp $CSRC/*.hip $CSRC/*.h $SCRATCH/eco/csrc/
 cp $ROOT/include/eco_hip.h $SCRATCH/include/
 (cd $SCRATCH/eco/csrc && patch -p1 -s < $ROOT/tools/exp/probes.patch)
 OBJS=""
-for f in eco_api eco_conv eco_ops eco_wino eco_blocked eco_wgemm eco_wino3 eco_stem eco_stemb; do
+for f in eco_api eco_conv eco_ops eco_wino eco_blocked eco_blocked_ops eco_wgemm eco_wino3 eco_wino_s2 eco_stem eco_stemb; do
   if [ $f = $SRC ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=default -fno-slp-vectorize "$@" -c $SCRATCH/eco/csrc/$f.hip -o /tmp/${f}_$NAME.o
     OBJS="$OBJS /tmp/${f}_$NAME.o"
