@@ -70,12 +70,19 @@ __global__ __launch_bounds__(256, 2) void wgemm_kernel(const WGemmArgs a) {
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, l31 = lane & 31;
 
+  // XCD-aware numbering over the WHOLE launch (points x slices x tiles): the hardware deals consecutive blocks of the linearised
+  // grid to the eight XCDs in turn; xcd_remap gives every XCD a contiguous range of logical work items, so the M-blocks of a
+  // position tile -- consecutive items -- read their V rows through ONE L2.  (Until round 6 the remap ran inside a point only: with
+  // the four / eight tiles per point of the stride-2 problems every M-block of a position tile sat on a different XCD and V was
+  // fetched four / eight times -- PMC: 2.18 GB per res4a launch against 1.17 algorithmic.)
   const int ntiles = a.mblocks * a.nblk_n;
-  const int slice = (int)blockIdx.x / ntiles;
-  const int tile = xcd_remap((int)blockIdx.x - slice * ntiles, ntiles);
+  const int per_pt = (int)gridDim.x;                       // = ntiles * ksplit
+  const int work = xcd_remap((int)blockIdx.y * per_pt + (int)blockIdx.x, per_pt * (int)gridDim.y);
+  const int pt = work / per_pt, rest = work - pt * per_pt;
+  const int slice = rest / ntiles;
+  const int tile = rest - slice * ntiles;
   const int mblk = tile % a.mblocks, nblk = tile / a.mblocks;
   const int n0 = nblk * BN;
-  const int pt = (int)blockIdx.y;
   const int s_begin = (int)((long)slice * a.nstages / a.ksplit);
   const int s_end = (int)((long)(slice + 1) * a.nstages / a.ksplit);
 
