@@ -14,7 +14,8 @@
 // 320 * 8 / 196 = 13.1 multiplies per output and input channel instead of 27 -- and V / M are only 1.63x the input /
 // output volume.  Measured (GEMM alone, 32 clips, K = 1024): res4a_1 and res4a_down as ONE problem of 512 output
 // channels 0.66 ms at 131 TFLOP/s, against 2 x (0.82 + 0.06) ms on the direct kernel.  res5a (4 x 7 x 7 outputs: one
-// tile per clip, 32 positions per point) would stream 1.3 GB of transformed weights per layer and stays direct.
+// tile per clip, 32 positions per point) would stream 1.3 GB of transformed weights per layer on this form (measured 0.68 ms
+// per conv against 0.43 direct) and takes the 2-D form below instead.
 //
 // THE 2-D FORM (points = 64): where the output volume has too few 4 x 7 x 7 tiles for that (res5a: 4 x 7 x 7 outputs, one tile
 // per clip -- 32 positions per point would stream 1.3 GB of transformed weights per layer) or there is no depth axis at all

@@ -150,8 +150,9 @@ class Engine:
         # STRIDE-2 3x3x3 layers (res4a_1 / res4a_down) as eight polyphase F(4,2) x F(7,2) x F(7,2) problems on the same GEMM
         # (csrc/eco_wino_s2.hip): 13.1 multiplies per output and input channel instead of 27, where the output volume tiles
         # by 4 x 7 x 7, the input is exactly twice as large and a transform point still has wino_s2_min_positions tile
-        # positions (res5a at 32 clips has 32 and would stream 1.3 GB of transformed weights: it stays direct).  Convs of
-        # one geometry on the same bottom share the input transform and the GEMM.
+        # positions; else (res5a at 32 clips has 32 and would stream 1.3 GB of transformed weights) the 2-D form, F(7,2) x F(7,2) with
+        # every output plane a position and the depth taps in the reduction -- also for strided 2-D 3x3 convs where a cost estimate
+        # says the transforms pay (_ws2_form).  Convs of one geometry on the same bottom share the input transform and the GEMM.
         self.wino_s2 = True
         self.wino_s2_min_positions = 128
         self._ws2_groups: Dict[str, dict] = {}
