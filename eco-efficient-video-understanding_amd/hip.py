@@ -127,8 +127,9 @@ def convb_kernel_name(plan: "ConvBPlan") -> str:
     if plan.dt == DT_BF16 and plan.span_pieces:
         if plan.pgrid and plan.span_pieces <= 6 and os.environ.get("ECO_SPANP", "1") != "0":
             return f"eco::convb_spanp_kernel<{plan.bm // 32}>"      # persistent form (round 4)
+        # (fallback of the persistent form since ABI v19: the per-tap LDS-DMA kernel on the span plan's 256-position tiles)
         tm, tn, wm, wn = {128: (4, 2, 1, 4), 96: (3, 2, 1, 4), 64: (2, 2, 1, 4), 32: (1, 2, 1, 4)}[plan.bm]
-        return f"eco::convb_span_kernel<{tm}, {tn}, {wm}, {wn}>"
+        return f"eco::convb_dma_kernel<{tm}, {tn}, {wm}, {wn}>"
     if plan.dt == DT_BF16:   # LDS-DMA kernel
         tm, tn, wm, wn = {(256, 128): (4, 2, 2, 2), (128, 256): (4, 2, 1, 4)}.get((plan.bm, plan.bn)) or _CONV_TILES[(plan.bm, plan.bn)]
         return f"eco::convb_dma_kernel<{tm}, {tn}, {wm}, {wn}>"
