@@ -167,10 +167,15 @@ class Engine:
         # BN, ReLU) on its cout output channels instead of on the cin input channels (csrc/eco_ops.hip,
         # avgpool2d_k3s1p1_affine_kernel).  fp32 path; logits differ from the reference order by fp32 rounding.
         self.pool_commute = True
-        # ... and a residual block's strided first conv with its projection shortcut (res4a_1 | res4a_down).  Off:
-        # measured at 32 clips the 512-channel launch quantises worse over the CUs than the two 256-channel ones
-        # (1.73-1.89 ms against 2 x 0.80 ms; res5a: 0.80 against 0.85), see profiles/r02_notes.md
-        self.sibling_blocks = False
+        # ... and a residual block's strided first conv with its projection shortcut (res4a_1 | res4a_down, res5a_1 | res5a_down) as
+        # one direct launch; the shortcut then keeps its raw value and the Eltwise rides on the block's second conv.  Round 2 left
+        # this off: at 32 clips the fp32 512-channel launch quantised worse over the CUs than two 256-channel ones (1.73-1.89 ms
+        # against 2 x 0.80; res5a: 0.80 against 0.85, profiles/r02_notes.md).  Round 6: at 32 clips the fp32 pairs run as polyphase
+        # groups (_ws2_form) and never get here; what does get here gains -- fp32 at small batches (one clip per step: 1.150 ->
+        # 1.083 ms, two: 1.525 -> 1.483, four: 2.076 -> 2.054; tools/exp/b1_sibling_blocks.py) and the blocked bf16 path, whose
+        # strided launches are bound by operand traffic through L2 (configs[4]: res4a 0.196 + 0.214 -> 0.335 ms, res5a 0.115 +
+        # 0.125 -> 0.171, step 6.47 -> 6.35; tools/exp/bf16_sibling_blocks.py): the pair reads (gathers) its positions once.
+        self.sibling_blocks = True
         self.num_cu = num_cu       # None = the device's 256 CUs (tests shrink it to reach split-K paths)
         self.params: Dict[str, List[np.ndarray]] = {}
         self._param_dev: Dict[str, dict] = {}    # layer name -> device-side state
