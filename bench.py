@@ -63,6 +63,8 @@ def main() -> None:
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the configs[3] / configs[4] legs a default single-GPU run appends as `extra_configs`")
     ap.add_argument("--extra-steps", type=int, default=10)
+    ap.add_argument("--extra-parity-few", action="store_true",
+                    help="extra_configs: check only the 2 / 4 sample clips against the CPU reference, not every clip of the batch")
     args = ap.parse_args()
 
     import numpy as np
@@ -325,7 +327,8 @@ def main() -> None:
         for key, kw in (("configs3", dict(variant="full", N=16, dtype="f32")),
                         ("configs4", dict(variant="lite", N=32, dtype="bf16"))):
             try:
-                extra[key] = extra_config(kw["variant"], kw["N"], B, kw["dtype"], args.extra_steps, dev)
+                extra[key] = extra_config(kw["variant"], kw["N"], B, kw["dtype"], args.extra_steps, dev,
+                                          all_parity=not args.extra_parity_few)
             except Exception as e:  # the headline line must survive a failing side leg
                 extra[key] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
@@ -488,7 +491,27 @@ def parity_record(got, ref, dtype: str, what: str, clips=None) -> dict:
     return rec
 
 
-def extra_config(variant: str, N: int, B: int, dtype: str, steps: int, dev) -> dict:
+def reference_logits_batch(gen, N, B, frames, params):
+    """fp32 CPU reference logits of ALL B clips of `frames` in one forward: the oracle's layer sequence with every convolution through
+    the compiled reference im2col + one OpenBLAS sgemm per image, images spread over host threads (checker only)."""
+    from eco_amd.netspec import NetSpec
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import eco_oracle  # checker only; never on the product path
+    import eco_ref
+    if not eco_ref.available():
+        raise RuntimeError("oracle/_ref is not built")
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    img_threads = min(cores, 64)   # OpenBLAS keeps one buffer per concurrent caller, at most its NUM_THREADS (64)
+    eco_ref.set_blas_threads(min(cores, 64))
+    specB = NetSpec.from_prototxt(gen(num_segments=N, num_clips=B))
+    return eco_oracle.forward(specB, params, {"data": frames[:B * N]},
+                              conv_impl=lambda *a: eco_ref.convolution(*a, image_threads=img_threads))[specB.outputs[0]]
+
+
+def extra_config(variant: str, N: int, B: int, dtype: str, steps: int, dev, all_parity: bool = True) -> dict:
     """One of the other single-GPU BASELINE.json configurations on the same device: `steps` timed steps between
     device synchronisations (wall clock over the whole run, three warm-up steps, no per-step events), the per-launch floors
     of Engine.profile, and clips of the batch against the CPU reference: first / two in the middle / last for the bf16
@@ -525,8 +548,20 @@ def extra_config(variant: str, N: int, B: int, dtype: str, steps: int, dev) -> d
     dom = max(fam.items(), key=lambda kv: kv[1])
     clips = [0, B // 3, (2 * B) // 3, B - 1] if dtype == "bf16" else [0, B - 1]
     clips = sorted(set(c for c in clips if 0 <= c < B))
-    got = net.blobs[spec.outputs[0]].tensor.detach().float().cpu().numpy()[clips]
+    got_all = net.blobs[spec.outputs[0]].tensor.detach().float().cpu().numpy()
+    got = got_all[clips]
     ref = reference_logits(gen, N, frames, params, clips=clips)
+    # ... and EVERY clip of the batch against the reference's im2col + sgemm call sequence with the batch's images spread over the
+    # host cores (the arithmetic of bench.py's `image_parallel` CPU leg, pinned bit-identically to the compiled ConvolutionLayer
+    # class in tests/test_oracle_ref.py): one CPU forward of the whole batch, 15-30 s
+    all_clips = None
+    if all_parity:
+        try:
+            all_clips = parity_record(got_all, reference_logits_batch(gen, N, B, frames, params), dtype,
+                                      "reference im2col (compiled from util/im2col.cpp) + OpenBLAS sgemm, the batch's images spread "
+                                      "over host threads; all clips of the batch", list(range(B)))
+        except Exception as e:  # the leg must survive a failing whole-batch reference (memory, missing oracle/_ref, ...)
+            all_clips = {"error": f"{type(e).__name__}: {e}"}
     name = "Lite" if variant == "lite" else "Full"
     out = {"workload": "ECO-%s num_segments=%d batch=%d %s (%s)" % (name, N, B, dtype, baseline_config(variant, N, B, dtype, 1)),
            "steps": steps, "ms_per_step": round(ms, 3), "clips_per_s": round(B * 1e3 / ms, 1), "dtype": dtype,
@@ -542,6 +577,14 @@ def extra_config(variant: str, N: int, B: int, dtype: str, steps: int, dev) -> d
     out["top1_equal"] = out["parity"]["top1_equal"]
     out["top1_equal_or_reference_near_tie"] = out["parity"]["top1_equal_or_reference_near_tie"]
     out["max_rel_err"] = out["parity"]["max_rel_err"]
+    if all_clips is not None:
+        out["parity_all_clips"] = all_clips
+        if "max_rel_err" in all_clips:   # the top-level figures speak for the whole batch when it was checked
+            out["clips_checked"] = all_clips["clips_checked"]
+            out["max_rel_err"] = max(out["max_rel_err"], all_clips["max_rel_err"])
+            out["top1_equal"] = bool(out["top1_equal"] and all_clips["top1_equal"])
+            out["top1_equal_or_reference_near_tie"] = bool(out["top1_equal_or_reference_near_tie"] and
+                                                            all_clips["top1_equal_or_reference_near_tie"])
     del net
     return out
 
